@@ -1,0 +1,58 @@
+"""Build libcsm_hip.so (gfx950) in-tree with hipcc.  No torch involvement: the library is a plain C-ABI
+shared object (include/csm_hip.h).  `python -m csm_hf_amd.build` or `build_library()`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libcsm_hip.so")
+UNITS = ["gemv", "launchers", "engine"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _sources_mtime() -> float:
+    m = os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "csm_hip.h"))
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".h")):
+            m = max(m, os.path.getmtime(os.path.join(CSRC, f)))
+    return m
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _sources_mtime():
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_one(u):
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(OBJ, u + ".o")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {u}.hip:\n{r.stderr[-4000:]}")
+        if verbose:
+            print(f"[build] {u}.o", file=sys.stderr)
+
+    with ThreadPoolExecutor(len(UNITS)) as ex:
+        list(ex.map(compile_one, UNITS))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(OBJ, u + ".o") for u in UNITS], "-o", LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

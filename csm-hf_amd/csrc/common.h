@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CSM_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic is done in fp32
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (finite inputs; NaN stays NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// Load 8 consecutive weights as fp32.  bf16: one 16-byte load; fp32: two.
+template <typename WT>
+struct W8;
+template <>
+struct W8<bf16_t> {
+  u32x4 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void load_nt(const bf16_t* p) {
+    r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  }
+  __device__ __forceinline__ void zero() { r = (u32x4)(0u); }
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t u = r[i >> 1];
+    return (i & 1) ? bf16_hi(u) : bf16_lo(u);
+  }
+};
+template <>
+struct W8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void load_nt(const float* p) {
+    a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+  }
+  __device__ __forceinline__ void zero() { a = (f32x4)(0.f); b = (f32x4)(0.f); }
+  __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_kv(bf16_t* p, float v) { *p = f32_to_bf16(v); }

@@ -1,0 +1,703 @@
+// libcsm_hip.so -- engine + C ABI (include/csm_hip.h).  Orchestrates the gfx950 kernels of gemv.h,
+// attn.h, gemm.h, misc.h into the three phases of the reference's generate():
+//   prefill        = CSMModel.forward on the context         (modeling_csm.py:321-365)
+//   decode_frame   = generate_frame after its forward        (modeling_csm.py:522-589)
+//   backbone_step  = the forward of the next generate_frame  (modeling_csm.py:508-520, S = 1)
+// decode_frame + backbone_step are captured once into a hipGraph and replayed per frame; the frame
+// index and the backbone length live in device memory so a replay takes no parameters.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/csm_hip.h"
+#define CSM_ARGS_ONLY 1  // kernel definitions live in gemv.hip / launchers.hip
+#include "attn.h"
+#include "gemm.h"
+#include "gemv.h"
+#include "misc.h"
+
+int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a);
+int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
+                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add);
+int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
+int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
+int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
+int launch_set_int(hipStream_t st, int* p, int v);
+int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
+int gemv_configure_all();
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCK(x)                                                                              \
+  do {                                                                                        \
+    hipError_t _e = (x);                                                                      \
+    if (_e != hipSuccess) return fail((int)_e, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define LCK(x)                                                                                \
+  do {                                                                                        \
+    int _e = (x);                                                                             \
+    if (_e != 0) return fail(_e > 0 ? _e : CSM_ERR_ARG, "%s failed with %d (%s:%d)", #x, _e, __FILE__, __LINE__); \
+  } while (0)
+
+struct Stack {
+  csm_llama_cfg_t c{};
+  std::vector<csm_layer_weights_t> layers;
+  const float* final_norm = nullptr;
+  const float* cos = nullptr;
+  const float* sin = nullptr;
+  int rope_positions = 0;
+  std::vector<void*> kc, vc;
+  int lmax = 0;
+  int nqkv() const { return (c.n_q + 2 * c.n_kv) * c.head_dim; }
+};
+
+struct GraphKey {
+  int B, topk;
+  float temperature;
+  uint64_t seed;
+  const void *noise, *forced, *ltrace, *htrace;
+  bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+struct csm_engine {
+  csm_config_t cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  csm_weights_t w{};
+  bool bound = false;
+  Stack bb, dec;
+  int esz_kv = 4;
+  // device state
+  int* d_len = nullptr;
+  int* d_frame = nullptr;
+  int* d_kv_start = nullptr;
+  int64_t* ring = nullptr;
+  // decode scratch
+  float *q_bb = nullptr, *att_bb = nullptr, *part_bb = nullptr, *act_bb = nullptr, *h_bb = nullptr;
+  float* head_out = nullptr;  // [B][ld_head]: [0,Hd) decoder pos-0 input, [Hd, Hd+V) codebook-0 logits
+  int ld_head = 0;
+  float *dec_x = nullptr, *q_dec = nullptr, *att_dec = nullptr, *act_dec = nullptr, *logits_dec = nullptr;
+  float* last_h = nullptr;
+  int64_t* ids_stage = nullptr;
+  uint8_t* mask_stage = nullptr;
+  // prefill scratch
+  float *p_h = nullptr, *p_xn = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_att = nullptr, *p_act = nullptr;
+  int *p_row_seq = nullptr, *p_row_pos = nullptr;
+  // host mirrors
+  int B = 0;
+  int h_len = 0, h_frame = 0;
+  bool ready = false;   // head_out holds valid c0 logits
+  int nsplit_bb = 1;
+  int nt_backbone = 1, nt_decoder = 0;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  std::vector<void*> allocs;
+};
+
+template <typename T>
+static int dalloc(csm_engine* e, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t r = hipMalloc(&q, n * sizeof(T) + 256);
+  if (r != hipSuccess) return fail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(r));
+  e->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+extern "C" const char* csm_last_error(void) { return g_err; }
+extern "C" int csm_abi_version(void) { return CSM_ABI_VERSION; }
+
+static int check_stack(const csm_llama_cfg_t& c, const char* name) {
+  if (c.hidden % 8 || c.ffn % 8 || c.layers < 1) return fail(CSM_ERR_ARG, "%s: hidden/ffn must be multiples of 8", name);
+  if (c.head_dim != 64 && c.head_dim != 128) return fail(CSM_ERR_ARG, "%s: head_dim must be 64 or 128, got %d", name, c.head_dim);
+  if (c.n_q % c.n_kv || c.n_q / c.n_kv > 16) return fail(CSM_ERR_ARG, "%s: unsupported GQA ratio", name);
+  return 0;
+}
+
+extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stream, csm_engine_t** out) {
+  if (!cfg || !out) return fail(CSM_ERR_ARG, "null argument");
+  if (cfg->abi_version != CSM_ABI_VERSION) return fail(CSM_ERR_ARG, "ABI version mismatch: %d vs %d", cfg->abi_version, CSM_ABI_VERSION);
+  if (int r = check_stack(cfg->backbone, "backbone")) return r;
+  if (int r = check_stack(cfg->decoder, "decoder")) return r;
+  if (cfg->max_batch < 1 || cfg->max_len < 1 || cfg->max_frames < 1 || cfg->max_prefill_rows < 1)
+    return fail(CSM_ERR_ARG, "max_batch/max_len/max_frames/max_prefill_rows must be >= 1");
+  if (cfg->n_codebooks < 2) return fail(CSM_ERR_ARG, "n_codebooks must be >= 2");
+  HIPCK(hipSetDevice(device));
+  LCK(gemv_configure_all());
+  csm_engine* e = new csm_engine();
+  e->cfg = *cfg;
+  e->device = device;
+  if (stream) {
+    e->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  HIPCK(hipEventCreate(&e->ev0));
+  HIPCK(hipEventCreate(&e->ev1));
+  e->bb.c = cfg->backbone;
+  e->dec.c = cfg->decoder;
+  e->esz_kv = cfg->kv_dtype == CSM_DTYPE_BF16 ? 2 : 4;
+  const int B = cfg->max_batch, C = cfg->n_codebooks, V = cfg->audio_vocab;
+  const int Hb = cfg->backbone.hidden, Hd = cfg->decoder.hidden;
+  int r;
+  // KV caches: +64 positions of slack so 16-byte tail reads of the last tile stay in bounds
+  e->bb.lmax = cfg->max_len;
+  e->dec.lmax = C;
+  for (Stack* s : {&e->bb, &e->dec}) {
+    const size_t per = (size_t)B * s->c.n_kv * s->lmax * s->c.head_dim * e->esz_kv;
+    for (int l = 0; l < s->c.layers; ++l) {
+      char *k = nullptr, *v = nullptr;
+      if ((r = dalloc(e, &k, per))) return r;
+      if ((r = dalloc(e, &v, per))) return r;
+      HIPCK(hipMemsetAsync(k, 0, per, e->stream));
+      HIPCK(hipMemsetAsync(v, 0, per, e->stream));
+      s->kc.push_back(k);
+      s->vc.push_back(v);
+    }
+  }
+  if ((r = dalloc(e, &e->d_len, 1)) || (r = dalloc(e, &e->d_frame, 1)) || (r = dalloc(e, &e->d_kv_start, (size_t)B)))
+    return r;
+  if ((r = dalloc(e, &e->ring, (size_t)B * cfg->max_frames * C))) return r;
+  HIPCK(hipMemsetAsync(e->ring, 0, (size_t)B * cfg->max_frames * C * sizeof(int64_t), e->stream));
+  HIPCK(hipMemsetAsync(e->d_kv_start, 0, B * sizeof(int), e->stream));
+  e->ld_head = (Hd + V + 3) & ~3;
+  const int nqb = cfg->backbone.n_q * cfg->backbone.head_dim, nqd = cfg->decoder.n_q * cfg->decoder.head_dim;
+  if ((r = dalloc(e, &e->h_bb, (size_t)B * Hb)) || (r = dalloc(e, &e->q_bb, (size_t)B * nqb)) ||
+      (r = dalloc(e, &e->att_bb, (size_t)B * nqb)) ||
+      (r = dalloc(e, &e->part_bb, (size_t)B * cfg->backbone.n_q * 64 * (cfg->backbone.head_dim + 2))) ||
+      (r = dalloc(e, &e->act_bb, (size_t)B * cfg->backbone.ffn)) || (r = dalloc(e, &e->head_out, (size_t)B * e->ld_head)) ||
+      (r = dalloc(e, &e->dec_x, (size_t)B * Hd)) || (r = dalloc(e, &e->q_dec, (size_t)B * nqd)) ||
+      (r = dalloc(e, &e->att_dec, (size_t)B * nqd)) || (r = dalloc(e, &e->act_dec, (size_t)B * cfg->decoder.ffn)) ||
+      (r = dalloc(e, &e->logits_dec, (size_t)B * ((V + 3) & ~3))) || (r = dalloc(e, &e->last_h, (size_t)B * Hb)) ||
+      (r = dalloc(e, &e->ids_stage, (size_t)B * (C + 1))) || (r = dalloc(e, &e->mask_stage, (size_t)B * (C + 1))))
+    return r;
+  const size_t R = cfg->max_prefill_rows;
+  if ((r = dalloc(e, &e->p_h, R * Hb)) || (r = dalloc(e, &e->p_xn, R * Hb)) ||
+      (r = dalloc(e, &e->p_qkv, R * e->bb.nqkv())) || (r = dalloc(e, &e->p_q, R * nqb)) ||
+      (r = dalloc(e, &e->p_att, R * nqb)) || (r = dalloc(e, &e->p_act, R * cfg->backbone.ffn)) ||
+      (r = dalloc(e, &e->p_row_seq, R)) || (r = dalloc(e, &e->p_row_pos, R)))
+    return r;
+  LCK(launch_set_int(e->stream, e->d_len, 0));
+  LCK(launch_set_int(e->stream, e->d_frame, 0));
+  HIPCK(hipStreamSynchronize(e->stream));
+  *out = e;
+  return 0;
+}
+
+static void drop_graphs(csm_engine* e) {
+  for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+  e->graphs.clear();
+}
+
+extern "C" int csm_engine_destroy(csm_engine_t* e) {
+  if (!e) return 0;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  drop_graphs(e);
+  for (void* p : e->allocs) hipFree(p);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+
+static int bind_stack(Stack& s, const csm_stack_weights_t& w, const char* name) {
+  if (!w.layers || !w.final_norm || !w.rope_cos || !w.rope_sin) return fail(CSM_ERR_ARG, "%s: null weight pointer", name);
+  s.layers.assign(w.layers, w.layers + s.c.layers);
+  for (auto& l : s.layers)
+    if (!l.wqkv || !l.wo || !l.wgu || !l.wd || !l.ln1 || !l.ln2) return fail(CSM_ERR_ARG, "%s: null layer weight", name);
+  s.final_norm = w.final_norm;
+  s.cos = w.rope_cos;
+  s.sin = w.rope_sin;
+  s.rope_positions = w.rope_positions;
+  if (s.rope_positions < s.lmax) return fail(CSM_ERR_ARG, "%s: RoPE table covers %d positions, cache needs %d", name, s.rope_positions, s.lmax);
+  return 0;
+}
+
+extern "C" int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w) {
+  if (!e || !w) return fail(CSM_ERR_ARG, "null argument");
+  if (!w->text_emb || !w->audio_emb || !w->proj_head0 || !w->audio_head_t) return fail(CSM_ERR_ARG, "null top-level weight");
+  if (int r = bind_stack(e->bb, w->backbone, "backbone")) return r;
+  if (int r = bind_stack(e->dec, w->decoder, "decoder")) return r;
+  e->w = *w;
+  e->w.backbone.layers = e->bb.layers.data();
+  e->w.decoder.layers = e->dec.layers.data();
+  e->bound = true;
+  drop_graphs(e);
+  return 0;
+}
+
+extern "C" int csm_set_proj_table(csm_engine_t* e, const float* t) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  e->w.proj_table = t;
+  drop_graphs(e);
+  return 0;
+}
+
+extern "C" int csm_reset(csm_engine_t* e) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  LCK(launch_set_int(e->stream, e->d_len, 0));
+  LCK(launch_set_int(e->stream, e->d_frame, 0));
+  HIPCK(hipMemsetAsync(e->d_kv_start, 0, e->cfg.max_batch * sizeof(int), e->stream));
+  e->h_len = e->h_frame = 0;
+  e->ready = false;
+  e->B = 0;
+  return 0;
+}
+
+extern "C" int csm_set_kv_start(csm_engine_t* e, const int32_t* kv_start_host, int B) {
+  if (!e || !kv_start_host || B < 1 || B > e->cfg.max_batch) return fail(CSM_ERR_ARG, "bad kv_start arguments");
+  HIPCK(hipMemcpyAsync(e->d_kv_start, kv_start_host, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
+  if (!e || !name) return fail(CSM_ERR_ARG, "null argument");
+  if (!strcmp(name, "nt_backbone")) e->nt_backbone = value;
+  else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value;
+  else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 1 ? 1 : (value > 64 ? 64 : value);
+  else return fail(CSM_ERR_ARG, "unknown option %s", name);
+  drop_graphs(e);
+  return 0;
+}
+
+// ---- decode-side GEMV with row grouping (M <= 4 per launch) -----------------------------------------
+static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
+  const float* x = a.x;
+  float* out = a.out;
+  float* q = a.qbuf;
+  const int* rs = a.row_seq;
+  const int* rp = a.row_pos;
+  int* ba = a.bump_a;
+  int* bbp = a.bump_b;
+  for (int m0 = 0; m0 < M; m0 += 4) {
+    const int m = (M - m0) < 4 ? (M - m0) : 4;
+    a.x = x + (size_t)m0 * a.ldx;
+    a.out = out ? out + (size_t)m0 * a.ldo : nullptr;
+    a.qbuf = q ? q + (size_t)m0 * a.n_q * a.hd : nullptr;
+    a.row_seq = rs ? rs + m0 : nullptr;
+    a.row_pos = rp ? rp + m0 : nullptr;
+    a.seq_base = m0;
+    const bool last = m0 + 4 >= M;
+    a.bump_a = last ? ba : nullptr;
+    a.bump_b = last ? bbp : nullptr;
+    int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
+    if (r) return r;
+  }
+  return 0;
+}
+
+// one Llama layer on M single-token rows (decode)
+static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
+                        float* qb, float* att, float* part, int nsplit, float* act, int nt) {
+  const csm_layer_weights_t& w = s.layers[l];
+  const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
+  GemvArgs a{};
+  a.nt = nt;
+  a.W = w.wqkv; a.N = s.nqkv(); a.K = H; a.x = h; a.ldx = ldh; a.ln = w.ln1; a.eps = s.c.rms_eps;
+  a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
+  a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
+  a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
+  LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
+
+  AttnArgs t{};
+  t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+  t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
+  t.nsplit = nsplit; t.out = att; t.part = part;
+  LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
+
+  GemvArgs o{};
+  o.nt = nt;
+  o.W = w.wo; o.N = H; o.K = nq * hd; o.x = att; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
+  LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
+
+  GemvArgs g{};
+  g.nt = nt;
+  g.W = w.wgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
+  LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
+
+  GemvArgs d{};
+  d.nt = nt;
+  d.W = w.wd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
+  LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
+  return 0;
+}
+
+// final norm + [projection ; codebook0_head] on the backbone residual rows -> head_out
+static int backbone_head(csm_engine* e, const float* h, int ldh, int M, bool bump_len, bool bump_frame) {
+  GemvArgs a{};
+  a.nt = e->nt_backbone;
+  a.W = e->w.proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = e->cfg.backbone.hidden;
+  a.x = h; a.ldx = ldh; a.ln = e->bb.final_norm; a.eps = e->bb.c.rms_eps; a.out = e->head_out; a.ldo = e->ld_head;
+  if (bump_len) {
+    a.bump_a = e->d_len;
+    a.bump_b = bump_frame ? e->d_frame : nullptr;
+  } else if (bump_frame) {
+    a.bump_a = e->d_frame;
+  }
+  return gemv_rows(e, M, PRO_NORM, EPI_STORE, a);
+}
+
+static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_ids, bool advance_frame, bool want_last_h) {
+  const int B = e->B, Hb = e->cfg.backbone.hidden;
+  EmbedArgs em{};
+  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
+  if (from_ids) {
+    em.ids = e->ids_stage;
+    em.mask = e->mask_stage;
+  } else {
+    em.ring = (s && s->forced) ? s->forced : e->ring;
+    em.frame_ptr = e->d_frame;
+    em.max_frames = e->cfg.max_frames;
+  }
+  em.out = e->h_bb;
+  LCK(launch_embed(e->stream, e->cfg.weight_dtype, B, em));
+  for (int l = 0; l < e->bb.c.layers; ++l)
+    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_bb, e->act_bb, e->nt_backbone));
+  if (want_last_h) {
+    LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
+    if (s && s->last_h_trace)
+      LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, s->last_h_trace, Hb, e->d_frame,
+                         (size_t)B * Hb, advance_frame ? 1 : 0));
+  }
+  LCK(backbone_head(e, e->h_bb, Hb, B, true, advance_frame));
+  return 0;
+}
+
+static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
+  const int B = e->B, C = e->cfg.n_codebooks, V = e->cfg.audio_vocab, Hd = e->cfg.decoder.hidden;
+  auto sample = [&](int cb, const float* logits, int ldl) -> int {
+    SampleArgs a{};
+    a.logits = logits; a.ldl = ldl; a.V = V; a.temperature = s->temperature; a.topk = s->topk; a.seed = s->seed;
+    if (s->noise) {
+      a.noise = s->noise + (size_t)cb * V;
+      a.noise_ld = (size_t)C * V;
+    }
+    a.cb = cb; a.C = C; a.B = B; a.frame_ptr = e->d_frame; a.max_frames = e->cfg.max_frames;
+    a.ring = e->ring; a.forced = s->forced; a.proj_table = e->w.proj_table; a.Hd = Hd; a.dec_x = e->dec_x;
+    a.logits_trace = s->logits_trace;
+    return launch_sample(e->stream, B, a);
+  };
+  LCK(sample(0, e->head_out + Hd, e->ld_head));
+  for (int p = 0; p < C; ++p) {
+    float* h = p == 0 ? e->head_out : e->dec_x;
+    const int ldh = p == 0 ? e->ld_head : Hd;
+    for (int l = 0; l < e->dec.c.layers; ++l)
+      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder));
+    if (p >= 1) {
+      GemvArgs a{};
+      a.nt = e->nt_backbone;  // each audio_head slice is read once per frame
+      a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4);
+      a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
+      a.out = e->logits_dec; a.ldo = (V + 3) & ~3;
+      LCK(gemv_rows(e, B, PRO_NORM, EPI_STORE, a));
+      LCK(sample(p, e->logits_dec, (V + 3) & ~3));
+    }
+  }
+  return 0;
+}
+
+static int check_ready(csm_engine* e, const csm_sampling_t* s) {
+  if (!e || !s) return fail(CSM_ERR_ARG, "null argument");
+  if (!e->bound || !e->w.proj_table) return fail(CSM_ERR_STATE, "weights / projection table not bound");
+  if (!e->ready) return fail(CSM_ERR_STATE, "no codebook-0 logits pending: call csm_prefill or csm_backbone_step first");
+  if (s->topk < 1) return fail(CSM_ERR_ARG, "topk must be >= 1 (selected index k out of range)");
+  if (s->topk > e->cfg.audio_vocab) return fail(CSM_ERR_ARG, "selected index k out of range (topk %d > vocab %d)", s->topk, e->cfg.audio_vocab);
+  return 0;
+}
+
+extern "C" int csm_decode_frame(csm_engine_t* e, const csm_sampling_t* s) {
+  if (int r = check_ready(e, s)) return r;
+  if (e->h_frame >= e->cfg.max_frames) return fail(CSM_ERR_CAPACITY, "frame ring full (%d)", e->cfg.max_frames);
+  LCK(decode_frame_impl(e, s));
+  e->ready = false;
+  return 0;
+}
+
+extern "C" int csm_backbone_step(csm_engine_t* e, const csm_sampling_t* s) {
+  if (!e || !e->bound) return fail(CSM_ERR_STATE, "weights not bound");
+  if (e->B < 1) return fail(CSM_ERR_STATE, "no active batch: call csm_prefill first");
+  if (e->h_len >= e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "KV cache full (%d positions)", e->cfg.max_len);
+  LCK(backbone_step_impl(e, s, false, true, true));
+  e->h_len++;
+  e->h_frame++;
+  e->ready = true;
+  return 0;
+}
+
+extern "C" int csm_backbone_step_ids(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int advance_frame) {
+  if (!e || !e->bound || !ids) return fail(CSM_ERR_STATE, "weights not bound / null ids");
+  if (B < 1 || B > e->cfg.max_batch || (e->B && B != e->B)) return fail(CSM_ERR_ARG, "batch %d does not match active batch %d", B, e->B);
+  if (e->h_len >= e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "KV cache full (%d positions)", e->cfg.max_len);
+  e->B = B;
+  const int C1 = e->cfg.n_codebooks + 1;
+  HIPCK(hipMemcpyAsync(e->ids_stage, ids, (size_t)B * C1 * sizeof(int64_t), hipMemcpyDeviceToDevice, e->stream));
+  if (mask) HIPCK(hipMemcpyAsync(e->mask_stage, mask, (size_t)B * C1, hipMemcpyDeviceToDevice, e->stream));
+  else HIPCK(hipMemsetAsync(e->mask_stage, 1, (size_t)B * C1, e->stream));
+  LCK(backbone_step_impl(e, nullptr, true, advance_frame != 0, true));
+  e->h_len++;
+  if (advance_frame) e->h_frame++;
+  e->ready = true;
+  return 0;
+}
+
+extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, float* last_h_out,
+                           float* c0_logits_out) {
+  if (!e || !e->bound || !ids) return fail(CSM_ERR_STATE, "weights not bound / null ids");
+  if (B < 1 || B > e->cfg.max_batch || S < 1) return fail(CSM_ERR_ARG, "bad batch/sequence (%d, %d)", B, S);
+  if (e->B && B != e->B) return fail(CSM_ERR_ARG, "batch %d does not match active batch %d (call csm_reset)", B, e->B);
+  const size_t R = (size_t)B * S;
+  if (R > (size_t)e->cfg.max_prefill_rows) return fail(CSM_ERR_CAPACITY, "B*S = %zu exceeds max_prefill_rows %d", R, e->cfg.max_prefill_rows);
+  if (e->h_len + S > e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "context %d + %d exceeds max_len %d", e->h_len, S, e->cfg.max_len);
+  e->B = B;
+  Stack& s = e->bb;
+  const int Hb = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
+  const int wd = e->cfg.weight_dtype;
+  LCK(launch_rows_iota(e->stream, e->p_row_seq, e->p_row_pos, (int)R, S, e->h_len));
+  EmbedArgs em{};
+  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
+  em.ids = ids; em.mask = mask; em.out = e->p_h;
+  LCK(launch_embed(e->stream, wd, (int)R, em));
+  for (int l = 0; l < s.c.layers; ++l) {
+    const csm_layer_weights_t& w = s.layers[l];
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
+    GemmArgs g{};
+    g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
+    LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
+    RopeArgs ra{};
+    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
+    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
+    ra.qbuf = e->p_q; ra.kcache = s.kc[l]; ra.vcache = s.vc[l]; ra.lmax = s.lmax;
+    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    AttnArgs t{};
+    t.q = e->p_q; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+    t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = e->d_kv_start; t.nsplit = 1; t.out = e->p_att;
+    LCK(launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t));
+    GemmArgs o{};
+    o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
+    LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
+    GemmArgs gu{};
+    gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
+    LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
+    GemmArgs d{};
+    d.A = e->p_act; d.lda = F; d.W = w.wd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
+    LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
+  }
+  // last position of every sequence: rows b*S + S-1
+  const float* hl = e->p_h + (size_t)(S - 1) * Hb;
+  const int ldl = S * Hb;
+  LCK(launch_rmsnorm(e->stream, hl, ldl, s.final_norm, B, Hb, s.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
+  LCK(launch_set_int(e->stream, e->d_len, e->h_len + S));
+  LCK(backbone_head(e, hl, ldl, B, false, false));
+  e->h_len += S;
+  e->ready = true;
+  if (last_h_out) HIPCK(hipMemcpyAsync(last_h_out, e->last_h, (size_t)B * Hb * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+  if (c0_logits_out)
+    HIPCK(hipMemcpy2DAsync(c0_logits_out, e->cfg.audio_vocab * sizeof(float), e->head_out + e->cfg.decoder.hidden,
+                           e->ld_head * sizeof(float), e->cfg.audio_vocab * sizeof(float), B, hipMemcpyDeviceToDevice, e->stream));
+  return 0;
+}
+
+extern "C" int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logits_out) {
+  if (!e || e->B < 1) return fail(CSM_ERR_STATE, "no active batch");
+  const int B = e->B;
+  if (last_h_out)
+    HIPCK(hipMemcpyAsync(last_h_out, e->last_h, (size_t)B * e->cfg.backbone.hidden * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+  if (c0_logits_out)
+    HIPCK(hipMemcpy2DAsync(c0_logits_out, e->cfg.audio_vocab * sizeof(float), e->head_out + e->cfg.decoder.hidden,
+                           e->ld_head * sizeof(float), e->cfg.audio_vocab * sizeof(float), B, hipMemcpyDeviceToDevice, e->stream));
+  return 0;
+}
+
+extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_frames, int use_graph) {
+  if (int r = check_ready(e, s)) return r;
+  if (n_frames < 0) return fail(CSM_ERR_ARG, "n_frames < 0");
+  if (e->h_frame + n_frames > e->cfg.max_frames) return fail(CSM_ERR_CAPACITY, "frame ring too small: %d + %d > %d", e->h_frame, n_frames, e->cfg.max_frames);
+  if (e->h_len + n_frames > e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "KV cache too small: %d + %d > %d", e->h_len, n_frames, e->cfg.max_len);
+  const bool want_h = s->last_h_trace != nullptr;
+  HIPCK(hipEventRecord(e->ev0, e->stream));
+  if (use_graph && n_frames > 0) {
+    GraphKey k{};
+    k.B = e->B; k.topk = s->topk; k.temperature = s->temperature; k.seed = s->seed;
+    k.noise = s->noise; k.forced = s->forced; k.ltrace = s->logits_trace; k.htrace = s->last_h_trace;
+    auto it = e->graphs.find(k);
+    if (it == e->graphs.end()) {
+      hipGraph_t g = nullptr;
+      HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      int r = decode_frame_impl(e, s);
+      if (!r) r = backbone_step_impl(e, s, false, true, want_h);
+      hipError_t ce = hipStreamEndCapture(e->stream, &g);
+      if (r) {
+        if (g) hipGraphDestroy(g);
+        return r;
+      }
+      HIPCK(ce);
+      hipGraphExec_t ge = nullptr;
+      HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      HIPCK(hipGraphDestroy(g));
+      it = e->graphs.emplace(k, ge).first;
+    }
+    for (int i = 0; i < n_frames; ++i) HIPCK(hipGraphLaunch(it->second, e->stream));
+  } else {
+    for (int i = 0; i < n_frames; ++i) {
+      LCK(decode_frame_impl(e, s));
+      LCK(backbone_step_impl(e, s, false, true, want_h));
+    }
+  }
+  HIPCK(hipEventRecord(e->ev1, e->stream));
+  e->h_len += n_frames;
+  e->h_frame += n_frames;
+  return 0;
+}
+
+extern "C" int csm_last_generate_ms(csm_engine_t* e, float* ms_host) {
+  if (!e || !ms_host) return fail(CSM_ERR_ARG, "null argument");
+  HIPCK(hipEventSynchronize(e->ev1));
+  HIPCK(hipEventElapsedTime(ms_host, e->ev0, e->ev1));
+  return 0;
+}
+
+extern "C" int csm_read_frames(csm_engine_t* e, int64_t* frames_out, int first, int n) {
+  if (!e || !frames_out || first < 0 || n < 0 || first + n > e->cfg.max_frames) return fail(CSM_ERR_ARG, "bad frame range");
+  const int C = e->cfg.n_codebooks;
+  if (n == 0) return 0;
+  HIPCK(hipMemcpy2DAsync(frames_out, (size_t)n * C * sizeof(int64_t), e->ring + (size_t)first * C,
+                         (size_t)e->cfg.max_frames * C * sizeof(int64_t), (size_t)n * C * sizeof(int64_t), e->B,
+                         hipMemcpyDeviceToDevice, e->stream));
+  return 0;
+}
+
+extern "C" int csm_frames_done(csm_engine_t* e, int* n_host) {
+  if (!e || !n_host) return fail(CSM_ERR_ARG, "null argument");
+  HIPCK(hipMemcpyAsync(n_host, e->d_frame, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" int csm_cur_len(csm_engine_t* e, int* len_host) {
+  if (!e || !len_host) return fail(CSM_ERR_ARG, "null argument");
+  HIPCK(hipMemcpyAsync(len_host, e->d_len, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+extern "C" int csm_sync(csm_engine_t* e) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// proj_table[r,:] = projection.weight @ audio_emb[r,:], fp32, through the prefill GEMM in row chunks
+extern "C" int csm_build_proj_table(csm_engine_t* e, float* out) {
+  if (!e || !e->bound || !out) return fail(CSM_ERR_STATE, "weights not bound / null output");
+  const int Hb = e->cfg.backbone.hidden, Hd = e->cfg.decoder.hidden;
+  const size_t rows = (size_t)e->cfg.n_codebooks * e->cfg.audio_vocab;
+  const size_t esz = e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4;
+  const size_t chunk = e->cfg.max_prefill_rows;
+  // projection.weight = first Hd rows of proj_head0
+  for (size_t r0 = 0; r0 < rows; r0 += chunk) {
+    const size_t n = rows - r0 < chunk ? rows - r0 : chunk;
+    LCK(launch_widen(e->stream, e->cfg.weight_dtype, (const char*)e->w.audio_emb + r0 * Hb * esz, e->p_xn, n * Hb));
+    GemmArgs g{};
+    g.A = e->p_xn; g.lda = Hb; g.W = e->w.proj_head0; g.R = (int)n; g.N = Hd; g.K = Hb; g.C = out + r0 * Hd; g.ldc = Hd;
+    LCK(launch_gemm(e->stream, e->cfg.weight_dtype, GEPI_STORE, g));
+  }
+  HIPCK(hipStreamSynchronize(e->stream));
+  e->w.proj_table = out;
+  return 0;
+}
+
+// ---- per-kernel entry points (unit parity) -----------------------------------------------------------
+extern "C" int csm_embed_sum(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int rows, float* out) {
+  if (!e || !e->bound) return fail(CSM_ERR_STATE, "weights not bound");
+  EmbedArgs em{};
+  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = e->cfg.backbone.hidden; em.C = e->cfg.n_codebooks;
+  em.V = e->cfg.audio_vocab; em.ids = ids; em.mask = mask; em.out = out;
+  LCK(launch_embed(e->stream, e->cfg.weight_dtype, rows, em));
+  return 0;
+}
+
+extern "C" int csm_rmsnorm(csm_engine_t* e, const float* x, const float* w, int rows, int hidden, float eps, float* out) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  LCK(launch_rmsnorm(e->stream, x, hidden, w, rows, hidden, eps, out, hidden, nullptr, 0, 0));
+  return 0;
+}
+
+extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* x, int M, const float* ln,
+                        float eps, float* y) {
+  if (!e || M < 1 || M > 64) return fail(CSM_ERR_ARG, "bad gemv arguments");
+  GemvArgs a{};
+  a.W = W; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps; a.out = y; a.ldo = N;
+  const int save = e->cfg.weight_dtype;
+  e->cfg.weight_dtype = wdtype;
+  int r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, EPI_STORE, a);
+  e->cfg.weight_dtype = save;
+  if (r) return fail(r > 0 ? r : CSM_ERR_ARG, "gemv launch failed (%d): N=%d K=%d M=%d", r, N, K, M);
+  return 0;
+}
+
+extern "C" int csm_gemm(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* A, int R, float* C) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  GemmArgs g{};
+  g.A = A; g.lda = K; g.W = W; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
+  LCK(launch_gemm(e->stream, wdtype, GEPI_STORE, g));
+  return 0;
+}
+
+extern "C" int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, int V, float temperature, int topk,
+                               uint64_t seed, const float* noise, int32_t* out_idx) {
+  if (!logits || !out_idx) return fail(CSM_ERR_ARG, "null argument");
+  if (topk < 1 || topk > V) return fail(CSM_ERR_ARG, "selected index k out of range");
+  hipStream_t st = e ? e->stream : nullptr;  // engine-less call (module-level sample_topk): null stream
+  SampleArgs a{};
+  a.logits = logits; a.ldl = V; a.V = V; a.temperature = temperature; a.topk = topk; a.seed = seed; a.noise = noise;
+  a.noise_ld = V; a.cb = 0; a.C = 1; a.B = rows; a.max_frames = 1; a.idx_out = out_idx;
+  LCK(launch_sample(st, rows, a));
+  if (!e) HIPCK(hipStreamSynchronize(st));
+  return 0;
+}
+
+extern "C" int csm_attn_decode(csm_engine_t* e, int which, int layer, const float* q, const int32_t* row_seq,
+                               const int32_t* row_pos, int rows, int nsplit, float* out) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  Stack& s = which ? e->dec : e->bb;
+  if (layer < 0 || layer >= s.c.layers) return fail(CSM_ERR_ARG, "bad layer");
+  if (nsplit > 1 && (size_t)rows > (size_t)e->cfg.max_batch) return fail(CSM_ERR_ARG, "split attention limited to max_batch rows");
+  AttnArgs t{};
+  t.q = q; t.kcache = s.kc[layer]; t.vcache = s.vc[layer]; t.n_q = s.c.n_q; t.n_kv = s.c.n_kv; t.hd = s.c.head_dim;
+  t.lmax = s.lmax; t.row_seq = row_seq; t.row_pos = row_pos; t.kv_start = which ? nullptr : e->d_kv_start;
+  t.nsplit = nsplit < 1 ? 1 : nsplit; t.out = out; t.part = e->part_bb;
+  LCK(launch_attn(e->stream, e->cfg.kv_dtype, rows, t));
+  return 0;
+}
+
+// write K/V rows into a layer cache from raw qkv projections (test hook for csm_attn_decode):
+// qkv [rows][(n_q+2n_kv)*hd] -> q_out [rows][n_q*hd] (rotated, scaled) + cache
+extern "C" int csm_rope_scatter(csm_engine_t* e, int which, int layer, const float* qkv, const int32_t* row_seq,
+                                const int32_t* row_pos, int rows, float* q_out) {
+  if (!e || !e->bound) return fail(CSM_ERR_STATE, "weights not bound");
+  Stack& s = which ? e->dec : e->bb;
+  if (layer < 0 || layer >= s.c.layers) return fail(CSM_ERR_ARG, "bad layer");
+  RopeArgs ra{};
+  ra.qkv = qkv; ra.n_q = s.c.n_q; ra.n_kv = s.c.n_kv; ra.hd = s.c.head_dim; ra.qscale = 1.0f / sqrtf((float)s.c.head_dim);
+  ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = row_seq; ra.row_pos = row_pos; ra.qbuf = q_out;
+  ra.kcache = s.kc[layer]; ra.vcache = s.vc[layer]; ra.lmax = s.lmax;
+  LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, rows, ra));
+  return 0;
+}

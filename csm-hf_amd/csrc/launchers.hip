@@ -1,0 +1,108 @@
+// Host launchers for attention / GEMM / misc kernels.
+#include "attn.h"
+#include "gemm.h"
+#include "misc.h"
+
+int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
+  if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
+  if (a.nsplit < 1) return -1;
+  const int grid = rows * a.n_kv * a.nsplit;
+  if (a.hd == 64) {
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(256), 0, st, a);
+  } else if (a.hd == 128) {
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 128>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    return -1;
+  }
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  if (a.nsplit > 1) {
+    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows), dim3(256), 0, st, a.part, a.n_q, a.nsplit, a.out);
+    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows), dim3(256), 0, st, a.part, a.n_q, a.nsplit, a.out);
+    e = (int)hipGetLastError();
+  }
+  return e;
+}
+
+template <typename WT>
+static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
+  const int grid = ((a.R + 127) / 128) * (a.N / 128);
+  switch (epi) {
+    case GEPI_STORE: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_RESID: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_RESID>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_SWIGLU>), dim3(grid), dim3(256), 0, st, a); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
+  if (a.N % 128 != 0 || a.K % 32 != 0 || a.R < 1) return -1;
+  return wdtype == 1 ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_t<float>(st, epi, a);
+}
+
+int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
+  if (a.H % 8 != 0) return -1;
+  if (wdtype == 1) hipLaunchKernelGGL((embed_sum_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((embed_sum_kernel<float>), dim3(rows), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
+                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add) {
+  if (H % 4 != 0) return -1;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, H, eps, out, ldo, frame_ptr,
+                     frame_stride, frame_add);
+  return (int)hipGetLastError();
+}
+
+int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a) {
+  if (kvdtype == 1) hipLaunchKernelGGL((rope_scatter_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((rope_scatter_kernel<float>), dim3(rows), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_sample(hipStream_t st, int rows, const SampleArgs& a) {
+  const size_t lds = (size_t)a.V * sizeof(float);
+  hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+// ---- tiny utility kernels -----------------------------------------------------------------------
+__global__ void rows_iota_kernel(int* row_seq, int* row_pos, int R, int S, int past) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) {
+    row_seq[r] = r / S;
+    row_pos[r] = past + r % S;
+  }
+}
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
+template <typename WT>
+__global__ void widen_rows_kernel(const WT* src, float* dst, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i < n) {
+    W8<WT> w;
+    w.load(src + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[i + e] = w.get(e);
+  }
+}
+
+int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past) {
+  hipLaunchKernelGGL(rows_iota_kernel, dim3((R + 255) / 256), dim3(256), 0, st, row_seq, row_pos, R, S, past);
+  return (int)hipGetLastError();
+}
+int launch_set_int(hipStream_t st, int* p, int v) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, p, v);
+  return (int)hipGetLastError();
+}
+int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n) {
+  if (n % 8) return -1;
+  const int grid = (int)((n / 8 + 255) / 256);
+  if (wdtype == 1) hipLaunchKernelGGL((widen_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n);
+  else hipLaunchKernelGGL((widen_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, dst, n);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,365 @@
+// Small HBM/L2-bound kernels of the path: frame-embedding gather-sum (K1), row RMSNorm (K2, prefill),
+// RoPE + KV scatter for prefill rows (K4/K5), fused sample + feedback (K12/K13).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// K1: out[r,:] = sum_{c<C} mask[r,c] * audio_emb[ids[r,c] + c*V, :] + mask[r,C] * text_emb[ids[r,C], :]
+// Reference: modeling_csm.py:261-282 (_embed_tokens) + :327-334 (mask, sum(dim=2)) -- without the
+// [B,S,33,H] intermediate.  fp32 accumulate in codebook order, one output write.
+// Ring mode (ids == nullptr): row b takes its 32 audio tokens from the on-device frame ring at the
+// current frame index (the frame generate() feeds back, modeling_csm.py:675-687: text column masked).
+// Algorithmic bytes: live_tokens * H * sizeof(WT) read + H*4 written per row.
+// ---------------------------------------------------------------------------------------------------
+struct EmbedArgs {
+  const void* text_emb;
+  const void* audio_emb;
+  int H, C, V;
+  const int64_t* ids;   // [rows][C+1] or nullptr (ring mode)
+  const uint8_t* mask;  // [rows][C+1] or nullptr (all live)
+  const int64_t* ring;  // [B][max_frames][C]
+  const int* frame_ptr;
+  int max_frames;
+  float* out;  // [rows][H]
+};
+
+#ifndef CSM_ARGS_ONLY
+template <typename WT>
+__global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
+  const int row = blockIdx.x;
+  const WT* te = reinterpret_cast<const WT*>(a.text_emb);
+  const WT* ae = reinterpret_cast<const WT*>(a.audio_emb);
+  const int f = a.ids ? 0 : *a.frame_ptr;
+  for (int k = threadIdx.x * 8; k < a.H; k += 256 * 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      int64_t tok;
+      bool live;
+      if (a.ids) {
+        tok = a.ids[(size_t)row * (a.C + 1) + c];
+        live = a.mask ? a.mask[(size_t)row * (a.C + 1) + c] != 0 : true;
+      } else {
+        tok = a.ring[((size_t)row * a.max_frames + f) * a.C + c];
+        live = true;
+      }
+      if (live) {
+        W8<WT> w;
+        w.load(ae + ((size_t)tok + (size_t)c * a.V) * a.H + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += w.get(i);
+      }
+    }
+    if (a.ids) {
+      const bool live = a.mask ? a.mask[(size_t)row * (a.C + 1) + a.C] != 0 : true;
+      if (live) {
+        const int64_t tok = a.ids[(size_t)row * (a.C + 1) + a.C];
+        W8<WT> w;
+        w.load(te + (size_t)tok * a.H + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += w.get(i);
+      }
+    }
+    f32x4 o0 = {acc[0], acc[1], acc[2], acc[3]}, o1 = {acc[4], acc[5], acc[6], acc[7]};
+    *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.H + k) = o0;
+    *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.H + k + 4) = o1;
+  }
+}
+
+#endif  // CSM_ARGS_ONLY
+
+// ---------------------------------------------------------------------------------------------------
+// K2 (stand-alone form, prefill + last_hidden_state): out = w * (x * rsqrt(mean(x^2) + eps))
+// Reference: transformers LlamaRMSNorm.forward (modeling_llama.py:62-67).
+// `frame_ptr`/`frame_stride`/`frame_add`: optional output offset (trace ring) = (*frame_ptr+add)*stride.
+// ---------------------------------------------------------------------------------------------------
+#ifndef CSM_ARGS_ONLY
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, const float* w, int H, float eps,
+                                                      float* out, int ldo, const int* frame_ptr,
+                                                      size_t frame_stride, int frame_add) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * ldx;
+  float* o = out + (size_t)row * ldo;
+  if (frame_ptr) o += (size_t)(*frame_ptr + frame_add) * frame_stride;
+  float ss = 0.f;
+  for (int k = tid * 4; k < H; k += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float sc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  for (int k = tid * 4; k < H; k += 1024) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(w + k);
+    v[0] = (v[0] * sc) * g[0];
+    v[1] = (v[1] * sc) * g[1];
+    v[2] = (v[2] * sc) * g[2];
+    v[3] = (v[3] * sc) * g[3];
+    *reinterpret_cast<f32x4*>(o + k) = v;
+  }
+}
+
+#endif  // CSM_ARGS_ONLY
+
+// ---------------------------------------------------------------------------------------------------
+// K4/K5 for prefill rows: qkv [R][(n_q+2n_kv)*hd] raw projections -> q (RoPE, scaled) and the KV cache.
+// Reference: apply_rotary_pos_emb (modeling_llama.py:130-160), DynamicCache.update (cache_utils.py:144).
+// ---------------------------------------------------------------------------------------------------
+struct RopeArgs {
+  const float* qkv;
+  int n_q, n_kv, hd;
+  float qscale;
+  const float* cos_tab;
+  const float* sin_tab;
+  const int* row_seq;
+  const int* row_pos;
+  float* qbuf;
+  void* kcache;
+  void* vcache;
+  int lmax;
+};
+
+#ifndef CSM_ARGS_ONLY
+template <typename KT>
+__global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
+  const int row = blockIdx.x;
+  const int b = a.row_seq[row], pos = a.row_pos[row];
+  const int half = a.hd >> 1;
+  const int nh = a.n_q + 2 * a.n_kv;
+  const float* src = a.qkv + (size_t)row * nh * a.hd;
+  KT* kc = reinterpret_cast<KT*>(a.kcache);
+  KT* vc = reinterpret_cast<KT*>(a.vcache);
+  for (int p = threadIdx.x; p < nh * half; p += 256) {
+    const int head = p / half, i = p - head * half;
+    if (head < a.n_q + a.n_kv) {
+      const float v0 = src[head * a.hd + i], v1 = src[head * a.hd + i + half];
+      const float c = a.cos_tab[(size_t)pos * half + i], s = a.sin_tab[(size_t)pos * half + i];
+      const float o0 = v0 * c - v1 * s, o1 = v1 * c + v0 * s;
+      if (head < a.n_q) {
+        float* q = a.qbuf + (size_t)row * a.n_q * a.hd + head * a.hd;
+        q[i] = o0 * a.qscale;
+        q[i + half] = o1 * a.qscale;
+      } else {
+        const int j = head - a.n_q;
+        const size_t base = (((size_t)b * a.n_kv + j) * (a.hd >> 2)) * a.lmax;
+        store_kv(kc + (base + (size_t)(i >> 2) * a.lmax + pos) * 4 + (i & 3), o0);
+        const int i2 = i + half;
+        store_kv(kc + (base + (size_t)(i2 >> 2) * a.lmax + pos) * 4 + (i2 & 3), o1);
+      }
+    } else {
+      const int j = head - a.n_q - a.n_kv;
+      KT* vr = vc + (((size_t)b * a.n_kv + j) * a.lmax + pos) * a.hd;
+      store_kv(vr + 2 * i, src[head * a.hd + 2 * i]);
+      store_kv(vr + 2 * i + 1, src[head * a.hd + 2 * i + 1]);
+    }
+  }
+}
+
+#endif  // CSM_ARGS_ONLY
+
+// ---------------------------------------------------------------------------------------------------
+// K12 + K13: sample one codebook from a logits row and feed it back.
+// Reference: sample_topk / _multinomial_sample_one_no_sync (modeling_csm.py:170-189):
+//   x = logits / T; kth = k-th largest; x[x < kth] = -inf (ties at kth survive);
+//   p = softmax(log_softmax(x)); q ~ Exp(1) per vocabulary entry; idx = argmax(p / q) (first max).
+// Greedy (topk == 1, or T == 0 which the reference cannot do) = argmax, lowest index on exact ties.
+// Then (modeling_csm.py:535,542 / 564-565): next decoder input = projection(audio_emb[tok + cb*V]),
+// served from the precomputed fp32 table `proj_table`.
+// One workgroup per row; wavefront shuffles for the reductions; 8-bit radix select for the k-th value.
+// ---------------------------------------------------------------------------------------------------
+struct SampleArgs {
+  const float* logits;  // [rows][ldl]
+  int ldl, V;
+  float temperature;
+  int topk;
+  uint64_t seed;
+  const float* noise;  // nullable, [rows][noise_ld] (already offset to this codebook)
+  size_t noise_ld;
+  int cb, C, B;
+  const int* frame_ptr;  // nullable (standalone call)
+  int max_frames;
+  int64_t* ring;          // [B][max_frames][C] nullable
+  const int64_t* forced;  // [B][max_frames][C] nullable
+  int32_t* idx_out;       // [rows] nullable
+  const float* proj_table;  // [C*V][Hd] nullable
+  int Hd;
+  float* dec_x;         // [rows][Hd]
+  float* logits_trace;  // [max_frames][B][C][V] nullable
+};
+
+#ifndef CSM_ARGS_ONLY
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ uint32_t f32_key(float x) {  // monotone float -> uint map
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// block-wide argmax with lowest-index tie-break; result broadcast through LDS
+__device__ __forceinline__ int block_argmax(float v, int idx, float* s_val, int* s_idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = idx; }
+  __syncthreads();
+  float bv = s_val[0];
+  int bi = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+  }
+  return bi;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* s_val) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_val[0] + s_val[1] + s_val[2] + s_val[3];
+}
+__device__ __forceinline__ float block_max(float v, float* s_val) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(s_val[0], s_val[1]), fmaxf(s_val[2], s_val[3]));
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sx[];  // [V] scaled logits
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_sel[2];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int V = a.V;
+  const float* lg = a.logits + (size_t)row * a.ldl;
+  const int f = a.frame_ptr ? *a.frame_ptr : 0;
+  const bool greedy = (a.topk <= 1) || (a.temperature == 0.f);
+
+  if (a.logits_trace) {
+    float* tr = a.logits_trace + (((size_t)f * a.B + row) * a.C + a.cb) * V;
+    for (int i = tid; i < V; i += 256) tr[i] = lg[i];
+  }
+
+  int choice;
+  if (greedy) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      const float v = lg[i];
+      if (v > bv) { bv = v; bi = i; }
+    }
+    choice = block_argmax(bv, bi, s_val, s_idx);
+  } else {
+    for (int i = tid; i < V; i += 256) sx[i] = lg[i] / a.temperature;
+    __syncthreads();
+    // ---- k-th largest value by 4 passes of 8-bit radix select on the monotone key ---------------
+    uint32_t prefix = 0, pmask = 0;
+    int krem = a.topk < V ? a.topk : V;
+    for (int pass = 3; pass >= 0; --pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += 256) {
+        const uint32_t k = f32_key(sx[i]);
+        if ((k & pmask) == prefix) atomicAdd(&hist[(k >> (pass * 8)) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int cum = 0, d = 255;
+        for (; d > 0; --d) {
+          if (cum + (int)hist[d] >= krem) break;
+          cum += hist[d];
+        }
+        s_sel[0] = (unsigned)d;
+        s_sel[1] = (unsigned)(krem - cum);
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << (pass * 8);
+      pmask |= 255u << (pass * 8);
+      krem = (int)s_sel[1];
+      __syncthreads();
+    }
+    const uint32_t kth_key = prefix;  // key of the k-th largest value
+    // ---- log_softmax then softmax over the survivors (two normalisations, like the reference) ----
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) {
+      const float v = sx[i];
+      if (f32_key(v) >= kth_key) mx = fmaxf(mx, v); else sx[i] = -INFINITY;
+    }
+    mx = block_max(mx, s_val);
+    float se = 0.f;
+    for (int i = tid; i < V; i += 256) se += expf(sx[i] - mx);
+    se = block_sum(se, s_val);
+    const float lse = logf(se);
+    float m2 = -INFINITY;
+    for (int i = tid; i < V; i += 256) {
+      const float lp = (sx[i] - mx) - lse;
+      sx[i] = lp;
+      m2 = fmaxf(m2, lp);
+    }
+    m2 = block_max(m2, s_val);
+    float s2 = 0.f;
+    for (int i = tid; i < V; i += 256) s2 += expf(sx[i] - m2);
+    s2 = block_sum(s2, s_val);
+    // ---- exponential race ------------------------------------------------------------------------
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      const float p = expf(sx[i] - m2) / s2;
+      float q;
+      if (a.noise) {
+        q = a.noise[(size_t)row * a.noise_ld + i];
+      } else {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)i, (uint32_t)row, (uint32_t)a.cb, (uint32_t)f, (uint32_t)a.seed,
+                      (uint32_t)(a.seed >> 32), r);
+        const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        q = -logf(u);
+      }
+      const float v = p / q;
+      if (v > bv) { bv = v; bi = i; }
+    }
+    choice = block_argmax(bv, bi, s_val, s_idx);
+  }
+
+  int64_t feed = choice;
+  const size_t slot = ((size_t)row * a.max_frames + f) * a.C + a.cb;
+  if (a.forced) feed = a.forced[slot];
+  if (tid == 0) {
+    if (a.ring) a.ring[slot] = choice;
+    if (a.idx_out) a.idx_out[row] = choice;
+  }
+  if (a.proj_table && a.cb < a.C - 1) {
+    const float* src = a.proj_table + ((size_t)feed + (size_t)a.cb * V) * a.Hd;
+    float* dst = a.dec_x + (size_t)row * a.Hd;
+    for (int k = tid * 4; k < a.Hd; k += 1024)
+      *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
+  }
+}
+#endif  // CSM_ARGS_ONLY

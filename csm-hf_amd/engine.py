@@ -1,0 +1,455 @@
+"""ctypes binding of libcsm_hip.so (include/csm_hip.h) and the host-side engine wrapper.
+
+torch is used here for device memory (weights, outputs) only; every computation of the path is a HIP
+kernel behind the C ABI.  There is NO CPU fallback: if the library cannot be loaded, or no GPU is
+present, constructing an `Engine` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+from .configuration_csm import CSMConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
+ABI_VERSION = 1
+DT_F32, DT_BF16 = 0, 1
+
+EXPORTS = [
+    "csm_engine_create", "csm_engine_destroy", "csm_bind_weights", "csm_build_proj_table", "csm_set_proj_table",
+    "csm_reset", "csm_set_option", "csm_prefill", "csm_decode_frame", "csm_backbone_step", "csm_backbone_step_ids",
+    "csm_get_state", "csm_generate", "csm_read_frames", "csm_frames_done", "csm_cur_len", "csm_set_kv_start",
+    "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
+    "csm_attn_decode", "csm_rope_scatter", "csm_sync", "csm_last_error", "csm_abi_version",
+]
+
+
+class LlamaCfg(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("ffn", C.c_int32), ("layers", C.c_int32), ("n_q", C.c_int32),
+                ("n_kv", C.c_int32), ("head_dim", C.c_int32), ("rms_eps", C.c_float)]
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("text_vocab", C.c_int32), ("audio_vocab", C.c_int32),
+                ("n_codebooks", C.c_int32), ("backbone", LlamaCfg), ("decoder", LlamaCfg),
+                ("weight_dtype", C.c_int32), ("kv_dtype", C.c_int32), ("max_batch", C.c_int32),
+                ("max_len", C.c_int32), ("max_frames", C.c_int32), ("max_prefill_rows", C.c_int32)]
+
+
+class LayerW(C.Structure):
+    _fields_ = [("wqkv", C.c_void_p), ("wo", C.c_void_p), ("wgu", C.c_void_p), ("wd", C.c_void_p),
+                ("ln1", C.c_void_p), ("ln2", C.c_void_p)]
+
+
+class StackW(C.Structure):
+    _fields_ = [("layers", C.POINTER(LayerW)), ("final_norm", C.c_void_p), ("rope_cos", C.c_void_p),
+                ("rope_sin", C.c_void_p), ("rope_positions", C.c_int32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("backbone", StackW), ("decoder", StackW), ("text_emb", C.c_void_p), ("audio_emb", C.c_void_p),
+                ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p), ("proj_table", C.c_void_p)]
+
+
+class Sampling(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("topk", C.c_int32), ("seed", C.c_uint64), ("noise", C.c_void_p),
+                ("forced", C.c_void_p), ("logits_trace", C.c_void_p), ("last_h_trace", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libcsm_hip.so and declare its prototypes.  Raises if missing -- there is no fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `python -m csm_hf_amd.build` (hipcc, gfx950); "
+                           "csm_hf_amd has no CPU fallback")
+    lib = C.CDLL(p)
+    lib.csm_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        if name != "csm_last_error":
+            fn.restype = C.c_int
+    if lib.csm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libcsm_hip.so ABI {lib.csm_abi_version()} != binding {ABI_VERSION}")
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.csm_engine_create.argtypes = [C.POINTER(EngineCfg), i32, vp, C.POINTER(vp)]
+    lib.csm_engine_destroy.argtypes = [vp]
+    lib.csm_bind_weights.argtypes = [vp, C.POINTER(Weights)]
+    lib.csm_build_proj_table.argtypes = [vp, vp]
+    lib.csm_set_proj_table.argtypes = [vp, vp]
+    lib.csm_reset.argtypes = [vp]
+    lib.csm_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.csm_prefill.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.csm_decode_frame.argtypes = [vp, C.POINTER(Sampling)]
+    lib.csm_backbone_step.argtypes = [vp, C.POINTER(Sampling)]
+    lib.csm_backbone_step_ids.argtypes = [vp, vp, vp, i32, i32]
+    lib.csm_get_state.argtypes = [vp, vp, vp]
+    lib.csm_generate.argtypes = [vp, C.POINTER(Sampling), i32, i32]
+    lib.csm_read_frames.argtypes = [vp, vp, i32, i32]
+    lib.csm_frames_done.argtypes = [vp, C.POINTER(i32)]
+    lib.csm_cur_len.argtypes = [vp, C.POINTER(i32)]
+    lib.csm_set_kv_start.argtypes = [vp, C.POINTER(C.c_int32), i32]
+    lib.csm_last_generate_ms.argtypes = [vp, C.POINTER(f32)]
+    lib.csm_embed_sum.argtypes = [vp, vp, vp, i32, vp]
+    lib.csm_rmsnorm.argtypes = [vp, vp, vp, i32, i32, f32, vp]
+    lib.csm_gemv.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f32, vp]
+    lib.csm_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.csm_sample_topk.argtypes = [vp, vp, i32, i32, f32, i32, C.c_uint64, vp, vp]
+    lib.csm_attn_decode.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp]
+    lib.csm_rope_scatter.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+    lib.csm_sync.argtypes = [vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ck(lib, rc: int):
+    if rc != 0:
+        msg = lib.csm_last_error().decode(errors="replace")
+        if rc == -3:
+            raise ValueError(f"csm_hip capacity error: {msg}")
+        raise RuntimeError(f"csm_hip error {rc}: {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---- llama3 RoPE table (published algorithm: Llama-3.1 rope scaling; parameters from the reference
+#      modeling_csm.py:78-85,99-106).  Computed on the CPU in fp32 exactly like the reference does
+#      (angle = pos * inv_freq in fp32, then cos/sin), uploaded once. ------------------------------------
+def llama3_inv_freq(head_dim: int, base: float, scaling: Optional[dict]) -> torch.Tensor:
+    inv = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))
+    if not scaling or scaling.get("type", scaling.get("rope_type", "default")) in (None, "default"):
+        return inv
+    if scaling.get("type", scaling.get("rope_type")) != "llama3":
+        raise ValueError(f"unsupported rope scaling {scaling}")
+    factor, lo, hi = scaling["factor"], scaling["low_freq_factor"], scaling["high_freq_factor"]
+    old = scaling["original_max_position_embeddings"]
+    wavelen = 2 * math.pi / inv
+    scaled = torch.where(wavelen > old / lo, inv / factor, inv)
+    smooth = (old / wavelen - lo) / (hi - lo)
+    mid = (1 - smooth) * scaled / factor + smooth * scaled
+    is_mid = ~(wavelen < old / hi) * ~(wavelen > old / lo)
+    return torch.where(is_mid, mid, scaled)
+
+
+def rope_tables(lc, n_pos: int):
+    inv = llama3_inv_freq(lc.head_dim, lc.rope_theta, lc.rope_scaling)
+    ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: torch.dtype, max_len: int):
+    """Reference checkpoint layout -> engine layout (include/csm_hip.h)."""
+    def mat(t):
+        return t.detach().to(device=device, dtype=wdtype).contiguous()
+
+    def vec(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    packed = {"_keep": []}
+    for prefix, lc, npos in (("backbone", cfg.backbone_config, max_len), ("decoder", cfg.decoder_config,
+                                                                          cfg.audio_num_codebooks)):
+        layers = []
+        for i in range(lc.num_hidden_layers):
+            p = f"{prefix}.layers.{i}"
+            wqkv = torch.cat([mat(sd[f"{p}.self_attn.q_proj.weight"]), mat(sd[f"{p}.self_attn.k_proj.weight"]),
+                              mat(sd[f"{p}.self_attn.v_proj.weight"])], dim=0).contiguous()
+            g, u = mat(sd[f"{p}.mlp.gate_proj.weight"]), mat(sd[f"{p}.mlp.up_proj.weight"])
+            wgu = torch.stack([g, u], dim=1).reshape(2 * g.shape[0], g.shape[1]).contiguous()
+            del g, u
+            layers.append(dict(wqkv=wqkv, wo=mat(sd[f"{p}.self_attn.o_proj.weight"]), wgu=wgu,
+                               wd=mat(sd[f"{p}.mlp.down_proj.weight"]), ln1=vec(sd[f"{p}.input_layernorm.weight"]),
+                               ln2=vec(sd[f"{p}.post_attention_layernorm.weight"])))
+        cos, sin = rope_tables(lc, npos)
+        packed[prefix] = dict(layers=layers, final_norm=vec(sd[f"{prefix}.norm.weight"]), cos=cos.to(device),
+                              sin=sin.to(device), npos=npos)
+    packed["text_emb"] = mat(sd["text_embeddings.weight"])
+    packed["audio_emb"] = mat(sd["audio_embeddings.weight"])
+    packed["proj_head0"] = torch.cat([mat(sd["projection.weight"]), mat(sd["codebook0_head.weight"])], 0).contiguous()
+    packed["audio_head_t"] = mat(sd["audio_head"]).transpose(1, 2).contiguous()
+    return packed
+
+
+class Engine:
+    """One engine = one GPU, one stream, one resident batch."""
+
+    def __init__(self, cfg: CSMConfig, state_dict: Dict[str, torch.Tensor], device, dtype: torch.dtype,
+                 max_batch: int = 1, max_len: int = 2048, max_frames: int = 512, max_prefill_rows: int = 2048,
+                 kv_dtype: torch.dtype = torch.float32, packed=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("csm_hf_amd needs an AMD GPU (gfx950); no CPU fallback exists")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"unsupported model dtype {dtype}: use torch.float32 or torch.bfloat16")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.max_batch, self.max_len, self.max_frames = max_batch, max_len, max_frames
+        self.max_prefill_rows = max(max_prefill_rows, 128)
+        self.C = cfg.audio_num_codebooks
+        self.V = cfg.audio_vocab_size
+        self.Hb = cfg.backbone_config.hidden_size
+        self.Hd = cfg.decoder_config.hidden_size
+        ec = EngineCfg()
+        ec.abi_version = ABI_VERSION
+        ec.text_vocab, ec.audio_vocab, ec.n_codebooks = cfg.text_vocab_size, self.V, self.C
+        for dst, lc in ((ec.backbone, cfg.backbone_config), (ec.decoder, cfg.decoder_config)):
+            dst.hidden, dst.ffn, dst.layers = lc.hidden_size, lc.intermediate_size, lc.num_hidden_layers
+            dst.n_q, dst.n_kv, dst.head_dim = lc.num_attention_heads, lc.num_key_value_heads, lc.head_dim
+            dst.rms_eps = lc.rms_norm_eps
+        ec.weight_dtype = DT_BF16 if dtype == torch.bfloat16 else DT_F32
+        ec.kv_dtype = DT_BF16 if kv_dtype == torch.bfloat16 else DT_F32
+        ec.max_batch, ec.max_len, ec.max_frames = max_batch, max_len, max_frames
+        ec.max_prefill_rows = self.max_prefill_rows
+        self._h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_engine_create(C.byref(ec), self.device.index or 0, None, C.byref(self._h)))
+        self.packed = packed if packed is not None else pack_weights(cfg, state_dict, self.device, dtype, max_len)
+        if self.packed["backbone"]["npos"] < max_len:
+            cos, sin = rope_tables(cfg.backbone_config, max_len)
+            self.packed["backbone"].update(cos=cos.to(self.device), sin=sin.to(self.device), npos=max_len)
+        torch.cuda.current_stream().synchronize()
+        self._bind()
+        if "proj_table" not in self.packed:
+            self.packed["proj_table"] = torch.empty(self.C * self.V, self.Hd, dtype=torch.float32, device=self.device)
+            torch.cuda.current_stream().synchronize()
+            _ck(self.lib, self.lib.csm_build_proj_table(self._h, _ptr(self.packed["proj_table"])))
+        else:
+            _ck(self.lib, self.lib.csm_set_proj_table(self._h, _ptr(self.packed["proj_table"])))
+        self.batch = 0
+        self.length = 0
+        self.frames = 0
+
+    def _bind(self):
+        w = Weights()
+        self._layer_arrays = []
+        for name, dst in (("backbone", w.backbone), ("decoder", w.decoder)):
+            st = self.packed[name]
+            arr = (LayerW * len(st["layers"]))()
+            for i, l in enumerate(st["layers"]):
+                arr[i].wqkv, arr[i].wo, arr[i].wgu, arr[i].wd = (l["wqkv"].data_ptr(), l["wo"].data_ptr(),
+                                                                 l["wgu"].data_ptr(), l["wd"].data_ptr())
+                arr[i].ln1, arr[i].ln2 = l["ln1"].data_ptr(), l["ln2"].data_ptr()
+            self._layer_arrays.append(arr)
+            dst.layers = arr
+            dst.final_norm = st["final_norm"].data_ptr()
+            dst.rope_cos, dst.rope_sin = st["cos"].data_ptr(), st["sin"].data_ptr()
+            dst.rope_positions = st["npos"]
+        w.text_emb = self.packed["text_emb"].data_ptr()
+        w.audio_emb = self.packed["audio_emb"].data_ptr()
+        w.proj_head0 = self.packed["proj_head0"].data_ptr()
+        w.audio_head_t = self.packed["audio_head_t"].data_ptr()
+        w.proj_table = None
+        _ck(self.lib, self.lib.csm_bind_weights(self._h, C.byref(w)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.csm_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ---------------------------------------------------------------------------------------
+    def sync(self):
+        _ck(self.lib, self.lib.csm_sync(self._h))
+
+    def reset(self):
+        _ck(self.lib, self.lib.csm_reset(self._h))
+        self.batch = self.length = self.frames = 0
+
+    def set_option(self, name: str, value: int):
+        _ck(self.lib, self.lib.csm_set_option(self._h, name.encode(), int(value)))
+
+    def set_kv_start(self, starts):
+        arr = (C.c_int32 * len(starts))(*[int(s) for s in starts])
+        _ck(self.lib, self.lib.csm_set_kv_start(self._h, arr, len(starts)))
+
+    # ---- the path ---------------------------------------------------------------------------------------
+    def _prep_ids(self, ids: torch.Tensor, mask: Optional[torch.Tensor]):
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        m = None
+        if mask is not None:
+            m = (mask.to(self.device) != 0).to(torch.uint8).contiguous()
+        torch.cuda.current_stream().synchronize()
+        return ids, m
+
+    def prefill(self, ids: torch.Tensor, mask: Optional[torch.Tensor], want_outputs: bool = True):
+        """ids/mask [B,S,C+1].  Appends S positions; returns (last_h [B,Hb], c0_logits [B,V]) fp32."""
+        B, S = ids.shape[0], ids.shape[1]
+        ids, m = self._prep_ids(ids, mask)
+        lh = torch.empty(B, self.Hb, dtype=torch.float32, device=self.device) if want_outputs else None
+        lg = torch.empty(B, self.V, dtype=torch.float32, device=self.device) if want_outputs else None
+        torch.cuda.current_stream().synchronize()
+        done = 0
+        # chunk long contexts so that B*chunk fits the prefill scratch
+        chunk = max(1, self.max_prefill_rows // B)
+        while done < S:
+            n = min(chunk, S - done)
+            ci = ids[:, done:done + n].contiguous()
+            cm = m[:, done:done + n].contiguous() if m is not None else None
+            torch.cuda.current_stream().synchronize()
+            if n == 1 and self.length > 0:
+                _ck(self.lib, self.lib.csm_backbone_step_ids(self._h, _ptr(ci), _ptr(cm), B, 0))
+                _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
+            else:
+                _ck(self.lib, self.lib.csm_prefill(self._h, _ptr(ci), _ptr(cm), B, n, _ptr(lh), _ptr(lg)))
+            self.sync()
+            done += n
+            self.length += n
+        self.batch = B
+        return lh, lg
+
+    def step_ids(self, ids: torch.Tensor, mask: Optional[torch.Tensor], advance_frame: bool):
+        B = ids.shape[0]
+        ids, m = self._prep_ids(ids.reshape(B, -1), None if mask is None else mask.reshape(B, -1))
+        _ck(self.lib, self.lib.csm_backbone_step_ids(self._h, _ptr(ids), _ptr(m), B, 1 if advance_frame else 0))
+        lh = torch.empty(B, self.Hb, dtype=torch.float32, device=self.device)
+        lg = torch.empty(B, self.V, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
+        self.sync()
+        self.length += 1
+        if advance_frame:
+            self.frames += 1
+        self.batch = B
+        return lh, lg
+
+    def sampling(self, temperature=1.0, topk=50, seed=0, noise=None, forced=None, logits_trace=None,
+                 last_h_trace=None) -> Sampling:
+        s = Sampling()
+        s.temperature, s.topk, s.seed = float(temperature), int(topk), int(seed) & (2 ** 64 - 1)
+        s.noise = None if noise is None else noise.data_ptr()
+        s.forced = None if forced is None else forced.data_ptr()
+        s.logits_trace = None if logits_trace is None else logits_trace.data_ptr()
+        s.last_h_trace = None if last_h_trace is None else last_h_trace.data_ptr()
+        self._keep = (noise, forced, logits_trace, last_h_trace)
+        return s
+
+    def decode_frame(self, s: Sampling):
+        _ck(self.lib, self.lib.csm_decode_frame(self._h, C.byref(s)))
+
+    def backbone_step(self, s: Sampling):
+        _ck(self.lib, self.lib.csm_backbone_step(self._h, C.byref(s)))
+        self.length += 1
+        self.frames += 1
+
+    def generate(self, s: Sampling, n_frames: int, use_graph: bool = True):
+        _ck(self.lib, self.lib.csm_generate(self._h, C.byref(s), int(n_frames), 1 if use_graph else 0))
+        self.length += n_frames
+        self.frames += n_frames
+
+    def last_generate_ms(self) -> float:
+        ms = C.c_float()
+        _ck(self.lib, self.lib.csm_last_generate_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def read_frames(self, first: int, n: int) -> torch.Tensor:
+        out = torch.empty(self.batch, n, self.C, dtype=torch.int64, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        if n:
+            _ck(self.lib, self.lib.csm_read_frames(self._h, _ptr(out), first, n))
+        self.sync()
+        return out
+
+    def get_state(self):
+        lh = torch.empty(self.batch, self.Hb, dtype=torch.float32, device=self.device)
+        lg = torch.empty(self.batch, self.V, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
+        self.sync()
+        return lh, lg
+
+    def device_counters(self):
+        a, b = C.c_int(), C.c_int()
+        _ck(self.lib, self.lib.csm_cur_len(self._h, C.byref(a)))
+        _ck(self.lib, self.lib.csm_frames_done(self._h, C.byref(b)))
+        return a.value, b.value
+
+    # ---- per-kernel entry points (tests) ------------------------------------------------------------------
+    def k_embed_sum(self, ids, mask):
+        rows = ids.numel() // (self.C + 1)
+        ids, m = self._prep_ids(ids.reshape(rows, self.C + 1), None if mask is None else mask.reshape(rows, self.C + 1))
+        out = torch.empty(rows, self.Hb, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_embed_sum(self._h, _ptr(ids), _ptr(m), rows, _ptr(out)))
+        self.sync()
+        return out
+
+    def k_rmsnorm(self, x, w, eps):
+        x = x.to(self.device, torch.float32).contiguous()
+        w = w.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(x)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_rmsnorm(self._h, _ptr(x), _ptr(w), x.shape[0], x.shape[1], eps, _ptr(out)))
+        self.sync()
+        return out
+
+    def k_gemv(self, W, x, ln=None, eps=1e-5):
+        W = W.to(self.device).contiguous()
+        x = x.to(self.device, torch.float32).contiguous()
+        lnw = None if ln is None else ln.to(self.device, torch.float32).contiguous()
+        y = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        wd = DT_BF16 if W.dtype == torch.bfloat16 else DT_F32
+        _ck(self.lib, self.lib.csm_gemv(self._h, _ptr(W), wd, W.shape[0], W.shape[1], _ptr(x), x.shape[0], _ptr(lnw),
+                                        eps, _ptr(y)))
+        self.sync()
+        return y
+
+    def k_gemm(self, W, A):
+        W = W.to(self.device).contiguous()
+        A = A.to(self.device, torch.float32).contiguous()
+        out = torch.empty(A.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        wd = DT_BF16 if W.dtype == torch.bfloat16 else DT_F32
+        _ck(self.lib, self.lib.csm_gemm(self._h, _ptr(W), wd, W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out)))
+        self.sync()
+        return out
+
+    def k_sample(self, logits, topk, temperature, seed=0, noise=None):
+        lg = logits.to(self.device, torch.float32).contiguous()
+        nz = None if noise is None else noise.to(self.device, torch.float32).contiguous()
+        out = torch.empty(lg.shape[0], dtype=torch.int32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_sample_topk(self._h, _ptr(lg), lg.shape[0], lg.shape[1], float(temperature), int(topk),
+                                               int(seed), _ptr(nz), _ptr(out)))
+        self.sync()
+        return out
+
+    def k_rope_scatter(self, which, layer, qkv, row_seq, row_pos):
+        qkv = qkv.to(self.device, torch.float32).contiguous()
+        rs = row_seq.to(self.device, torch.int32).contiguous()
+        rp = row_pos.to(self.device, torch.int32).contiguous()
+        lc = self.cfg.decoder_config if which else self.cfg.backbone_config
+        q = torch.empty(qkv.shape[0], lc.num_attention_heads * lc.head_dim, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_rope_scatter(self._h, which, layer, _ptr(qkv), _ptr(rs), _ptr(rp), qkv.shape[0], _ptr(q)))
+        self.sync()
+        return q
+
+    def k_attn(self, which, layer, q, row_seq, row_pos, nsplit=1):
+        q = q.to(self.device, torch.float32).contiguous()
+        rs = row_seq.to(self.device, torch.int32).contiguous()
+        rp = row_pos.to(self.device, torch.int32).contiguous()
+        out = torch.empty_like(q)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_attn_decode(self._h, which, layer, _ptr(q), _ptr(rs), _ptr(rp), q.shape[0], nsplit, _ptr(out)))
+        self.sync()
+        return out

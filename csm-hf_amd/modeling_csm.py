@@ -1,0 +1,360 @@
+"""Host-side mirror of the reference's model API for the generation path.
+
+Same names, argument meaning and error behaviour as `/root/reference/modeling_csm.py`:
+`CSMOutput` (:30-49), `sample_topk` (:179-189), `CSMModel.{forward, generate_frame, generate,
+setup_caches, reset_caches}` (:284-702), HF-style `from_pretrained / save_pretrained / to / eval /
+state_dict` on the reference checkpoint layout.  All arithmetic runs in
+libcsm_hip.so (hand-written gfx950 kernels); torch only carries device memory.
+
+Deviations from the reference, all deliberate (DESIGN.md "Deviations"):
+  * `temperature == 0` means argmax (the reference divides by zero, :181).
+  * greedy ties resolve to the lowest index (the reference draws among exact ties, :183-189).
+  * left-padded rows mask their pads at every step, so a padded row equals its solo run (the reference
+    forgets the pad mask on decode steps).
+  * `past_key_values` is an opaque handle onto the engine-resident KV cache, not a `DynamicCache`.
+  * the training branch (`labels=`, :367-465) is out of scope and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, fields
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .configuration_csm import CSMConfig
+from .engine import Engine, load_library
+
+
+@dataclass
+class CSMOutput:
+    """reference modeling_csm.py:30-49 (a ModelOutput there; tuple/index/key access kept)."""
+    last_hidden_state: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+    samples: Optional[torch.Tensor] = None
+    loss: Optional[torch.Tensor] = None
+    backbone_loss: Optional[torch.Tensor] = None
+    decoder_loss: Optional[torch.Tensor] = None
+
+    def to_tuple(self):
+        return tuple(getattr(self, f.name) for f in fields(self) if getattr(self, f.name) is not None)
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+    def keys(self):
+        return [f.name for f in fields(self) if getattr(self, f.name) is not None]
+
+
+class CSMKVCache:
+    """Handle returned as `past_key_values`: the KV cache itself lives in the engine (pre-allocated, in
+    place), this object only proves which engine state a later call continues from."""
+
+    def __init__(self, model: "CSMModel", epoch: int, length: int, batch: int, frame_pending: bool):
+        self._model_id = id(model)
+        self.epoch, self.length, self.batch, self.frame_pending = epoch, length, batch, frame_pending
+
+    def get_seq_length(self) -> int:
+        return self.length
+
+
+_default_engine_for_sampling = {}
+
+
+def sample_topk(logits: torch.Tensor, topk: int, temperature: float, seed: Optional[int] = None,
+                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference `sample_topk` (modeling_csm.py:179-189): int32 `[..., 1]`, on the logits' device.
+    Runs the K12 sampler kernel through the C ABI (stand-alone entry `csm_sample_topk`)."""
+    import ctypes as C
+    if logits.device.type != "cuda":
+        raise RuntimeError("csm_hf_amd.sample_topk needs logits on the GPU (no CPU fallback)")
+    lib = load_library()
+    V = logits.shape[-1]
+    if topk > V or topk < 1:
+        raise RuntimeError("selected index k out of range")
+    lg = logits.reshape(-1, V).to(torch.float32).contiguous()
+    nz = None if noise is None else noise.reshape(-1, V).to(logits.device, torch.float32).contiguous()
+    out = torch.empty(lg.shape[0], dtype=torch.int32, device=logits.device)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.cuda.current_stream(logits.device).synchronize()
+    rc = lib.csm_sample_topk(None, C.c_void_p(lg.data_ptr()), lg.shape[0], V, float(temperature), int(topk), int(seed),
+                             None if nz is None else C.c_void_p(nz.data_ptr()), C.c_void_p(out.data_ptr()))
+    if rc != 0:
+        raise RuntimeError(lib.csm_last_error().decode())
+    return out.reshape(*logits.shape[:-1], 1)
+
+
+def _llama_modules(lc) -> nn.Module:
+    """Parameter containers named exactly like transformers.LlamaModel (embed_tokens is Identity in the
+    reference, modeling_csm.py:156-167, so it contributes no tensor)."""
+    m = nn.Module()
+    m.layers = nn.ModuleList()
+    hd = lc.head_dim
+    for _ in range(lc.num_hidden_layers):
+        layer = nn.Module()
+        att = nn.Module()
+        att.q_proj = nn.Linear(lc.hidden_size, lc.num_attention_heads * hd, bias=False)
+        att.k_proj = nn.Linear(lc.hidden_size, lc.num_key_value_heads * hd, bias=False)
+        att.v_proj = nn.Linear(lc.hidden_size, lc.num_key_value_heads * hd, bias=False)
+        att.o_proj = nn.Linear(lc.num_attention_heads * hd, lc.hidden_size, bias=False)
+        mlp = nn.Module()
+        mlp.gate_proj = nn.Linear(lc.hidden_size, lc.intermediate_size, bias=False)
+        mlp.up_proj = nn.Linear(lc.hidden_size, lc.intermediate_size, bias=False)
+        mlp.down_proj = nn.Linear(lc.intermediate_size, lc.hidden_size, bias=False)
+        layer.self_attn, layer.mlp = att, mlp
+        layer.input_layernorm = _Norm(lc.hidden_size)
+        layer.post_attention_layernorm = _Norm(lc.hidden_size)
+        m.layers.append(layer)
+    m.norm = _Norm(lc.hidden_size)
+    return m
+
+
+class _Norm(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+
+
+class CSMModel(nn.Module):
+    """reference `CSMModel` (modeling_csm.py:192-702), generation path only."""
+
+    config_class = CSMConfig
+    base_model_prefix = "csm"
+
+    def __init__(self, config: CSMConfig):
+        super().__init__()
+        self.config = config
+        with torch.device("meta"):
+            self.backbone = _llama_modules(config.backbone_config)
+            self.decoder = _llama_modules(config.decoder_config)
+            bh, dh = config.backbone_config.hidden_size, config.decoder_config.hidden_size
+            self.text_embeddings = nn.Embedding(config.text_vocab_size, bh)
+            self.audio_embeddings = nn.Embedding(config.audio_vocab_size * config.audio_num_codebooks, bh)
+            self.projection = nn.Linear(bh, dh, bias=False)
+            self.codebook0_head = nn.Linear(bh, config.audio_vocab_size, bias=False)
+            self.audio_head = nn.Parameter(torch.empty(config.audio_num_codebooks - 1, dh, config.audio_vocab_size))
+        self.requires_grad_(False)
+        self._using_kv_cache = False
+        self._engine: Optional[Engine] = None
+        self._epoch = 0
+        self._frame_pending = False
+        self._caps = dict(max_batch=1, max_len=0, max_frames=0, max_prefill_rows=0)
+        self.kv_dtype = torch.float32
+        self.use_graph = True
+        self.seed = 0
+
+    # ---- HF-style plumbing -------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = True):
+        self._drop_engine()
+        return super().load_state_dict(state_dict, strict=strict, assign=True)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_engine()
+        return super()._apply(fn, *a, **k)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = None, device=None, **_):
+        from safetensors.torch import load_file
+        cfg = CSMConfig.from_pretrained(path)
+        model = cls(cfg)
+        f = os.path.join(path, "model.safetensors")
+        if os.path.exists(f):
+            sd = load_file(f)
+        else:
+            idx = json.load(open(os.path.join(path, "model.safetensors.index.json")))
+            sd = {}
+            for shard in sorted(set(idx["weight_map"].values())):
+                sd.update(load_file(os.path.join(path, shard)))
+        if torch_dtype is not None:
+            sd = {k: v.to(torch_dtype) for k, v in sd.items()}
+        model.load_state_dict(sd, strict=True)
+        if device is not None:
+            model.to(device)
+        return model.eval()
+
+    def save_pretrained(self, path: str):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        self.config.torch_dtype = self.dtype
+        self.config.save_pretrained(path)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+
+    # ---- engine management ---------------------------------------------------------------------------------
+    def _drop_engine(self):
+        if getattr(self, "_engine", None) is not None:
+            self._engine.close()
+            self._engine = None
+            self._epoch += 1
+
+    def setup_caches(self, max_batch_size: int, max_seq_len: Optional[int] = None, max_frames: Optional[int] = None):
+        """reference :284-286 flips a flag; here it also sizes the engine-resident KV cache."""
+        self._using_kv_cache = True
+        self._caps["max_batch"] = max(self._caps["max_batch"], int(max_batch_size))
+        if max_seq_len:
+            self._caps["max_len"] = max(self._caps["max_len"], int(max_seq_len))
+        if max_frames:
+            self._caps["max_frames"] = max(self._caps["max_frames"], int(max_frames))
+
+    def reset_caches(self):
+        """reference :288-290 (`pass`): drop the cached context."""
+        if self._engine is not None:
+            self._engine.reset()
+        self._epoch += 1
+        self._frame_pending = False
+
+    def _ensure_engine(self, batch: int, need_len: int, need_frames: int, prefill_rows: int) -> Engine:
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError("CSMModel must be on an AMD GPU (model.to('cuda')): csm_hf_amd has no CPU path")
+        c = self._caps
+        grow = (self._engine is None or batch > self._engine.max_batch or need_len > self._engine.max_len or
+                need_frames > self._engine.max_frames or prefill_rows > self._engine.max_prefill_rows)
+        if grow:
+            c["max_batch"] = max(c["max_batch"], batch)
+            c["max_len"] = max(c["max_len"], need_len, self.config.max_seq_len)
+            c["max_frames"] = max(c["max_frames"], need_frames, 256)
+            c["max_prefill_rows"] = max(c["max_prefill_rows"], prefill_rows)
+            packed = None
+            if self._engine is not None:
+                packed = self._engine.packed
+                self._engine.close()
+                self._epoch += 1
+            self._engine = Engine(self.config, self.state_dict(), p.device, p.dtype, max_batch=c["max_batch"],
+                                  max_len=c["max_len"], max_frames=c["max_frames"],
+                                  max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed)
+        return self._engine
+
+    # ---- helpers -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _kv_starts(attention_mask: Optional[torch.Tensor], B: int, S: int):
+        if attention_mask is None:
+            return [0] * B
+        valid = (attention_mask.sum(dim=-1) > 0).cpu()
+        starts = []
+        for b in range(B):
+            v = valid[b]
+            n_pad = int((~v).sum())
+            if n_pad and not bool(v[n_pad:].all() and not v[:n_pad].any()):
+                raise ValueError("only left padding is supported: masked frames must form a prefix of the row")
+            starts.append(n_pad)
+        return starts
+
+    def _out_dtype(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.dtype)
+
+    # ---- reference API ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, temperature=1.0, topk=50,
+                generate_frame=False, labels=None):
+        """reference :292-482, inference branch.  `temperature/topk/generate_frame` accepted and ignored
+        as in the reference."""
+        if labels is not None:
+            raise NotImplementedError("the training branch (labels=) is out of scope of csm_hf_amd")
+        if position_ids is not None:
+            raise NotImplementedError("explicit position_ids are not supported (the reference passes None)")
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        use_cache = use_cache if use_cache is not None else self._using_kv_cache
+        B, S = input_ids.shape[0], input_ids.shape[1]
+        cont = past_key_values is not None
+        if cont:
+            if not isinstance(past_key_values, CSMKVCache) or past_key_values.epoch != self._epoch or \
+                    past_key_values._model_id != id(self) or self._engine is None or \
+                    past_key_values.length != self._engine.length or past_key_values.batch != B:
+                raise ValueError("stale or foreign past_key_values: the KV cache lives in the engine and only the "
+                                 "handle returned by the most recent call can be continued")
+        base = self._engine.length if cont else 0
+        eng = self._ensure_engine(B, base + S + 1, 1, min(B * S, max(B * S, 128)))
+        if not cont:
+            eng.reset()
+            self._epoch += 1
+            self._frame_pending = False
+            eng.set_kv_start(self._kv_starts(attention_mask, B, S))
+        if cont and S == 1:
+            last_h, c0 = eng.step_ids(input_ids, attention_mask, advance_frame=self._frame_pending)
+        else:
+            if cont and self._frame_pending:
+                raise NotImplementedError("multi-frame continuation right after generate_frame is not supported")
+            last_h, c0 = eng.prefill(input_ids, attention_mask)
+        self._frame_pending = False
+        pkv = CSMKVCache(self, self._epoch, eng.length, B, False) if use_cache else None
+        last_h, c0 = self._out_dtype(last_h), self._out_dtype(c0)
+        if not return_dict:
+            out = (last_h, c0)
+            return out + (pkv,) if use_cache else out
+        return CSMOutput(last_hidden_state=last_h, logits=c0, past_key_values=pkv)
+
+    @torch.no_grad()
+    def generate_frame(self, input_ids, attention_mask, position_ids=None, temperature=1.0, topk=50,
+                       past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                       return_dict=None):
+        """reference :484-589."""
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        use_cache = use_cache if use_cache is not None else self._using_kv_cache
+        out = self.forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                           past_key_values=past_key_values, use_cache=True, return_dict=True)
+        eng = self._engine
+        if eng.frames + 1 > eng.max_frames:
+            # ring full: restartable because frames already returned are owned by the caller
+            raise ValueError("frame ring full: call setup_caches(max_frames=...) with a larger value")
+        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed())
+        eng.decode_frame(s)
+        tokens = eng.read_frames(eng.frames, 1)[:, 0, :]
+        self._frame_pending = True
+        pkv = CSMKVCache(self, self._epoch, eng.length, eng.batch, True) if use_cache else None
+        if not use_cache:
+            self._epoch += 1
+        if not return_dict:
+            return tokens
+        return CSMOutput(last_hidden_state=out.last_hidden_state, logits=out.logits, past_key_values=pkv, samples=tokens)
+
+    def _next_seed(self) -> int:
+        self.seed += 1
+        return (int(torch.initial_seed()) * 1000003 + self.seed) & (2 ** 63 - 1)
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: int = 100,
+                 temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True):
+        """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.
+
+        One prefill, then per frame one replay of the captured hipGraph (31-step decoder loop + next
+        backbone step).  With `stop_on_all_zeros` the host checks each frame (one sync per frame, like the
+        reference's `torch.all(new_frame == 0)`, :662); without it no host sync happens until the end."""
+        B, T = input_ids.shape[0], input_ids.shape[1]
+        C = self.config.audio_num_codebooks
+        if max_new_frames <= 0:
+            return torch.zeros(B, 0, C, dtype=torch.long, device=input_ids.device)
+        eng = self._ensure_engine(B, T + max_new_frames + 1, max_new_frames, B * T)
+        eng.reset()
+        self._epoch += 1
+        self._frame_pending = False
+        eng.set_kv_start(self._kv_starts(attention_mask, B, T))
+        eng.prefill(input_ids, attention_mask, want_outputs=False)
+        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed())
+        n = 0
+        if stop_on_all_zeros:
+            while n < max_new_frames:
+                eng.generate(s, 1, self.use_graph)
+                frame = eng.read_frames(n, 1)
+                if bool(torch.all(frame == 0)):
+                    break
+                n += 1
+        else:
+            eng.generate(s, max_new_frames, self.use_graph)
+            n = max_new_frames
+        out = eng.read_frames(0, n) if n else torch.zeros(B, 0, C, dtype=torch.long, device=eng.device)
+        self._epoch += 1  # generate() does not hand out a cache handle
+        return out.to(input_ids.device)

@@ -1,0 +1,180 @@
+/*
+ * csm_hip.h -- C ABI of libcsm_hip.so, the MI355X (gfx950) implementation of the CSM generation hot
+ * path.  Plain C: pointers, sizes, POD structs -- no torch / C++ types cross this boundary.
+ *
+ * The reference (thomasgauthier/csm-hf) is pure Python and has NO plugin/FFI interface for this path
+ * (SURVEY.md section 8-b): the path sits behind `CSMModel.forward / generate_frame / generate`
+ * (/root/reference/modeling_csm.py:292-365, 484-589, 591-702).  Each entry point below names the
+ * reference interface it replaces; the host-side mirror of the Python API lives in
+ * `csm-hf_amd/modeling_csm.py` and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - return 0 on success; negative = csm error code, positive = hipError_t.  Never throws.
+ *     `csm_last_error()` returns a thread-local message for the last failure.
+ *   - every `const void*`/`void*` is a DEVICE pointer unless the name ends in `_host`.
+ *   - weights are BORROWED (caller keeps them alive, e.g. torch tensors); KV caches, activation
+ *     scratch, RoPE tables and graphs are engine-owned.
+ *   - an engine is bound to one device and one stream and is not thread-safe; multi-GPU = one engine
+ *     (one process) per device.
+ *   - nothing allocates or synchronises inside a captured region.
+ */
+#ifndef CSM_HIP_H
+#define CSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSM_ABI_VERSION 1
+
+enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1 };
+
+enum {
+  CSM_OK = 0,
+  CSM_ERR_ARG = -1,       /* bad argument / unsupported shape */
+  CSM_ERR_STATE = -2,     /* call sequence error (e.g. frame before prefill) */
+  CSM_ERR_CAPACITY = -3,  /* batch / length exceeds what kv_reserve allocated */
+  CSM_ERR_NOMEM = -4
+};
+
+/* One Llama stack (reference: LlamaConfig fields used at modeling_csm.py:68-109). */
+typedef struct {
+  int32_t hidden, ffn, layers, n_q, n_kv, head_dim;
+  float rms_eps;
+} csm_llama_cfg_t;
+
+/* reference: CSMConfig (modeling_csm.py:52-143) + engine sizing knobs. */
+typedef struct {
+  int32_t abi_version;   /* must be CSM_ABI_VERSION */
+  int32_t text_vocab, audio_vocab, n_codebooks;
+  csm_llama_cfg_t backbone, decoder;
+  int32_t weight_dtype;  /* CSM_DTYPE_*: dtype of all matrices and embedding tables */
+  int32_t kv_dtype;      /* CSM_DTYPE_*: backbone/decoder KV-cache storage */
+  int32_t max_batch;     /* sequences per engine (per GPU) */
+  int32_t max_len;       /* backbone KV positions per sequence (context + generated frames) */
+  int32_t max_frames;    /* capacity of the on-device generated-frame ring */
+  int32_t max_prefill_rows; /* max B*S handled by one csm_prefill call (activation scratch) */
+} csm_config_t;
+
+/* Per-layer weights, ENGINE LAYOUT (host packs once at load time, csm-hf_amd/engine.py):
+ *   wqkv [(n_q+2*n_kv)*head_dim, hidden]  = cat(q_proj, k_proj, v_proj) rows
+ *   wo   [hidden, n_q*head_dim]
+ *   wgu  [2*ffn, hidden]                  row 2i = gate_proj row i, row 2i+1 = up_proj row i
+ *   wd   [hidden, ffn]
+ *   ln1, ln2 [hidden]  fp32 always
+ */
+typedef struct {
+  const void *wqkv, *wo, *wgu, *wd;
+  const float *ln1, *ln2;
+} csm_layer_weights_t;
+
+typedef struct {
+  const csm_layer_weights_t* layers; /* host array [cfg.layers] */
+  const float* final_norm;           /* [hidden] fp32 */
+  const float* rope_cos;             /* [rope_positions, head_dim/2] fp32, host-computed llama3 table */
+  const float* rope_sin;
+  int32_t rope_positions;
+} csm_stack_weights_t;
+
+/* reference tensors: modeling_csm.py:222-240 (names in SURVEY.md section 8 f-1). */
+typedef struct {
+  csm_stack_weights_t backbone, decoder;
+  const void* text_emb;      /* [text_vocab, Hb] */
+  const void* audio_emb;     /* [n_codebooks*audio_vocab, Hb] */
+  const void* proj_head0;    /* [Hd + audio_vocab, Hb] = cat(projection.weight, codebook0_head.weight) */
+  const void* audio_head_t;  /* [n_codebooks-1, audio_vocab, Hd] = audio_head.transpose(1,2) */
+  const float* proj_table;   /* [n_codebooks*audio_vocab, Hd] fp32 = projection(audio_emb); may be NULL at
+                                bind time and supplied later by csm_build_proj_table / csm_set_proj_table */
+} csm_weights_t;
+
+typedef struct csm_engine csm_engine_t;
+
+/* sampling controls of one frame (reference: sample_topk, modeling_csm.py:179-189). */
+typedef struct {
+  float temperature;     /* 0 => argmax (the reference would produce NaNs) */
+  int32_t topk;          /* 1 => greedy */
+  uint64_t seed;         /* Philox key for the Exp(1) race; ignored when noise != NULL or greedy */
+  const float* noise;    /* optional explicit Exp(1) draws [max_frames?1][B][n_codebooks][audio_vocab] for
+                            parity tests; indexed [b][cb][v] for the CURRENT frame */
+  const int64_t* forced; /* optional teacher-forced tokens [B][max_frames][n_codebooks]: fed back instead
+                            of the model's samples (samples are still recorded) */
+  float* logits_trace;   /* optional [max_frames][B][n_codebooks][audio_vocab] fp32 dump of every logits row */
+  float* last_h_trace;   /* optional [max_frames][B][Hb] fp32 dump of last_hidden_state per frame */
+} csm_sampling_t;
+
+/* ---- lifecycle: CSMModel.__init__ / setup_caches / reset_caches (modeling_csm.py:214-245, 284-290) */
+int csm_engine_create(const csm_config_t* cfg, int device, void* stream /* hipStream_t */, csm_engine_t** out);
+int csm_engine_destroy(csm_engine_t* e);
+int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w);
+/* proj_table[r,:] = projection.weight @ audio_emb[r,:]  (fp32 accumulate, fp32 out, caller-owned
+ * [n_codebooks*audio_vocab, Hd] buffer); replaces the per-codebook embed+projection of
+ * modeling_csm.py:535,542,564-565 by one table row read.  Needs max_prefill_rows scratch. */
+int csm_build_proj_table(csm_engine_t* e, float* proj_table_out);
+int csm_set_proj_table(csm_engine_t* e, const float* proj_table);
+int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; graphs stay */
+/* engine knobs: "nt_backbone", "nt_decoder" (non-temporal weight loads), "nsplit_backbone" */
+int csm_set_option(csm_engine_t* e, const char* name, int value);
+
+/* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
+ * ids [B,S,C+1] int64, mask [B,S,C+1] uint8 (0/1).  Appends S positions to the backbone KV cache and
+ * leaves the codebook-0 logits of the last position (and the decoder's position-0 input) in the
+ * engine, ready for csm_decode_frame.  Optional outputs: last_h [B,Hb] fp32, c0_logits [B,V] fp32. */
+int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S,
+                float* last_h_out, float* c0_logits_out);
+
+/* ---- CSMModel.generate_frame minus its backbone forward (modeling_csm.py:522-589): sample c0,
+ * run the 31-step decoder loop, write the frame into the on-device ring at the current frame index. */
+int csm_decode_frame(csm_engine_t* e, const csm_sampling_t* s);
+/* ---- the backbone step of the NEXT generate_frame call (modeling_csm.py:508-520 with S=1): embeds
+ * the frame just generated (or the forced one), appends one KV position, computes c0 logits. */
+int csm_backbone_step(csm_engine_t* e, const csm_sampling_t* s);
+/* same step but fed with an explicit [B,1,C+1] row (API path of forward / generate_frame with
+ * past_key_values); `advance_frame` != 0 when a csm_decode_frame preceded it. */
+int csm_backbone_step_ids(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int advance_frame);
+/* copy out the pending last_hidden_state [B,Hb] / codebook-0 logits [B,V] (either may be NULL) */
+int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logits_out);
+
+/* ---- CSMModel.generate (modeling_csm.py:631-702) after prefill: n_frames x (decode_frame +
+ * backbone_step), replayed from a hipGraph when `use_graph`.  Frames land in the ring; read them with
+ * csm_read_frames.  No host sync inside. */
+int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_frames, int use_graph);
+int csm_read_frames(csm_engine_t* e, int64_t* frames_out /* device [B,n,C] */, int first, int n);
+int csm_frames_done(csm_engine_t* e, int* n_host);            /* syncs the stream */
+int csm_cur_len(csm_engine_t* e, int* len_host);              /* syncs the stream */
+/* per-row first valid KV position (left padding): pads are masked at every step */
+int csm_set_kv_start(csm_engine_t* e, const int32_t* kv_start_host, int B);
+
+/* ---- timing hook for bench.py: HIP events on the engine stream around the last csm_generate */
+int csm_last_generate_ms(csm_engine_t* e, float* ms_host);
+
+/* ---- per-kernel entry points (unit parity tests; all on the engine stream) --------------------- */
+/* K1 frame embedding: out[r,:] = sum_c mask[r,c] * table_c[ids[r,c]]   (modeling_csm.py:261-282,327-334) */
+int csm_embed_sum(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int rows, float* out);
+/* K2 RMSNorm (transformers LlamaRMSNorm): out = w * (x * rsqrt(mean(x^2)+eps)) */
+int csm_rmsnorm(csm_engine_t* e, const float* x, const float* w, int rows, int hidden, float eps, float* out);
+/* K3/K8/K9 skinny GEMM y[M,N] = x[M,K] @ W[N,K]^T, M <= 16, optional fused RMSNorm prologue */
+int csm_gemv(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* x, int M,
+             const float* ln /* nullable */, float eps, float* y);
+/* prefill GEMM C[R,N] = A[R,K] @ W[N,K]^T on the MFMA path */
+int csm_gemm(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* A, int R, float* C);
+/* K12 sampler on a [rows,V] logits matrix; noise nullable; returns int32 indices */
+int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, int V, float temperature, int topk,
+                    uint64_t seed, const float* noise, int32_t* out_idx);
+/* K4-K6 one attention step on caller-provided q and a caller-provided cache (decode kernel):
+ * q [rows, n_q*hd] fp32 (already rotated, unscaled), kc/vc engine cache layout, pos[rows] */
+int csm_attn_decode(csm_engine_t* e, int which /*0 backbone,1 decoder*/, int layer, const float* q,
+                    const int32_t* row_seq, const int32_t* row_pos, int rows, int nsplit, float* out);
+/* K4/K5 RoPE + KV append for `rows` raw qkv projections [rows,(n_q+2n_kv)*hd] into a layer cache */
+int csm_rope_scatter(csm_engine_t* e, int which, int layer, const float* qkv, const int32_t* row_seq,
+                     const int32_t* row_pos, int rows, float* q_out);
+
+int csm_sync(csm_engine_t* e);
+const char* csm_last_error(void);
+int csm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSM_HIP_H */

@@ -1,0 +1,283 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and `transformers`); the reference never
+travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
+
+    python oracle/make_golden.py [--only tiny,sampler,cfg1,prefill512,cfg2] [--frames2 200]
+
+What it does
+  * imports /root/reference/modeling_csm.py unmodified;
+  * installs the decode-mask shim of SURVEY.md Appendix B-1 (transformers 5.15 right-pads the `[B,1]`
+    decode mask with zeros; the pinned 4.49 drops an all-ones mask) and SELF-CHECKS it: cached
+    `generate` must equal the `use_cache=False` growing-context recompute bit-for-bit;
+  * loads the deterministic synthetic checkpoint of `csm_hf_amd.synth` into the reference model with
+    `load_state_dict(strict=True)` (this also fills `audio_head`, which the reference leaves
+    uninitialised, modeling_csm.py:236-240);
+  * records, by wrapping `modeling_csm.sample_topk` / `CSMModel.generate_frame`, every sampled
+    logits row and every frame's `last_hidden_state`;
+  * runs the oracle (oracle/csm_oracle.py) on the same inputs and stores whether it agreed
+    (`oracle_tokens_equal`, `oracle_max_abs_logit_diff`) next to the vectors.
+
+Greedy = (topk=1, temperature=1.0): the reference's temperature=0 divides by zero
+(modeling_csm.py:181; SURVEY.md §0 finding 2).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import transformers.masking_utils as mu  # noqa: E402
+import modeling_csm as REF  # noqa: E402  (the reference, unmodified)
+from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding  # noqa: E402
+
+from csm_hf_amd import CSMConfig  # noqa: E402
+from csm_hf_amd.synth import synth_state_dict, synth_context  # noqa: E402
+from oracle import csm_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _pad_left_valid(attention_mask, kv_length, kv_offset=0, **_):
+    if attention_mask is not None and (n := kv_length + kv_offset - attention_mask.shape[-1]) > 0:
+        return F.pad(attention_mask, (n, 0), value=True)
+    return attention_mask
+
+
+mu.prepare_padding_mask = _pad_left_valid
+
+
+def ref_config(cfg: CSMConfig):
+    from transformers import LlamaConfig
+
+    def lc(c):
+        d = c.to_dict()
+        d.pop("model_type", None)
+        return LlamaConfig(**d)
+    return REF.CSMConfig(text_vocab_size=cfg.text_vocab_size, audio_vocab_size=cfg.audio_vocab_size,
+                         audio_num_codebooks=cfg.audio_num_codebooks, max_seq_len=cfg.max_seq_len,
+                         backbone_config=lc(cfg.backbone_config), decoder_config=lc(cfg.decoder_config))
+
+
+def build_ref(cfg: CSMConfig, sd, dtype):
+    rc = ref_config(cfg)
+    with torch.device("meta"):
+        model = REF.CSMModel(rc)
+    model.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True, assign=True)
+    # non-persistent rotary buffers were created on meta: rebuild them on CPU
+    model.backbone.rotary_emb = LlamaRotaryEmbedding(config=model.backbone.config)
+    model.decoder.rotary_emb = LlamaRotaryEmbedding(config=model.decoder.config)
+    model.eval()
+    return model
+
+
+class Recorder:
+    """Wraps the reference's sampler + generate_frame to capture logits / hidden states."""
+
+    def __init__(self, model, noise=None):
+        self.model = model
+        self.logits = []
+        self.last_h = []
+        self.noise = noise          # flat list of [B,V] tensors consumed in call order
+        self._n = 0
+
+    def __enter__(self):
+        self._orig_sample = REF.sample_topk
+        self._orig_multi = REF._multinomial_sample_one_no_sync
+        self._orig_gf = self.model.generate_frame
+        rec = self
+
+        def sample(logits, topk, temperature):
+            rec.logits.append(logits.detach().float().clone())
+            return rec._orig_sample(logits, topk, temperature)
+
+        def multi(probs):
+            if rec.noise is None:
+                return rec._orig_multi(probs)
+            q = rec.noise[rec._n].to(probs.dtype)
+            rec._n += 1
+            return torch.argmax(probs / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+        def gf(*a, **k):
+            out = rec._orig_gf(*a, **k)
+            rec.last_h.append(out.last_hidden_state.detach().float().clone())
+            return out
+
+        REF.sample_topk = sample
+        REF._multinomial_sample_one_no_sync = multi
+        self.model.generate_frame = gf
+        return self
+
+    def __exit__(self, *exc):
+        REF.sample_topk = self._orig_sample
+        REF._multinomial_sample_one_no_sync = self._orig_multi
+        self.model.generate_frame = self._orig_gf
+
+
+def topn(logits, n):
+    v, i = torch.topk(logits, n, dim=-1)
+    return v.numpy().astype(np.float32), i.numpy().astype(np.int32)
+
+
+@torch.inference_mode()
+def run_case(name, cfg, sd, dtype, ids, mask, frames, *, full_logits=False, topn_keep=4, extra=None,
+             check_nocache=False):
+    t0 = time.time()
+    model = build_ref(cfg, sd, dtype)
+    C, V = cfg.audio_num_codebooks, cfg.audio_vocab_size
+    torch.manual_seed(1234)   # bf16 top-1 ties are broken by the global RNG (modeling_csm.py:175)
+    with Recorder(model) as rec:
+        toks = model.generate(ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
+                              use_cache=True, stop_on_all_zeros=False)
+    n = toks.shape[1]
+    B = ids.shape[0]
+    logits = torch.stack(rec.logits).view(n, C, B, V).permute(0, 2, 1, 3).contiguous()   # [n,B,C,V]
+    last_h = torch.stack(rec.last_h)                                                      # [n,B,H]
+    if check_nocache:
+        # growing-context recompute with NO cache (reference `generate(use_cache=False)` would feed
+        # only the last frame, modeling_csm.py:689-690, so drive generate_frame by hand)
+        fi, fm, nc = ids, mask, []
+        for _ in range(frames):
+            o = model.generate_frame(fi, fm, temperature=1.0, topk=1, use_cache=False, return_dict=True)
+            nc.append(o.samples)
+            row = torch.cat([o.samples, torch.zeros(B, 1, dtype=torch.long)], 1).unsqueeze(1)
+            m1 = torch.zeros(B, 1, C + 1, dtype=mask.dtype)
+            m1[:, :, :C] = 1
+            fi, fm = torch.cat([fi, row], 1), torch.cat([fm, m1], 1)
+        assert torch.equal(toks, torch.stack(nc, 1)), "mask shim self-check failed: cached != no-cache"
+    t_ref = time.time() - t0
+    del model
+    # --- run the oracle on the same inputs -------------------------------------------------------
+    t0 = time.time()
+    sdd = {k: v.to(dtype) for k, v in sd.items()}
+    tr = {}
+    torch.manual_seed(1234)
+    otoks = O.generate(sdd, cfg, ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
+                       stop_on_all_zeros=False, trace=tr)
+    t_or = time.time() - t0
+    eq = bool(torch.equal(otoks, toks))
+    dl = float((tr["logits"] - logits).abs().max())
+    dh = float((tr["last_h"] - last_h).abs().max())
+    tv, ti = topn(logits, topn_keep)
+    margin = tv[..., 0] - tv[..., 1]
+    out = dict(input_ids=ids.numpy(), attention_mask=mask.numpy(), tokens=toks.numpy(),
+               last_h=last_h.numpy(), top_vals=tv, top_idx=ti,
+               min_margin=np.float32(margin.min()), n_exact_ties=np.int32((margin == 0).sum()),
+               oracle_tokens_equal=np.int32(eq), oracle_max_abs_logit_diff=np.float32(dl),
+               oracle_max_abs_lasth_diff=np.float32(dh), ref_seconds=np.float32(t_ref),
+               oracle_seconds=np.float32(t_or), torch_threads=np.int32(torch.get_num_threads()),
+               dtype=str(dtype))
+    if full_logits:
+        out["logits"] = logits.numpy()
+    if extra:
+        out.update(extra)
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: frames={n} min_margin={margin.min():.3e} ties={(margin == 0).sum()} "
+          f"oracle_eq={eq} dlogit={dl:.2e} dh={dh:.2e} ref={t_ref:.1f}s oracle={t_or:.1f}s", flush=True)
+    return toks
+
+
+def gen_tiny():
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    ids, mask = synth_context(cfg, 2, 4, 6, seed=1)
+    run_case("tiny_fp32", cfg, sd, torch.float32, ids, mask, 4, full_logits=True, check_nocache=True)
+    run_case("tiny_bf16", cfg, sd, torch.bfloat16, ids, mask, 4, full_logits=True)
+    # prefill hidden states per layer (kernel-level pins)
+    with torch.inference_mode():
+        model = build_ref(cfg, sd, torch.float32)
+        out = model.backbone(inputs_embeds=model._embed_tokens(ids).mul(mask.unsqueeze(-1)).sum(2),
+                             output_hidden_states=True, use_cache=False, return_dict=True)
+        hs = torch.stack(out.hidden_states).numpy()   # [layers+1, B, S, H]; last entry is post-norm
+        np.savez_compressed(os.path.join(GOLD, "tiny_fp32_hidden.npz"), hidden_states=hs,
+                            last_hidden_state=out.last_hidden_state.numpy())
+        # padded batch: expected = per-row SOLO reference runs (the oracle/product padding semantics)
+        ids_b, mask_b = synth_context(cfg, 2, 4, 6, seed=3)
+        pad = 3
+        solo = []
+        for b, cut in ((0, 0), (1, pad)):
+            solo.append(model.generate(ids_b[b:b + 1, cut:], mask_b[b:b + 1, cut:], max_new_frames=4,
+                                       temperature=1.0, topk=1, stop_on_all_zeros=False))
+        ids_p, mask_p = ids_b.clone(), mask_b.clone()
+        ids_p[1, :pad] = 0
+        mask_p[1, :pad] = 0
+        np.savez_compressed(os.path.join(GOLD, "tiny_padded.npz"), input_ids=ids_p.numpy(),
+                            attention_mask=mask_p.numpy(), tokens=torch.cat(solo, 0).numpy(),
+                            pad=np.int32(pad))
+        print("[golden] tiny_padded, tiny_fp32_hidden written", flush=True)
+
+
+def gen_sampler():
+    """K12 semantics: threshold keeps ties at the k-th value, double normalisation, exponential race."""
+    g = torch.Generator().manual_seed(7)
+    V = 2051
+    logits = torch.randn(16, V, generator=g) * 0.65
+    # rows 8..15: quantise so that exact ties (also at the k-th value) occur
+    logits[8:] = (logits[8:] * 8).round() / 8
+    noise = torch.empty(16, V).exponential_(1, generator=g)
+    out = dict(logits=logits.numpy(), noise=noise.numpy())
+    for topk in (1, 50):
+        for T in (0.7, 1.0):
+            REF_orig = REF._multinomial_sample_one_no_sync
+            REF._multinomial_sample_one_no_sync = lambda p: torch.argmax(p / noise.to(p.dtype), -1, keepdim=True).to(torch.int)
+            try:
+                idx = REF.sample_topk(logits, topk, T)
+            finally:
+                REF._multinomial_sample_one_no_sync = REF_orig
+            oidx = O.sample_topk(logits, topk, T, noise)
+            assert torch.equal(idx, oidx)
+            out[f"idx_k{topk}_T{T}"] = idx.squeeze(-1).numpy()
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **out)
+    print("[golden] sampler written", flush=True)
+
+
+def gen_1b(which, frames2):
+    cfg = CSMConfig()
+    t0 = time.time()
+    if "cfg1" in which:
+        sd = synth_state_dict(cfg, seed=0)
+        print(f"[golden] csm-1b fp32 weights {time.time() - t0:.1f}s", flush=True)
+        ids, mask = synth_context(cfg, 1, 16, 48, seed=1)
+        run_case("csm1b_cfg1_fp32", cfg, sd, torch.float32, ids, mask, 8)
+        del sd
+    sdb = synth_state_dict(cfg, seed=0, bf16_representable=True)
+    if "cfg1" in which:
+        ids, mask = synth_context(cfg, 1, 16, 48, seed=1)
+        run_case("csm1b_cfg1_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, 8)
+        run_case("csm1b_cfg1_bf16", cfg, sdb, torch.bfloat16, ids, mask, 8)
+    if "prefill512" in which:
+        ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
+        run_case("csm1b_prefill512_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, 1, topn_keep=8)
+        run_case("csm1b_prefill512_bf16", cfg, sdb, torch.bfloat16, ids, mask, 1, topn_keep=8)
+    if "cfg2" in which:
+        ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
+        run_case("csm1b_cfg2_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, frames2, topn_keep=2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="tiny,sampler,cfg1,prefill512,cfg2")
+    ap.add_argument("--frames2", type=int, default=200)
+    a = ap.parse_args()
+    which = set(a.only.split(","))
+    torch.manual_seed(0)
+    if "tiny" in which:
+        gen_tiny()
+    if "sampler" in which:
+        gen_sampler()
+    if which & {"cfg1", "prefill512", "cfg2"}:
+        gen_1b(which, a.frames2)
+
+
+if __name__ == "__main__":
+    main()
