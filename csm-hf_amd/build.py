@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcsm_hip.so")
-UNITS = ["gemv", "launchers", "engine"]
+UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "launchers", "engine"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 
 
@@ -26,7 +26,7 @@ def _hipcc() -> str:
 def _sources_mtime() -> float:
     m = os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "csm_hip.h"))
     for f in os.listdir(CSRC):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             m = max(m, os.path.getmtime(os.path.join(CSRC, f)))
     return m
 
@@ -45,7 +45,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(f"[build] {u}.o", file=sys.stderr)
 
-    with ThreadPoolExecutor(len(UNITS)) as ex:
+    with ThreadPoolExecutor(min(len(UNITS), os.cpu_count() or 4)) as ex:
         list(ex.map(compile_one, UNITS))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(OBJ, u + ".o") for u in UNITS], "-o", LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)

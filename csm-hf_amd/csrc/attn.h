@@ -28,34 +28,18 @@ struct AttnArgs {
   const int* kv_start;  // nullable: per-sequence first valid key (left padding)
   int nsplit;
   float* out;   // [rows][n_q*hd]                  (nsplit == 1)
-  float* part;  // [rows][n_q][nsplit][hd+2]       (nsplit > 1): acc[hd], m, l
+  float* part;  // [rows][n_q][nsplit][hd+4]       (nsplit > 1): acc[hd], m, l, pad
 };
 
 #ifndef CSM_ARGS_ONLY
-template <typename KT>
-struct K4 {};
-template <>
-struct K4<float> {
-  static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-};
-template <>
-struct K4<bf16_t> {
-  static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    f32x4 r;
-    r[0] = bf16_lo(u.x);
-    r[1] = bf16_hi(u.x);
-    r[2] = bf16_lo(u.y);
-    r[3] = bf16_hi(u.y);
-    return r;
-  }
-};
+#include "attn_tile.h"
 
-// HD = head_dim (64 or 128); each lane owns HD/64 output dims.
+// HD = head_dim (64 or 128).  One workgroup = (row, kv-head, split); wave g handles query head j*G+g.
 template <typename KT, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
-  constexpr int DPL = HD / 64;
+  using Tile = AttnTile32<KT, HD>;
   __shared__ __attribute__((aligned(16))) float qs[16 * HD];  // up to 16 q-heads per kv-head
+  __shared__ float pb[4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = a.n_q / a.n_kv;
   int blk = blockIdx.x;
@@ -73,59 +57,32 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   int t_hi = t_lo + span;
   if (t_hi > pos + 1) t_hi = pos + 1;
 
-  for (int i = tid; i < G * HD; i += 256) qs[i] = a.q[(size_t)row * a.n_q * HD + (size_t)j * G * HD + i];
-  __syncthreads();
-
   const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
   const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+  Tile tile;
+  if (t_lo < t_hi) tile.load(kc, vc, a.lmax, t_lo, min(32, t_hi - t_lo), lane);  // in flight during the q staging
+
+  for (int i = tid * 4; i < G * HD; i += 1024)
+    *reinterpret_cast<f32x4*>(qs + i) = *reinterpret_cast<const f32x4*>(a.q + (size_t)row * a.n_q * HD + (size_t)j * G * HD + i);
+  __syncthreads();
 
   for (int g = wave; g < G; g += 4) {
-    const float* qg = qs + g * HD;
     float m_run = -INFINITY, l_run = 0.f;
-    float acc[DPL];
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
-
-    for (int t0 = t_lo; t0 < t_hi; t0 += 64) {
-      const int t = t0 + lane;
-      const bool valid = t < t_hi;
-      const int tc = valid ? t : t_hi - 1;
-      float s = 0.f;
-#pragma unroll 8
-      for (int d4 = 0; d4 < HD / 4; ++d4) {
-        const f32x4 kv = K4<KT>::load(kc + ((size_t)d4 * a.lmax + tc) * 4);
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qg + d4 * 4);
-        s = fmaf(qv[0], kv[0], s);
-        s = fmaf(qv[1], kv[1], s);
-        s = fmaf(qv[2], kv[2], s);
-        s = fmaf(qv[3], kv[3], s);
-      }
-      if (!valid) s = -INFINITY;
-      const float m_new = fmaxf(m_run, wave_max(s));
-      const float p = valid ? __expf(s - m_new) : 0.f;
-      const float alpha = __expf(m_run - m_new);  // first tile: exp(-inf) = 0
-      l_run = l_run * alpha + wave_sum(p);
-#pragma unroll
-      for (int i = 0; i < DPL; ++i) acc[i] *= alpha;
-      m_run = m_new;
-      const int cnt = min(64, t_hi - t0);
-      const KT* vrow = vc + (size_t)t0 * HD;
-#pragma unroll 4
-      for (int tt = 0; tt < cnt; ++tt) {
-        const float pv = __shfl(p, tt, 64);
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) acc[i] = fmaf(pv, to_f32(vrow[(size_t)tt * HD + lane + 64 * i]), acc[i]);
-      }
+    f32x4 acc = (f32x4)(0.f);
+    for (int t0 = t_lo; t0 < t_hi; t0 += 32) {
+      const int cnt = min(32, t_hi - t0);
+      if (t0 != t_lo || g != wave) tile.load(kc, vc, a.lmax, t0, cnt, lane);
+      tile.accumulate(qs + g * HD, pb[wave], cnt, lane, m_run, l_run, acc);
     }
+    acc = Tile::reduce(acc);
     const int h = j * G + g;
     if (a.nsplit == 1) {
       const float inv = 1.f / l_run;
-#pragma unroll
-      for (int i = 0; i < DPL; ++i) a.out[(size_t)row * a.n_q * HD + (size_t)h * HD + lane + 64 * i] = acc[i] * inv;
+      if (lane < Tile::LPR)
+        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.n_q * HD + (size_t)h * HD + 4 * lane) = acc * inv;
     } else {
-      float* pp = a.part + (((size_t)row * a.n_q + h) * a.nsplit + sp) * (HD + 2);
-#pragma unroll
-      for (int i = 0; i < DPL; ++i) pp[lane + 64 * i] = acc[i];
+      float* pp = a.part + (((size_t)row * a.n_q + h) * a.nsplit + sp) * (HD + 4);
+      if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(pp + 4 * lane) = acc;
       if (lane == 0) {
         pp[HD] = m_run;
         pp[HD + 1] = l_run;
@@ -135,22 +92,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 }
 
 // merge the per-split partials: out[row][h][d] = sum_s acc_s e^{m_s-M} / sum_s l_s e^{m_s-M}
+// one wave per (row, head); lane s owns split s (nsplit <= 64), then lane = output dim; all partial
+// loads are issued up front (predicated full unroll).
 template <int HD>
-__global__ __launch_bounds__(256) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out) {
-  const int row = blockIdx.x;
-  for (int i = threadIdx.x; i < n_q * HD; i += 256) {
-    const int h = i / HD, d = i - h * HD;
-    const float* pp = part + ((size_t)row * n_q + h) * nsplit * (HD + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * (HD + 2) + HD]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const float ms = pp[s * (HD + 2) + HD];
-      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-      num = fmaf(pp[s * (HD + 2) + d], w, num);
-      den = fmaf(pp[s * (HD + 2) + HD + 1], w, den);
-    }
-    out[(size_t)row * n_q * HD + i] = num / den;
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out) {
+  const int rh = blockIdx.x, lane = threadIdx.x;
+  const float* pp = part + (size_t)rh * nsplit * (HD + 4);
+  float pv[HD / 64][64];
+#pragma unroll
+  for (int s = 0; s < 64; ++s)
+#pragma unroll
+    for (int i = 0; i < HD / 64; ++i) pv[i][s] = s < nsplit ? pp[s * (HD + 4) + lane + 64 * i] : 0.f;
+  const float ms = lane < nsplit ? pp[lane * (HD + 4) + HD] : -INFINITY;
+  const float ls = lane < nsplit ? pp[lane * (HD + 4) + HD + 1] : 0.f;
+  const float M = wave_max(ms);
+  const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+  const float inv = 1.f / wave_sum(ls * w);
+#pragma unroll
+  for (int i = 0; i < HD / 64; ++i) {
+    float num = 0.f;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) num = fmaf(__shfl(w, s, 64), pv[i][s], num);
+    out[(size_t)rh * HD + lane + 64 * i] = num * inv;
   }
 }
 

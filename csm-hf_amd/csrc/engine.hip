@@ -100,8 +100,16 @@ struct csm_engine {
   int B = 0;
   int h_len = 0, h_frame = 0;
   bool ready = false;   // head_out holds valid c0 logits
-  int nsplit_bb = 1;
+  int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
+  int fuse_dec_attn = 1;
   int nt_backbone = 1, nt_decoder = 0;
+  int nsplit_eff() const {
+    if (nsplit_bb > 0) return nsplit_bb;
+    int ns = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
+    int p = 1;
+    while (p * 2 <= ns && p < 64) p *= 2;
+    return p;
+  }
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
@@ -179,7 +187,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   const int nqb = cfg->backbone.n_q * cfg->backbone.head_dim, nqd = cfg->decoder.n_q * cfg->decoder.head_dim;
   if ((r = dalloc(e, &e->h_bb, (size_t)B * Hb)) || (r = dalloc(e, &e->q_bb, (size_t)B * nqb)) ||
       (r = dalloc(e, &e->att_bb, (size_t)B * nqb)) ||
-      (r = dalloc(e, &e->part_bb, (size_t)B * cfg->backbone.n_q * 64 * (cfg->backbone.head_dim + 2))) ||
+      (r = dalloc(e, &e->part_bb, (size_t)B * cfg->backbone.n_q * 64 * (cfg->backbone.head_dim + 4))) ||
       (r = dalloc(e, &e->act_bb, (size_t)B * cfg->backbone.ffn)) || (r = dalloc(e, &e->head_out, (size_t)B * e->ld_head)) ||
       (r = dalloc(e, &e->dec_x, (size_t)B * Hd)) || (r = dalloc(e, &e->q_dec, (size_t)B * nqd)) ||
       (r = dalloc(e, &e->att_dec, (size_t)B * nqd)) || (r = dalloc(e, &e->act_dec, (size_t)B * cfg->decoder.ffn)) ||
@@ -272,7 +280,8 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   if (!e || !name) return fail(CSM_ERR_ARG, "null argument");
   if (!strcmp(name, "nt_backbone")) e->nt_backbone = value;
   else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value;
-  else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 1 ? 1 : (value > 64 ? 64 : value);
+  else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
+  else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
   else return fail(CSM_ERR_ARG, "unknown option %s", name);
   drop_graphs(e);
   return 0;
@@ -306,7 +315,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
 
 // one Llama layer on M single-token rows (decode)
 static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
-                        float* qb, float* att, float* part, int nsplit, float* act, int nt) {
+                        float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn) {
   const csm_layer_weights_t& w = s.layers[l];
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
   GemvArgs a{};
@@ -317,16 +326,23 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
   LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
 
-  AttnArgs t{};
-  t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
-  t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
-  t.nsplit = nsplit; t.out = att; t.part = part;
-  LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
-
   GemvArgs o{};
   o.nt = nt;
-  o.W = w.wo; o.N = H; o.K = nq * hd; o.x = att; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
-  LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
+  o.W = w.wo; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
+  if (fuse_attn) {
+    // short cache (decoder, <= 32 positions): SDPA runs as the prologue of the o_proj launch
+    o.x = qb; o.n_q = nq; o.n_kv = nkv; o.hd = hd; o.pos_ptr = pos_ptr; o.pos_const = pos_const;
+    o.kcache = s.kc[l]; o.vcache = s.vc[l]; o.lmax = s.lmax;
+    LCK(gemv_rows(e, M, PRO_ATTN, EPI_RESID, o));
+  } else {
+    AttnArgs t{};
+    t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+    t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
+    t.nsplit = nsplit; t.out = att; t.part = part;
+    LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
+    o.x = att;
+    LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
+  }
 
   GemvArgs g{};
   g.nt = nt;
@@ -370,7 +386,7 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   em.out = e->h_bb;
   LCK(launch_embed(e->stream, e->cfg.weight_dtype, B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
-    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_bb, e->act_bb, e->nt_backbone));
+    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false));
   if (want_last_h) {
     LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
     if (s && s->last_h_trace)
@@ -400,7 +416,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     float* h = p == 0 ? e->head_out : e->dec_x;
     const int ldh = p == 0 ? e->ld_head : Hd;
     for (int l = 0; l < e->dec.c.layers; ++l)
-      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder));
+      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder, e->fuse_dec_attn && e->dec.lmax <= 32));
     if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame

@@ -1,31 +1,39 @@
 // Weight-streaming skinny GEMM ("GEMV") for decode: y[M,N] = f(x)[M,K] @ W[N,K]^T, M <= 4 per launch.
 //
 // Roofline: HBM.  Algorithmic bytes = N*K*sizeof(WT) (each weight read exactly once per launch); x is
-// M*K*4 bytes re-read per block from L2.  One wave owns a PAIR of output rows per task so that the
-// fused epilogues that need two outputs (RoPE pair i / i+hd/2, SwiGLU gate/up) stay wave-local.
-// 64 lanes x 16 B = 1 KiB per load instruction, 2*U loads in flight per wave; no LDS round trip for
-// the weights (cdna_hip_programming.md "GEMV / M<=16 decode weights" row).
+// M*K*4 bytes re-read per block from L2.  A *task* is a PAIR of output rows so that the fused epilogues
+// that need two outputs (RoPE pair i / i+hd/2, SwiGLU gate/up) stay wave-local.  KS waves of a block
+// cooperate on one task (K split KS ways) so that even a 1024-row matrix spreads over >= 256 workgroups;
+// 64 lanes x 16 B = 1 KiB per load instruction, up to 8 loads in flight per wave, issued BEFORE the
+// x/RMSNorm/attention prologue so the weight latency overlaps it; the next task's loads are issued before
+// the current task's reduction.  No LDS round trip for the weights (cdna_hip_programming.md "GEMV / M<=16
+// decode weights" row).
 //
 // Replaces (reference call sites): q/k/v/o_proj, gate/up/down_proj inside transformers.LlamaModel as
 // called from modeling_csm.py:345-354,545-552,568-576; codebook0_head (:361), projection (:542),
 // audio_head matmul (:557); RMSNorm (transformers modeling_llama.py:62-67) as prologue; RoPE
-// (modeling_llama.py:130-160) + DynamicCache append (cache_utils.py:144-145) as the QKV epilogue.
+// (modeling_llama.py:130-160) + DynamicCache append (cache_utils.py:144-145) as the QKV epilogue; and,
+// for short caches (the 32-position decoder), SDPA itself (sdpa_attention.py:97-163) as the prologue of
+// the o_proj launch (PRO_ATTN).
 #pragma once
 #include "common.h"
+#ifndef CSM_ARGS_ONLY
+#include "attn_tile.h"
+#endif
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
 struct GemvArgs {
   const void* W;
   int N, K;
-  const float* x;  // [M][ldx]
+  const float* x;  // [M][ldx]   (PRO_ATTN: q [M][n_q*hd], pre-scaled, rotated)
   int ldx;
   const float* ln;  // PRO_NORM weight [K]
   float eps;
   float* out;  // EPI_STORE/RESID: [M][ldo] indexed by output row; EPI_SWIGLU: [M][ldo] indexed by pair
   int ldo;
-  // EPI_QKV
+  // EPI_QKV / PRO_ATTN
   int n_q, n_kv, hd;
   float qscale;
   const float* cos_tab;  // [pos][hd/2]
@@ -56,16 +64,114 @@ __device__ __forceinline__ size_t v_index(int b, int j, int t, int d, int n_kv, 
   return (((size_t)b * n_kv + j) * lmax + t) * hd + d;
 }
 
-template <typename WT, typename KT, int M, int PRO, int EPI>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] then red[M][4]
+// Short-cache attention (<= 32 keys: the decoder) for one row into LDS: xs[h*hd + d] = softmax(q_h K^T) V.
+// Waves split the query heads; consecutive heads of a wave that share a kv-head reuse the register tile.
+template <typename KT, int HD>
+__device__ __forceinline__ void attn_short_to_lds(const GemvArgs& a, int m, float* xs, float* qs, float* pbuf) {
+  using Tile = AttnTile32<KT, HD>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = a.n_q / a.n_kv;
+  const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
+  const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+  const int cnt = pos + 1;  // <= 32
+  const int hpw = (a.n_q + 3) >> 2;
+  const int h0 = wave * hpw, h1 = min(a.n_q, h0 + hpw);
+  Tile tile;
+  int cur_j = -1;
+  if (h0 < h1) {
+    cur_j = h0 / G;
+    tile.load(reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + cur_j) * (size_t)(HD >> 2) * a.lmax * 4,
+              reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + cur_j) * (size_t)a.lmax * HD, a.lmax, 0, cnt, lane);
+  }
+  const float* q = a.x + (size_t)m * a.ldx;
+  for (int i = tid * 4; i < a.n_q * HD; i += 1024) *reinterpret_cast<f32x4*>(qs + i) = *reinterpret_cast<const f32x4*>(q + i);
+  __syncthreads();
+  for (int h = h0; h < h1; ++h) {
+    const int j = h / G;
+    if (j != cur_j) {
+      cur_j = j;
+      tile.load(reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD >> 2) * a.lmax * 4,
+                reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD, a.lmax, 0, cnt, lane);
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc = (f32x4)(0.f);
+    tile.accumulate(qs + h * HD, pbuf + wave * 32, cnt, lane, m_run, l_run, acc);
+    acc = Tile::reduce(acc);
+    if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(xs + h * HD + 4 * lane) = acc * (1.f / l_run);
+  }
+}
+
+template <typename WT, typename KT, int M, int PRO, int EPI, int KS>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] | red[M][4] | part[4][2M] | (PRO_ATTN) p[4][32] q[K]
+  constexpr int U = 4;
+  constexpr int TPB = 4 / KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   float* red = xs + (size_t)M * K;
+  float* part = red + M * 4;
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const int nch_w = (K >> 3) / KS;        // chunks (of 8 weights) per wave-slice
+  const int ch0 = kw * nch_w;
+  const int half = a.hd >> 1;
+  const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
+  const int stride = gridDim.x * TPB;
+  const int iters = (ntask - (int)blockIdx.x * TPB + stride - 1) / stride;  // block-uniform
 
-  // ---- prologue: stage (optionally RMS-normalised) x into LDS --------------------------------------
-  {
+  int task = blockIdx.x * TPB + tw;
+  int r0 = 0, r1 = 0, head = 0, hi = 0;
+  bool live = false, has1 = false;
+  auto map_task = [&](int t) {
+    live = t < ntask;
+    if (EPI == EPI_QKV) {
+      head = t / half;
+      hi = t - head * half;
+      if (head < a.n_q + a.n_kv) { r0 = head * a.hd + hi; r1 = r0 + half; }
+      else { r0 = head * a.hd + 2 * hi; r1 = r0 + 1; }
+    } else {
+      r0 = 2 * t;
+      r1 = r0 + 1;
+    }
+    has1 = live && r1 < a.N;
+  };
+  W8<WT> w0[U], w1[U];
+  auto issue = [&](int cb) {
+    const WT* w0p = W + (size_t)r0 * K;
+    const WT* w1p = W + (size_t)(has1 ? r1 : r0) * K;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = cb + u * 64 + lane;
+      if (live && c < nch_w) {
+        if (a.nt) {
+          w0[u].load_nt(w0p + (size_t)(ch0 + c) * 8);
+          w1[u].load_nt(w1p + (size_t)(ch0 + c) * 8);
+        } else {
+          w0[u].load(w0p + (size_t)(ch0 + c) * 8);
+          w1[u].load(w1p + (size_t)(ch0 + c) * 8);
+        }
+      } else {
+        w0[u].zero();
+        w1[u].zero();
+      }
+    }
+  };
+  map_task(task);
+  issue(0);  // weights of the first task are in flight while the prologue runs
+
+  // ---- prologue: stage x into LDS (plain | RMS-normalised | short-cache attention output) -----------
+  if (PRO == PRO_ATTN) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (a.hd == 128) attn_short_to_lds<KT, 128>(a, m, xs + (size_t)m * K, part + 4 * 2 * M + 128, part + 4 * 2 * M);
+      else attn_short_to_lds<KT, 64>(a, m, xs + (size_t)m * K, part + 4 * 2 * M + 128, part + 4 * 2 * M);
+      __syncthreads();
+    }
+  } else {
     float ss[M];
+    // norm weight for this thread's first column block is fetched together with x (one latency, not two)
+    f32x4 lnw = (f32x4)(1.f);
+    if (PRO == PRO_NORM && tid * 4 < K) lnw = *reinterpret_cast<const f32x4*>(a.ln + tid * 4);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       ss[m] = 0.f;
@@ -89,7 +195,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         float sc = rsqrtf(s / (float)K + a.eps);
         for (int k = tid * 4; k < K; k += 1024) {
           f32x4 v = *reinterpret_cast<f32x4*>(xs + (size_t)m * K + k);
-          f32x4 w = *reinterpret_cast<const f32x4*>(a.ln + k);
+          const f32x4 w = (k == tid * 4) ? lnw : *reinterpret_cast<const f32x4*>(a.ln + k);
           v[0] = (v[0] * sc) * w[0];
           v[1] = (v[1] * sc) * w[1];
           v[2] = (v[2] * sc) * w[2];
@@ -101,58 +207,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     __syncthreads();
   }
 
-  const WT* W = reinterpret_cast<const WT*>(a.W);
-  const int nch = K >> 3;
-  const int half = a.hd >> 1;
-  const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
-  constexpr int U = 4;
-
-  for (int task = blockIdx.x * 4 + wave; task < ntask; task += gridDim.x * 4) {
-    int r0, r1, head = 0, hi = 0;
-    if (EPI == EPI_QKV) {
-      head = task / half;
-      hi = task - head * half;
-      if (head < a.n_q + a.n_kv) {
-        r0 = head * a.hd + hi;
-        r1 = r0 + half;
-      } else {
-        r0 = head * a.hd + 2 * hi;
-        r1 = r0 + 1;
-      }
-    } else {
-      r0 = 2 * task;
-      r1 = r0 + 1;
-    }
-    const bool has1 = r1 < a.N;
-    const WT* w0p = W + (size_t)r0 * K;
-    const WT* w1p = W + (size_t)(has1 ? r1 : r0) * K;
-
+  for (int it = 0; it < iters; ++it) {
     float acc0[M], acc1[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) acc0[m] = acc1[m] = 0.f;
-
-    for (int cb = 0; cb < nch; cb += 64 * U) {
-      W8<WT> w0[U], w1[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = cb + u * 64 + lane;
-        if (c < nch) {
-          if (a.nt) {
-            w0[u].load_nt(w0p + (size_t)c * 8);
-            w1[u].load_nt(w1p + (size_t)c * 8);
-          } else {
-            w0[u].load(w0p + (size_t)c * 8);
-            w1[u].load(w1p + (size_t)c * 8);
-          }
-        } else {
-          w0[u].zero();
-          w1[u].zero();
-        }
-      }
+    for (int cb = 0; cb < nch_w; cb += 64 * U) {
+      if (cb > 0) issue(cb);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int c = cb + u * 64 + lane;
-        c = c < nch ? c : nch - 1;
+        c = ch0 + (c < nch_w ? c : nch_w - 1);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (size_t)m * K + c * 8);
@@ -173,46 +237,72 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
       }
     }
+    // remember this task's coordinates, then put the next task's loads in flight before reducing
+    const int c_task = task, c_r0 = r0, c_r1 = r1, c_head = head, c_hi = hi;
+    const bool c_live = live, c_has1 = has1;
+    task += stride;
+    map_task(task);
+    if (it + 1 < iters) issue(0);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       acc0[m] = wave_sum(acc0[m]);
       acc1[m] = wave_sum(acc1[m]);
     }
-    if (lane == 0) {
+    if (KS > 1) {
+      if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          part[wave * 2 * M + 2 * m] = acc0[m];
+          part[wave * 2 * M + 2 * m + 1] = acc1[m];
+        }
+      }
+      __syncthreads();
+      if (kw == 0 && lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+          for (int s = 1; s < KS; ++s) {
+            acc0[m] += part[(wave + s) * 2 * M + 2 * m];
+            acc1[m] += part[(wave + s) * 2 * M + 2 * m + 1];
+          }
+      }
+      __syncthreads();
+    }
+    if (lane == 0 && kw == 0 && c_live) {
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         const float v0 = acc0[m], v1 = acc1[m];
         if (EPI == EPI_STORE) {
-          a.out[(size_t)m * a.ldo + r0] = v0;
-          if (has1) a.out[(size_t)m * a.ldo + r1] = v1;
+          a.out[(size_t)m * a.ldo + c_r0] = v0;
+          if (c_has1) a.out[(size_t)m * a.ldo + c_r1] = v1;
         } else if (EPI == EPI_RESID) {
-          a.out[(size_t)m * a.ldo + r0] += v0;
-          if (has1) a.out[(size_t)m * a.ldo + r1] += v1;
+          a.out[(size_t)m * a.ldo + c_r0] += v0;
+          if (c_has1) a.out[(size_t)m * a.ldo + c_r1] += v1;
         } else if (EPI == EPI_SWIGLU) {
-          a.out[(size_t)m * a.ldo + task] = (v0 / (1.f + __expf(-v0))) * v1;
+          a.out[(size_t)m * a.ldo + c_task] = (v0 / (1.f + __expf(-v0))) * v1;
         } else {  // EPI_QKV
           const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
           const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
           KT* kc = reinterpret_cast<KT*>(a.kcache);
           KT* vc = reinterpret_cast<KT*>(a.vcache);
-          if (head < a.n_q + a.n_kv) {
-            const float c = a.cos_tab[(size_t)pos * half + hi];
-            const float s = a.sin_tab[(size_t)pos * half + hi];
+          if (c_head < a.n_q + a.n_kv) {
+            const float c = a.cos_tab[(size_t)pos * half + c_hi];
+            const float s = a.sin_tab[(size_t)pos * half + c_hi];
             const float o0 = v0 * c - v1 * s;
             const float o1 = v1 * c + v0 * s;
-            if (head < a.n_q) {
-              float* q = a.qbuf + (size_t)m * a.n_q * a.hd + head * a.hd;
-              q[hi] = o0 * a.qscale;
-              q[hi + half] = o1 * a.qscale;
+            if (c_head < a.n_q) {
+              float* q = a.qbuf + (size_t)m * a.n_q * a.hd + c_head * a.hd;
+              q[c_hi] = o0 * a.qscale;
+              q[c_hi + half] = o1 * a.qscale;
             } else {
-              const int j = head - a.n_q;
-              store_kv(kc + k_index<KT>(b, j, hi, pos, a.n_kv, a.hd, a.lmax), o0);
-              store_kv(kc + k_index<KT>(b, j, hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
+              const int j = c_head - a.n_q;
+              store_kv(kc + k_index<KT>(b, j, c_hi, pos, a.n_kv, a.hd, a.lmax), o0);
+              store_kv(kc + k_index<KT>(b, j, c_hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
             }
           } else {
-            const int j = head - a.n_q - a.n_kv;
-            store_kv(vc + v_index(b, j, pos, 2 * hi, a.n_kv, a.hd, a.lmax), v0);
-            store_kv(vc + v_index(b, j, pos, 2 * hi + 1, a.n_kv, a.hd, a.lmax), v1);
+            const int j = c_head - a.n_q - a.n_kv;
+            store_kv(vc + v_index(b, j, pos, 2 * c_hi, a.n_kv, a.hd, a.lmax), v0);
+            store_kv(vc + v_index(b, j, pos, 2 * c_hi + 1, a.n_kv, a.hd, a.lmax), v1);
           }
         }
       }

@@ -19,8 +19,9 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   int e = (int)hipGetLastError();
   if (e) return e;
   if (a.nsplit > 1) {
-    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows), dim3(256), 0, st, a.part, a.n_q, a.nsplit, a.out);
-    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows), dim3(256), 0, st, a.part, a.n_q, a.nsplit, a.out);
+    if (a.nsplit > 64) return -1;
+    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out);
+    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out);
     e = (int)hipGetLastError();
   }
   return e;

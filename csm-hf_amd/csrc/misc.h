@@ -34,22 +34,33 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int c = 0; c < a.C; ++c) {
-      int64_t tok;
-      bool live;
-      if (a.ids) {
-        tok = a.ids[(size_t)row * (a.C + 1) + c];
-        live = a.mask ? a.mask[(size_t)row * (a.C + 1) + c] != 0 : true;
-      } else {
-        tok = a.ring[((size_t)row * a.max_frames + f) * a.C + c];
-        live = true;
-      }
-      if (live) {
-        W8<WT> w;
-        w.load(ae + ((size_t)tok + (size_t)c * a.V) * a.H + k);
+    // 8 independent row loads in flight per step (the token ids are read first, then all rows)
+    for (int c0 = 0; c0 < a.C; c0 += 8) {
+      W8<WT> w[8];
+      bool lv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += w.get(i);
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u;
+        int64_t tok = 0;
+        lv[u] = false;
+        if (c < a.C) {
+          if (a.ids) {
+            tok = a.ids[(size_t)row * (a.C + 1) + c];
+            lv[u] = a.mask ? a.mask[(size_t)row * (a.C + 1) + c] != 0 : true;
+          } else {
+            tok = a.ring[((size_t)row * a.max_frames + f) * a.C + c];
+            lv[u] = true;
+          }
+        }
+        const size_t r = lv[u] ? (size_t)tok + (size_t)c * a.V : 0;
+        w[u].load(ae + r * a.H + k);
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (lv[u]) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += w[u].get(i);
+        }
     }
     if (a.ids) {
       const bool live = a.mask ? a.mask[(size_t)row * (a.C + 1) + a.C] != 0 : true;
