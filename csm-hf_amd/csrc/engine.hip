@@ -717,3 +717,38 @@ extern "C" int csm_rope_scatter(csm_engine_t* e, int which, int layer, const flo
   LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, rows, ra));
   return 0;
 }
+
+// ---- kernel micro-benchmark hook (tools/bench_gemv.py): n_launch dependent launches of one GEMV shape,
+// cycling over `n_w` weight matrices `w_stride` bytes apart, captured in a hipGraph and replayed `reps`
+// times; returns microseconds per launch measured with HIP events on the engine stream. --------------
+extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, int n_w, int wdtype, int N, int K,
+                              const float* x, int M, const float* ln, float eps, float* y, int epi, int nt,
+                              int n_launch, int reps, float* us_per_launch) {
+  if (!e || !W || !x || !y || !us_per_launch || M < 1 || M > 4 || n_w < 1) return fail(CSM_ERR_ARG, "bad bench arguments");
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+  int r = 0;
+  for (int i = 0; i < n_launch && !r; ++i) {
+    GemvArgs a{};
+    a.W = (const char*)W + (size_t)(i % n_w) * w_stride; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps;
+    a.out = y; a.ldo = (epi == EPI_SWIGLU) ? N / 2 : N; a.nt = nt;
+    r = launch_gemv(e->stream, wdtype, 0, M, ln ? PRO_NORM : PRO_PLAIN, epi, a);
+  }
+  hipError_t ce = hipStreamEndCapture(e->stream, &g);
+  if (r) { if (g) hipGraphDestroy(g); return fail(CSM_ERR_ARG, "bench launch failed (%d)", r); }
+  HIPCK(ce);
+  HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIPCK(hipGraphLaunch(ge, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipEventRecord(e->ev0, e->stream));
+  for (int i = 0; i < reps; ++i) HIPCK(hipGraphLaunch(ge, e->stream));
+  HIPCK(hipEventRecord(e->ev1, e->stream));
+  HIPCK(hipEventSynchronize(e->ev1));
+  float ms = 0.f;
+  HIPCK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+  *us_per_launch = ms * 1000.f / ((float)reps * n_launch);
+  hipGraphExecDestroy(ge);
+  hipGraphDestroy(g);
+  return 0;
+}

@@ -53,6 +53,7 @@ struct GemvArgs {
   int* bump_b;
   int nt;  // non-temporal weight loads
   int configure_only;  // host-side: only set the kernel's dynamic-LDS attribute, do not launch
+  int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -98,6 +99,155 @@ __device__ __forceinline__ void attn_short_to_lds(const GemvArgs& a, int m, floa
     tile.accumulate(qs + h * HD, pbuf + wave * 32, cnt, lane, m_run, l_run, acc);
     acc = Tile::reduce(acc);
     if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(xs + h * HD + 4 * lane) = acc * (1.f / l_run);
+  }
+}
+
+struct GemvTask {
+  int task, r0, r1, head, hi;
+  bool live, has1;
+};
+
+template <int EPI>
+__device__ __forceinline__ GemvTask gemv_map_task(const GemvArgs& a, int t, int ntask) {
+  GemvTask k;
+  k.task = t;
+  k.live = t < ntask;
+  k.head = 0;
+  k.hi = 0;
+  if (EPI == EPI_QKV) {
+    const int half = a.hd >> 1;
+    k.head = t / half;
+    k.hi = t - k.head * half;
+    if (k.head < a.n_q + a.n_kv) { k.r0 = k.head * a.hd + k.hi; k.r1 = k.r0 + half; }
+    else { k.r0 = k.head * a.hd + 2 * k.hi; k.r1 = k.r0 + 1; }
+  } else {
+    k.r0 = 2 * t;
+    k.r1 = k.r0 + 1;
+  }
+  k.has1 = k.live && k.r1 < a.N;
+  return k;
+}
+
+// one lane writes the two outputs of a task for batch row m
+template <typename KT, int EPI>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const GemvTask& k, int m, float v0, float v1) {
+  if (EPI == EPI_STORE) {
+    a.out[(size_t)m * a.ldo + k.r0] = v0;
+    if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = v1;
+  } else if (EPI == EPI_RESID) {
+    a.out[(size_t)m * a.ldo + k.r0] += v0;
+    if (k.has1) a.out[(size_t)m * a.ldo + k.r1] += v1;
+  } else if (EPI == EPI_SWIGLU) {
+    a.out[(size_t)m * a.ldo + k.task] = (v0 / (1.f + __expf(-v0))) * v1;
+  } else {  // EPI_QKV
+    const int half = a.hd >> 1;
+    const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
+    const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+    KT* kc = reinterpret_cast<KT*>(a.kcache);
+    KT* vc = reinterpret_cast<KT*>(a.vcache);
+    if (k.head < a.n_q + a.n_kv) {
+      const float c = a.cos_tab[(size_t)pos * half + k.hi];
+      const float s = a.sin_tab[(size_t)pos * half + k.hi];
+      const float o0 = v0 * c - v1 * s;
+      const float o1 = v1 * c + v0 * s;
+      if (k.head < a.n_q) {
+        float* q = a.qbuf + (size_t)m * a.n_q * a.hd + k.head * a.hd;
+        q[k.hi] = o0 * a.qscale;
+        q[k.hi + half] = o1 * a.qscale;
+      } else {
+        const int j = k.head - a.n_q;
+        store_kv(kc + k_index<KT>(b, j, k.hi, pos, a.n_kv, a.hd, a.lmax), o0);
+        store_kv(kc + k_index<KT>(b, j, k.hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
+      }
+    } else {
+      const int j = k.head - a.n_q - a.n_kv;
+      store_kv(vc + v_index(b, j, pos, 2 * k.hi, a.n_kv, a.hd, a.lmax), v0);
+      store_kv(vc + v_index(b, j, pos, 2 * k.hi + 1, a.n_kv, a.hd, a.lmax), v1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// M = 1 fast path ("v2"): no LDS staging and no barrier for KS == 1.  One wave = one task (pair of rows);
+// the wave's 2*U weight loads, its x slice and the norm weights are all requested before anything is
+// consumed, so the launch costs ONE memory round trip.  Every wave recomputes the RMS statistic from its
+// own registers (K floats -- cheaper than a workgroup barrier).  Grid = all tasks (one per wave), so a
+// matrix of <= 64 KiB per CU is entirely in flight at once.  K must equal 512*U*KS.
+// ---------------------------------------------------------------------------------------------------
+template <typename WT, typename KT, int PRO, int EPI, int U, int KS>
+__global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
+  __shared__ float part[4][2];
+  constexpr int TPB = 4 / KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kw = wave % KS, tw = wave / KS;
+  const int K = a.K;
+  const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
+  const GemvTask k = gemv_map_task<EPI>(a, blockIdx.x * TPB + tw, ntask);
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const int e0 = kw * (U * 512) + lane * 8;  // first element of this lane's chunk 0; chunk u at + u*512
+  const WT* w0p = W + (size_t)(k.live ? k.r0 : 0) * K + e0;
+  const WT* w1p = W + (size_t)(k.has1 ? k.r1 : (k.live ? k.r0 : 0)) * K + e0;
+  W8<WT> w0[U], w1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (a.nt) { w0[u].load_nt(w0p + u * 512); w1[u].load_nt(w1p + u * 512); }
+    else { w0[u].load(w0p + u * 512); w1[u].load(w1p + u * 512); }
+  }
+  f32x4 xa[U], xb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    xa[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512);
+    xb[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512 + 4);
+  }
+  if (PRO == PRO_NORM) {  // KS == 1 here: the wave holds the whole row
+    f32x4 la[U], lb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      la[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512);
+      lb[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512 + 4);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss += xa[u][i] * xa[u][i] + xb[u][i] * xb[u][i];
+    const float sc = rsqrtf(wave_sum(ss) / (float)K + a.eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xa[u][i] = (xa[u][i] * sc) * la[u][i];
+        xb[u][i] = (xb[u][i] * sc) * lb[u][i];
+      }
+  }
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0 = fmaf(w0[u].get(i), xa[u][i], s0);
+      s1 = fmaf(w1[u].get(i), xa[u][i], s1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0 = fmaf(w0[u].get(4 + i), xb[u][i], s0);
+      s1 = fmaf(w1[u].get(4 + i), xb[u][i], s1);
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (KS > 1) {
+    if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; }
+    __syncthreads();
+    if (kw == 0 && lane == 0) {
+#pragma unroll
+      for (int s = 1; s < KS; ++s) { s0 += part[wave + s][0]; s1 += part[wave + s][1]; }
+    }
+  }
+  if (lane == 0 && kw == 0 && k.live) gemv_epilogue<KT, EPI>(a, k, 0, s0, s1);
+  if (a.bump_a && blockIdx.x == 0 && tid == 0) {
+    *a.bump_a += 1;
+    if (a.bump_b) *a.bump_b += 1;
   }
 }
 
@@ -269,43 +419,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       __syncthreads();
     }
     if (lane == 0 && kw == 0 && c_live) {
+      GemvTask ct;
+      ct.task = c_task; ct.r0 = c_r0; ct.r1 = c_r1; ct.head = c_head; ct.hi = c_hi; ct.live = c_live; ct.has1 = c_has1;
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const float v0 = acc0[m], v1 = acc1[m];
-        if (EPI == EPI_STORE) {
-          a.out[(size_t)m * a.ldo + c_r0] = v0;
-          if (c_has1) a.out[(size_t)m * a.ldo + c_r1] = v1;
-        } else if (EPI == EPI_RESID) {
-          a.out[(size_t)m * a.ldo + c_r0] += v0;
-          if (c_has1) a.out[(size_t)m * a.ldo + c_r1] += v1;
-        } else if (EPI == EPI_SWIGLU) {
-          a.out[(size_t)m * a.ldo + c_task] = (v0 / (1.f + __expf(-v0))) * v1;
-        } else {  // EPI_QKV
-          const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
-          const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
-          KT* kc = reinterpret_cast<KT*>(a.kcache);
-          KT* vc = reinterpret_cast<KT*>(a.vcache);
-          if (c_head < a.n_q + a.n_kv) {
-            const float c = a.cos_tab[(size_t)pos * half + c_hi];
-            const float s = a.sin_tab[(size_t)pos * half + c_hi];
-            const float o0 = v0 * c - v1 * s;
-            const float o1 = v1 * c + v0 * s;
-            if (c_head < a.n_q) {
-              float* q = a.qbuf + (size_t)m * a.n_q * a.hd + c_head * a.hd;
-              q[c_hi] = o0 * a.qscale;
-              q[c_hi + half] = o1 * a.qscale;
-            } else {
-              const int j = c_head - a.n_q;
-              store_kv(kc + k_index<KT>(b, j, c_hi, pos, a.n_kv, a.hd, a.lmax), o0);
-              store_kv(kc + k_index<KT>(b, j, c_hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
-            }
-          } else {
-            const int j = c_head - a.n_q - a.n_kv;
-            store_kv(vc + v_index(b, j, pos, 2 * c_hi, a.n_kv, a.hd, a.lmax), v0);
-            store_kv(vc + v_index(b, j, pos, 2 * c_hi + 1, a.n_kv, a.hd, a.lmax), v1);
-          }
-        }
-      }
+      for (int m = 0; m < M; ++m) gemv_epilogue<KT, EPI>(a, ct, m, acc0[m], acc1[m]);
     }
   }
   if (a.bump_a && blockIdx.x == 0 && tid == 0) {

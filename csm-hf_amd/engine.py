@@ -25,7 +25,7 @@ EXPORTS = [
     "csm_reset", "csm_set_option", "csm_prefill", "csm_decode_frame", "csm_backbone_step", "csm_backbone_step_ids",
     "csm_get_state", "csm_generate", "csm_read_frames", "csm_frames_done", "csm_cur_len", "csm_set_kv_start",
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
-    "csm_attn_decode", "csm_rope_scatter", "csm_sync", "csm_last_error", "csm_abi_version",
+    "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
 ]
 
 
@@ -107,6 +107,8 @@ def load_library(path: Optional[str] = None):
     lib.csm_sample_topk.argtypes = [vp, vp, i32, i32, f32, i32, C.c_uint64, vp, vp]
     lib.csm_attn_decode.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp]
     lib.csm_rope_scatter.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+    lib.csm_bench_gemv.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, vp, i32, vp, f32, vp, i32, i32, i32, i32,
+                                   C.POINTER(f32)]
     lib.csm_sync.argtypes = [vp]
     if path is None:
         _lib = lib
@@ -432,6 +434,21 @@ class Engine:
                                                int(seed), _ptr(nz), _ptr(out)))
         self.sync()
         return out
+
+    def bench_gemv(self, N, K, M=1, norm=False, epi=0, nt=1, pool_mb=512, n_launch=200, reps=10, dtype=torch.bfloat16):
+        """us per launch of one GEMV shape inside a dependent hipGraph chain (weights cycle over a pool)."""
+        esz = 2 if dtype == torch.bfloat16 else 4
+        wbytes = N * K * esz
+        n_w = max(1, (pool_mb << 20) // wbytes)
+        W = (torch.randn(n_w * N * K // 4 + 16, device=self.device) * 0.02).to(dtype).repeat(4)[: n_w * N * K].contiguous()
+        x = torch.randn(M, K, device=self.device)
+        ln = torch.ones(K, device=self.device) if norm else None
+        y = torch.zeros(M, N, device=self.device)
+        us = C.c_float()
+        torch.cuda.synchronize()
+        _ck(self.lib, self.lib.csm_bench_gemv(self._h, _ptr(W), wbytes, n_w, DT_BF16 if dtype == torch.bfloat16 else DT_F32,
+                                              N, K, _ptr(x), M, _ptr(ln), 1e-5, _ptr(y), epi, nt, n_launch, reps, C.byref(us)))
+        return float(us.value), wbytes
 
     def k_rope_scatter(self, which, layer, qkv, row_seq, row_pos):
         qkv = qkv.to(self.device, torch.float32).contiguous()

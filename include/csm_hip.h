@@ -170,6 +170,11 @@ int csm_attn_decode(csm_engine_t* e, int which /*0 backbone,1 decoder*/, int lay
 int csm_rope_scatter(csm_engine_t* e, int which, int layer, const float* qkv, const int32_t* row_seq,
                      const int32_t* row_pos, int rows, float* q_out);
 
+/* micro-benchmark hook: n_launch dependent launches of one GEMV shape in a hipGraph, us per launch */
+int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, int n_w, int wdtype, int N, int K,
+                   const float* x, int M, const float* ln, float eps, float* y, int epi, int nt,
+                   int n_launch, int reps, float* us_per_launch);
+
 int csm_sync(csm_engine_t* e);
 const char* csm_last_error(void);
 int csm_abi_version(void);
