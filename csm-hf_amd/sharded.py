@@ -1,0 +1,56 @@
+"""Batch-sharded generation across the GPUs of one node.
+
+Utterances are independent -- the only cross-row operation in the reference is the global all-zero stop
+test (`modeling_csm.py:662`) -- so the path shards by contiguous blocks of batch rows with replicated
+weights, one process per GPU, and NO collective on the per-frame path.  RCCL (`backend="nccl"`) is used
+only to gather the finished `[rows, n, 32]` frames; the same code runs under `gloo` on CPU for tests.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of rows owned by `rank` (first `n_rows % world` ranks take one extra row)."""
+    base, extra = divmod(n_rows, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_frames(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
+    """all_gather ragged row blocks `[rows_r, n, C]` into `[n_rows, n, C]` on every rank."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    rank = dist.get_rank(group)
+    sizes = [shard_rows(n_rows, r, world) for r in range(world)]
+    cap = max(b - a for a, b in sizes)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    assert sizes[rank][1] - sizes[rank][0] == local.shape[0]
+    return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0)
+
+
+def generate_sharded(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, group=None, **gen_kwargs) -> torch.Tensor:
+    """Every rank passes the FULL `[B, T, 33]` batch; each generates its own rows; all ranks return the
+    full `[B, n, 32]` result.  `stop_on_all_zeros` keeps the reference's semantics per shard only when
+    False (the global stop test would need a per-frame all-reduce)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if gen_kwargs.get("stop_on_all_zeros", True) and world > 1:
+        raise ValueError("generate_sharded needs stop_on_all_zeros=False: shards would stop at different frames")
+    a, b = shard_rows(input_ids.shape[0], rank, world)
+    if b > a:
+        local = model.generate(input_ids[a:b], attention_mask[a:b], **gen_kwargs)
+    else:  # more ranks than rows
+        n = int(gen_kwargs.get("max_new_frames", 100))
+        local = torch.zeros(0, n, input_ids.shape[2] - 1, dtype=torch.long, device=input_ids.device)
+    if world == 1:
+        return local
+    return gather_frames(local, input_ids.shape[0], group)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""HBM traffic per frame-step from a rocprofv3 --pmc FETCH_SIZE (and optionally WRITE_SIZE) pass.
+usage: python tools/pmc_summary.py fetch.db frames [write.db]  -> JSON on stdout
+FETCH_SIZE is reported in KiB and, on gfx950, counts 128-byte requests as 64 bytes for wide coalesced
+streaming reads (MI355X_MICROARCH.md section HBM) -- the engine's weight streams are exactly that pattern
+(16 B per lane), so the raw value is doubled.  WRITE_SIZE is uncalibrated and reported raw."""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    q = ("select name, count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%gemv%' or "
+         "name like '%attn_%' or name like 'sample_kernel%' or name like '%embed_sum%') and name not like '%at::native%' "
+         "group by name order by 3 desc")
+    return list(db.cursor().execute(q, (counter,)))
+
+
+frames = float(sys.argv[2])
+rows = per_kernel(sys.argv[1], "FETCH_SIZE")
+raw_kib = sum(r[2] for r in rows)
+out = {
+    "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, attn_*, sample, embed_sum)",
+    "frames_profiled": frames,
+    "fetch_kib_raw_per_step": raw_kib / frames,
+    "gfx950_wide_read_correction": 2.0,
+    "hbm_read_bytes_per_step": int(2.0 * raw_kib * 1024 / frames),
+    "top_kernels": [{"kernel": r[0][:80], "launches": r[1], "avg_MB_corrected": round(2.0 * r[2] / r[1] / 1024, 3)} for r in rows[:8]],
+}
+if len(sys.argv) > 3:
+    w = per_kernel(sys.argv[3], "WRITE_SIZE")
+    out["write_kib_raw_per_step"] = sum(r[2] for r in w) / frames
+out["hbm_bytes_per_step"] = out["hbm_read_bytes_per_step"] + int(out.get("write_kib_raw_per_step", 0) * 1024)
+print(json.dumps(out, indent=1))
