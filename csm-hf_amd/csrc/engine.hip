@@ -19,6 +19,7 @@
 #define CSM_ARGS_ONLY 1  // kernel definitions live in gemv.hip / launchers.hip
 #include "attn.h"
 #include "gemm.h"
+#include "gemm16.h"
 #include "gemv.h"
 #include "misc.h"
 
@@ -102,6 +103,10 @@ struct csm_engine {
   bool ready = false;   // head_out holds valid c0 logits
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
   int fuse_dec_attn = 1;
+  int use_mfma = 1;
+  float* g16_slabs = nullptr;
+  size_t g16_slab_floats = 0;
+  int* g16_tickets = nullptr;
   int nt_backbone = 1, nt_decoder = 0;
   int nsplit_eff() const {
     if (nsplit_bb > 0) return nsplit_bb;
@@ -200,6 +205,10 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->p_att, R * nqb)) || (r = dalloc(e, &e->p_act, R * cfg->backbone.ffn)) ||
       (r = dalloc(e, &e->p_row_seq, R)) || (r = dalloc(e, &e->p_row_pos, R)))
     return r;
+  // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
+  e->g16_slab_floats = (size_t)1 << 20;
+  if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
+  HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   HIPCK(hipStreamSynchronize(e->stream));
@@ -282,6 +291,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value;
   else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
+  else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
   else return fail(CSM_ERR_ARG, "unknown option %s", name);
   drop_graphs(e);
   return 0;
@@ -289,6 +299,11 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
 
 // ---- decode-side GEMV with row grouping (M <= 4 per launch) -----------------------------------------
 static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
+  if (M >= 2 && M <= 16 && e->use_mfma) {  // batched decode: matrix-core path (bf16 weights, eligible shapes)
+    const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, M, pro, epi, a, e->g16_slabs,
+                                e->g16_slab_floats, e->g16_tickets, 4096);
+    if (r != -2) return r;
+  }
   const float* x = a.x;
   float* out = a.out;
   float* q = a.qbuf;
@@ -416,7 +431,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     float* h = p == 0 ? e->head_out : e->dec_x;
     const int ldh = p == 0 ? e->ld_head : Hd;
     for (int l = 0; l < e->dec.c.layers; ++l)
-      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder, e->fuse_dec_attn && e->dec.lmax <= 32));
+      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder, e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1));
     if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame
@@ -723,8 +738,10 @@ extern "C" int csm_rope_scatter(csm_engine_t* e, int which, int layer, const flo
 // times; returns microseconds per launch measured with HIP events on the engine stream. --------------
 extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, int n_w, int wdtype, int N, int K,
                               const float* x, int M, const float* ln, float eps, float* y, int epi, int nt,
-                              int n_launch, int reps, float* us_per_launch) {
-  if (!e || !W || !x || !y || !us_per_launch || M < 1 || M > 4 || n_w < 1) return fail(CSM_ERR_ARG, "bad bench arguments");
+                              int n_launch, int reps, float* us_per_launch, int grid_cap, int v2_tasks, int force_generic) {
+  if (!e || !W || !x || !y || !us_per_launch || M < 1 || M > 16 || n_w < 1) return fail(CSM_ERR_ARG, "bad bench arguments");
+  const int save_wd = e->cfg.weight_dtype;
+  e->cfg.weight_dtype = wdtype;
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
   HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -733,8 +750,10 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
     GemvArgs a{};
     a.W = (const char*)W + (size_t)(i % n_w) * w_stride; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps;
     a.out = y; a.ldo = (epi == EPI_SWIGLU) ? N / 2 : N; a.nt = nt;
-    r = launch_gemv(e->stream, wdtype, 0, M, ln ? PRO_NORM : PRO_PLAIN, epi, a);
+    a.grid_cap = grid_cap; a.v2_tasks = v2_tasks; a.force_generic = force_generic;
+    r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, epi, a);
   }
+  e->cfg.weight_dtype = save_wd;
   hipError_t ce = hipStreamEndCapture(e->stream, &g);
   if (r) { if (g) hipGraphDestroy(g); return fail(CSM_ERR_ARG, "bench launch failed (%d)", r); }
   HIPCK(ce);

@@ -1,0 +1,263 @@
+// Skinny GEMM on the matrix cores for batched decode: y[M<=16, N] = f(x)[M,K] @ W[N,K]^T, bf16 weights.
+//
+// Roofline: HBM (weights N*K*2 bytes read once per launch, independent of M).  Each 16x16x32 MFMA consumes
+// a 16-row x 32-k weight fragment straight from registers (A operand) against the activations (B operand);
+// no LDS round trip for the weights.  Activations stay fp32-exact: x is split on the fly into three bf16
+// parts by truncation (x = hi + mid + lo, 3 x 8 = 24 mantissa bits, no rounding) and every weight fragment is multiplied by all three
+// (bf16 x bf16 products are exact in fp32), so the result matches the M<=4 fp32-FMA kernels to fp32
+// summation-order error; the matrix pipe has >8x headroom over the HBM stream even at 3 MFMAs per fragment.
+// The k index inside a 128-wide chunk is permuted (lane group g, step j -> k = g*32 + j*8 + 0..7) so every
+// lane reads 64 contiguous bytes of its weight row per chunk; x uses the same permutation.
+// A workgroup owns a panel of PT 16-row tiles; its NW waves take one 128-wide k chunk each and meet in LDS.
+//
+// Same prologues/epilogues as gemv.h (plain | RMSNorm ; store | residual | SwiGLU | RoPE + KV append).
+#pragma once
+#include "gemv.h"
+
+#ifndef CSM_ARGS_ONLY
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+
+// x = hi + mid + lo EXACTLY, each part a bf16: truncation splits fp32's 24 mantissa bits 8 + 8 + 8 and the
+// two subtractions are exact, so no rounding happens anywhere (cheaper than three RNE conversions).
+__device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  uint32_t* ph = reinterpret_cast<uint32_t*>(&hi);
+  uint32_t* pm = reinterpret_cast<uint32_t*>(&mid);
+  uint32_t* pl = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float v0 = p < 2 ? a[2 * p] : b[2 * p - 4], v1 = p < 2 ? a[2 * p + 1] : b[2 * p - 3];
+    const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+    const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+    ph[p] = (h0 >> 16) | h1;
+    pm[p] = (m0 >> 16) | m1;
+    pl[p] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+}
+
+// panel row of tile t, local row r (0..15).  QKV panels pair the two RoPE halves of a head (PT == 2).
+template <int EPI, int PT>
+__device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int r) {
+  if (EPI == EPI_QKV) {
+    const int half = a.hd >> 1, spp = half / 16;  // sub-panels per head
+    const int head = panel / spp, s = panel - head * spp;
+    return head * a.hd + t * half + s * 16 + r;
+  }
+  return (panel * PT + t) * 16 + r;
+}
+
+// One 128-wide k chunk per wave: every load of the wave (PT*4 weight fragments, its x slice, the norm
+// weights) is issued before anything is consumed.  grid = (row panels, KB); KB > 1 splits K across
+// workgroups (K = 8192 down_proj): partial panels go to `slabs`, a per-panel ticket elects the last arriver,
+// which sums them in fixed order (deterministic) and runs the epilogue.  PRO_NORM needs KB == 1.
+template <typename KT, int PRO, int EPI, int NW, int PT>
+__global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag
+  float* red = lds;
+  float* panel = lds + NW * PT * 256;
+  int* flag = reinterpret_cast<int*>(panel + PT * 256);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+  const int m = lane & 15, g = lane >> 4;
+  const bool mlive = m < M;
+  const int k0 = ((int)blockIdx.y * NW + wave) * 128 + g * 32;
+
+  // epilogue inputs of this thread's elements (residual value, or position + cos/sin) are requested now,
+  // not at the tail of the kernel
+  constexpr int NE = (PT * 256 + 64 * NW - 1) / (64 * NW);
+  float pre0[NE], pre1[NE];
+  int ppos[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    pre0[e] = pre1[e] = 0.f;
+    ppos[e] = 0;
+    const int i = tid + e * 64 * NW;
+    if (i < PT * 256) {
+      const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
+      const int mm = l & 15, r = (l >> 4) * 4 + reg;
+      const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+      if (mm < M && n < a.N) {
+        if (EPI == EPI_RESID) pre0[e] = a.out[(size_t)mm * a.ldo + n];
+        if (EPI == EPI_QKV) {
+          ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+          const int half = a.hd >> 1, spp = half / 16;
+          const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
+          if (t == 0 && head < a.n_q + a.n_kv) {
+            pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+            pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+          }
+        }
+      }
+    }
+  }
+  u32x4 wf[PT][4];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
+    n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
+    const bf16_t* wr = W + (size_t)n * K + k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.nt) wf[t][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + j * 8));
+      else wf[t][j] = *reinterpret_cast<const u32x4*>(wr + j * 8);
+    }
+  }
+  const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
+  f32x4 xa[4], xb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
+    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8 + 4);
+  }
+  if (PRO == PRO_NORM) {
+    f32x4 la[4], lb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8);
+      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8 + 4);
+    }
+    // RMS statistic of row m from the registers: lanes (m, g) of all NW waves cover the whole row
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss += xa[j][i] * xa[j][i] + xb[j][i] * xb[j][i];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) red[wave * 16 + lane] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w * 16 + m];
+    const float sc = rsqrtf(tot / (float)K + a.eps);
+    __syncthreads();  // red is reused below
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xa[j][i] = (xa[j][i] * sc) * la[j][i];
+        xb[j][i] = (xb[j][i] * sc) * lb[j][i];
+      }
+  }
+  f32x4 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[t] = (f32x4)(0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
+    bf16x8 xh, xm, xl;
+    split3(xa[j], xb[j], xh, xm, xl);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      bf16x8 af;
+      *reinterpret_cast<u32x4*>(&af) = wf[t][j];
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl, acc[t], 0, 0, 0);  // small terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh, acc[t], 0, 0, 0);
+    }
+  }
+
+  // ---- K reduction across the waves through LDS, fixed order (deterministic) ---------------------------
+  // C/D layout of 16x16x32: col (= batch row m) = lane & 15, row (= weight row) = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int t = 0; t < PT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * PT + t) * 64 + lane) * 4) = acc[t];
+  __syncthreads();
+  for (int i = tid; i < PT * 256; i += 64 * NW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * PT * 256 + i];
+    panel[i] = s;
+  }
+  if (KB > 1) {
+    // ---- K reduction across workgroups: slab + ticket, last arriver combines (cdna guide, Guideline 16) --
+    float* slab = slabs + ((size_t)blockIdx.x * KB + blockIdx.y) * (PT * 256);
+    // write-through (sc1) slab stores: no release fence / L2 write-back per workgroup needed
+    for (int i = tid; i < PT * 256; i += 64 * NW)   // same thread wrote panel[i]
+      __hip_atomic_store(slab + i, panel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = tk == KB - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const float* base = slabs + (size_t)blockIdx.x * KB * (PT * 256);
+    for (int i = tid; i < PT * 256; i += 64 * NW) {
+      float v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) v[kb] = kb < KB ? base[(size_t)kb * (PT * 256) + i] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) s += v[kb];
+      panel[i] = s;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: element i = (t, l, reg): weight row = tile row (l>>4)*4+reg, batch row = l & 15 -------
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int i = tid + e * 64 * NW;
+    if (i >= PT * 256) continue;
+    const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
+    const int mm = l & 15, r = (l >> 4) * 4 + reg;
+    if (mm >= M) continue;
+    const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+    if (n >= a.N) continue;
+    const float v = panel[i];
+    if (EPI == EPI_STORE) {
+      a.out[(size_t)mm * a.ldo + n] = v;
+    } else if (EPI == EPI_RESID) {
+      a.out[(size_t)mm * a.ldo + n] = pre0[e] + v;
+    } else if (EPI == EPI_SWIGLU) {
+      if (!(reg & 1)) {
+        const float u = panel[i + 1];
+        a.out[(size_t)mm * a.ldo + (n >> 1)] = (v / (1.f + __expf(-v))) * u;
+      }
+    } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
+      const int half = a.hd >> 1, spp = half / 16;
+      const int head = blockIdx.x / spp, s = blockIdx.x - head * spp;
+      const int hi = s * 16 + r;  // index inside the half
+      const int b = a.row_seq ? a.row_seq[mm] : a.seq_base + mm;
+      const int pos = ppos[e];
+      KT* kc = reinterpret_cast<KT*>(a.kcache);
+      KT* vc = reinterpret_cast<KT*>(a.vcache);
+      if (head < a.n_q + a.n_kv) {
+        if (t == 0) {
+          const float v0 = v, v1 = panel[256 + (i & 255)];
+          const float c = pre0[e], sn = pre1[e];
+          const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
+          if (head < a.n_q) {
+            float* q = a.qbuf + (size_t)mm * a.n_q * a.hd + head * a.hd;
+            q[hi] = o0 * a.qscale;
+            q[hi + half] = o1 * a.qscale;
+          } else {
+            const int j = head - a.n_q;
+            store_kv(kc + k_index<KT>(b, j, hi, pos, a.n_kv, a.hd, a.lmax), o0);
+            store_kv(kc + k_index<KT>(b, j, hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
+          }
+        }
+      } else {
+        const int j = head - a.n_q - a.n_kv;
+        store_kv(vc + v_index(b, j, pos, t * half + hi, a.n_kv, a.hd, a.lmax), v);
+      }
+    }
+  }
+  if (a.bump_a && blockIdx.x == 0 && tid == 0) {
+    *a.bump_a += 1;
+    if (a.bump_b) *a.bump_b += 1;
+  }
+}
+#endif  // CSM_ARGS_ONLY
+
+// returns -2 when the shape / dtype is not covered by the MFMA path
+int launch_gemm16(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                  size_t slab_floats, int* tickets, int n_tickets);

@@ -1,0 +1,54 @@
+// Instantiations + launcher of the MFMA skinny GEMM (gemm16.h).
+#include "gemm16.h"
+
+template <typename KT, int PRO, int EPI, int NW, int PT>
+static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
+                      int n_tickets) {
+  int gx;
+  if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
+  else gx = ((a.N + 15) / 16 + PT - 1) / PT;
+  if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
+  const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16) * sizeof(float);
+  hipLaunchKernelGGL((gemm16_kernel<KT, PRO, EPI, NW, PT>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  return (int)hipGetLastError();
+}
+
+template <typename KT, int PRO, int EPI, int PT>
+static int launch_nw(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
+  if (nw == 16) return launch_g16<KT, PRO, EPI, 16, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  if (nw == 8) return launch_g16<KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  return launch_g16<KT, PRO, EPI, 4, PT>(st, M, KB, a, slabs, sf, tk, nt);
+}
+
+int launch_gemm16(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                  size_t slab_floats, int* tickets, int n_tickets) {
+  if (wdtype != 1 || M < 1 || M > 16 || a.configure_only) return -2;
+  if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
+  if (a.K % 512 != 0 || a.ldx % 4 != 0) return -2;
+  // waves per workgroup x workgroup-level K splits: every wave owns exactly one 128-wide chunk
+  const int nchunks = a.K / 128;
+  int nw = nchunks >= 16 ? 16 : (nchunks >= 8 ? 8 : 4), KB = 1;
+  if (nchunks > 16) {  // K = 8192: 4 waves x 16 splits keeps x traffic per workgroup small and fills the chip
+    if (pro == PRO_NORM) return -2;
+    nw = 4;
+    KB = nchunks / 4;
+    if (KB > 16) return -2;
+  }
+  if (nchunks % nw) return -2;
+  if (epi == EPI_QKV) {
+    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || KB != 1) return -2;
+    if (kvdtype == 1) return launch_nw<bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    return launch_nw<float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  }
+  // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels
+  const int ntiles = (a.N + 15) / 16;
+  const bool big = (ntiles / 4) * KB >= 128;
+#define G16(P, E)                                                                                              \
+  if (pro == P && epi == E) {                                                                                  \
+    if (big) return launch_nw<float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \
+    return launch_nw<float, P, E, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);                \
+  }
+  G16(PRO_PLAIN, EPI_STORE) G16(PRO_NORM, EPI_STORE) G16(PRO_PLAIN, EPI_RESID) G16(PRO_NORM, EPI_SWIGLU)
+#undef G16
+  return -2;
+}

@@ -54,6 +54,8 @@ struct GemvArgs {
   int nt;  // non-temporal weight loads
   int configure_only;  // host-side: only set the kernel's dynamic-LDS attribute, do not launch
   int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
+  int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
+  int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -128,44 +130,68 @@ __device__ __forceinline__ GemvTask gemv_map_task(const GemvArgs& a, int t, int 
   return k;
 }
 
-// one lane writes the two outputs of a task for batch row m
-template <typename KT, int EPI>
-__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const GemvTask& k, int m, float v0, float v1) {
-  if (EPI == EPI_STORE) {
-    a.out[(size_t)m * a.ldo + k.r0] = v0;
-    if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = v1;
-  } else if (EPI == EPI_RESID) {
-    a.out[(size_t)m * a.ldo + k.r0] += v0;
-    if (k.has1) a.out[(size_t)m * a.ldo + k.r1] += v1;
-  } else if (EPI == EPI_SWIGLU) {
-    a.out[(size_t)m * a.ldo + k.task] = (v0 / (1.f + __expf(-v0))) * v1;
-  } else {  // EPI_QKV
-    const int half = a.hd >> 1;
-    const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
-    const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
-    KT* kc = reinterpret_cast<KT*>(a.kcache);
-    KT* vc = reinterpret_cast<KT*>(a.vcache);
-    if (k.head < a.n_q + a.n_kv) {
-      const float c = a.cos_tab[(size_t)pos * half + k.hi];
-      const float s = a.sin_tab[(size_t)pos * half + k.hi];
-      const float o0 = v0 * c - v1 * s;
-      const float o1 = v1 * c + v0 * s;
-      if (k.head < a.n_q) {
-        float* q = a.qbuf + (size_t)m * a.n_q * a.hd + k.head * a.hd;
-        q[k.hi] = o0 * a.qscale;
-        q[k.hi + half] = o1 * a.qscale;
-      } else {
-        const int j = k.head - a.n_q;
-        store_kv(kc + k_index<KT>(b, j, k.hi, pos, a.n_kv, a.hd, a.lmax), o0);
-        store_kv(kc + k_index<KT>(b, j, k.hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
+// Epilogue of one task.  Everything the epilogue must READ (the residual values for EPI_RESID; the row
+// position and its cos/sin for EPI_QKV) is requested by `prefetch` when the task's weight loads are issued,
+// so no memory round trip is left at the tail of the kernel.
+template <typename KT, int EPI, int M>
+struct GemvEpi {
+  float a0[M], a1[M];
+  int pos[M];
+  __device__ __forceinline__ void prefetch(const GemvArgs& a, const GemvTask& k) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      a0[m] = a1[m] = 0.f;
+      pos[m] = 0;
+      if (!k.live) continue;
+      if (EPI == EPI_RESID) {
+        a0[m] = a.out[(size_t)m * a.ldo + k.r0];
+        if (k.has1) a1[m] = a.out[(size_t)m * a.ldo + k.r1];
+      } else if (EPI == EPI_QKV) {
+        pos[m] = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+        if (k.head < a.n_q + a.n_kv) {
+          const int half = a.hd >> 1;
+          a0[m] = a.cos_tab[(size_t)pos[m] * half + k.hi];
+          a1[m] = a.sin_tab[(size_t)pos[m] * half + k.hi];
+        }
       }
-    } else {
-      const int j = k.head - a.n_q - a.n_kv;
-      store_kv(vc + v_index(b, j, pos, 2 * k.hi, a.n_kv, a.hd, a.lmax), v0);
-      store_kv(vc + v_index(b, j, pos, 2 * k.hi + 1, a.n_kv, a.hd, a.lmax), v1);
     }
   }
-}
+  // one lane writes the two outputs of the task for batch row m
+  __device__ __forceinline__ void store(const GemvArgs& a, const GemvTask& k, int m, float v0, float v1) const {
+    if (EPI == EPI_STORE) {
+      a.out[(size_t)m * a.ldo + k.r0] = v0;
+      if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = v1;
+    } else if (EPI == EPI_RESID) {
+      a.out[(size_t)m * a.ldo + k.r0] = a0[m] + v0;
+      if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = a1[m] + v1;
+    } else if (EPI == EPI_SWIGLU) {
+      a.out[(size_t)m * a.ldo + k.task] = (v0 / (1.f + __expf(-v0))) * v1;
+    } else {  // EPI_QKV
+      const int half = a.hd >> 1;
+      const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
+      KT* kc = reinterpret_cast<KT*>(a.kcache);
+      KT* vc = reinterpret_cast<KT*>(a.vcache);
+      if (k.head < a.n_q + a.n_kv) {
+        const float c = a0[m], s = a1[m];
+        const float o0 = v0 * c - v1 * s;
+        const float o1 = v1 * c + v0 * s;
+        if (k.head < a.n_q) {
+          float* q = a.qbuf + (size_t)m * a.n_q * a.hd + k.head * a.hd;
+          q[k.hi] = o0 * a.qscale;
+          q[k.hi + half] = o1 * a.qscale;
+        } else {
+          const int j = k.head - a.n_q;
+          store_kv(kc + k_index<KT>(b, j, k.hi, pos[m], a.n_kv, a.hd, a.lmax), o0);
+          store_kv(kc + k_index<KT>(b, j, k.hi + half, pos[m], a.n_kv, a.hd, a.lmax), o1);
+        }
+      } else {
+        const int j = k.head - a.n_q - a.n_kv;
+        store_kv(vc + v_index(b, j, pos[m], 2 * k.hi, a.n_kv, a.hd, a.lmax), v0);
+        store_kv(vc + v_index(b, j, pos[m], 2 * k.hi + 1, a.n_kv, a.hd, a.lmax), v1);
+      }
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // M = 1 fast path ("v2"): no LDS staging and no barrier for KS == 1.  One wave = one task (pair of rows);
@@ -174,24 +200,30 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, const GemvTask&
 // own registers (K floats -- cheaper than a workgroup barrier).  Grid = all tasks (one per wave), so a
 // matrix of <= 64 KiB per CU is entirely in flight at once.  K must equal 512*U*KS.
 // ---------------------------------------------------------------------------------------------------
-template <typename WT, typename KT, int PRO, int EPI, int U, int KS>
+template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T>
 __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
-  __shared__ float part[4][2];
+  __shared__ float part[4][2 * T];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
-  const GemvTask k = gemv_map_task<EPI>(a, blockIdx.x * TPB + tw, ntask);
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const int e0 = kw * (U * 512) + lane * 8;  // first element of this lane's chunk 0; chunk u at + u*512
-  const WT* w0p = W + (size_t)(k.live ? k.r0 : 0) * K + e0;
-  const WT* w1p = W + (size_t)(k.has1 ? k.r1 : (k.live ? k.r0 : 0)) * K + e0;
-  W8<WT> w0[U], w1[U];
+  GemvTask k[T];
+  GemvEpi<KT, EPI, 1> epi[T];
+  W8<WT> w0[T][U], w1[T][U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (a.nt) { w0[u].load_nt(w0p + u * 512); w1[u].load_nt(w1p + u * 512); }
-    else { w0[u].load(w0p + u * 512); w1[u].load(w1p + u * 512); }
+  for (int t = 0; t < T; ++t) {  // T tasks per wave share one x slice; every weight load is issued up front
+    k[t] = gemv_map_task<EPI>(a, (blockIdx.x * TPB + tw) * T + t, ntask);
+    if (kw == 0) epi[t].prefetch(a, k[t]);
+    const WT* w0p = W + (size_t)(k[t].live ? k[t].r0 : 0) * K + e0;
+    const WT* w1p = W + (size_t)(k[t].has1 ? k[t].r1 : (k[t].live ? k[t].r0 : 0)) * K + e0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (a.nt) { w0[t][u].load_nt(w0p + u * 512); w1[t][u].load_nt(w1p + u * 512); }
+      else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
+    }
   }
   f32x4 xa[U], xb[U];
 #pragma unroll
@@ -220,31 +252,44 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
         xb[u][i] = (xb[u][i] * sc) * lb[u][i];
       }
   }
-  float s0 = 0.f, s1 = 0.f;
+  float s0[T], s1[T];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+  for (int t = 0; t < T; ++t) {
+    float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s0 = fmaf(w0[u].get(i), xa[u][i], s0);
-      s1 = fmaf(w1[u].get(i), xa[u][i], s1);
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c0 = fmaf(w0[t][u].get(i), xa[u][i], c0);
+        c1 = fmaf(w1[t][u].get(i), xa[u][i], c1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c0 = fmaf(w0[t][u].get(4 + i), xb[u][i], c0);
+        c1 = fmaf(w1[t][u].get(4 + i), xb[u][i], c1);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s0 = fmaf(w0[u].get(4 + i), xb[u][i], s0);
-      s1 = fmaf(w1[u].get(4 + i), xb[u][i], s1);
-    }
+    s0[t] = wave_sum(c0);
+    s1[t] = wave_sum(c1);
   }
-  s0 = wave_sum(s0);
-  s1 = wave_sum(s1);
   if (KS > 1) {
-    if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; }
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) { part[wave][2 * t] = s0[t]; part[wave][2 * t + 1] = s1[t]; }
+    }
     __syncthreads();
     if (kw == 0 && lane == 0) {
 #pragma unroll
-      for (int s = 1; s < KS; ++s) { s0 += part[wave + s][0]; s1 += part[wave + s][1]; }
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int s = 1; s < KS; ++s) { s0[t] += part[wave + s][2 * t]; s1[t] += part[wave + s][2 * t + 1]; }
     }
   }
-  if (lane == 0 && kw == 0 && k.live) gemv_epilogue<KT, EPI>(a, k, 0, s0, s1);
+  if (lane == 0 && kw == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (k[t].live) epi[t].store(a, k[t], 0, s0[t], s1[t]);
+  }
   if (a.bump_a && blockIdx.x == 0 && tid == 0) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
@@ -269,30 +314,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int stride = gridDim.x * TPB;
   const int iters = (ntask - (int)blockIdx.x * TPB + stride - 1) / stride;  // block-uniform
 
-  int task = blockIdx.x * TPB + tw;
-  int r0 = 0, r1 = 0, head = 0, hi = 0;
-  bool live = false, has1 = false;
-  auto map_task = [&](int t) {
-    live = t < ntask;
-    if (EPI == EPI_QKV) {
-      head = t / half;
-      hi = t - head * half;
-      if (head < a.n_q + a.n_kv) { r0 = head * a.hd + hi; r1 = r0 + half; }
-      else { r0 = head * a.hd + 2 * hi; r1 = r0 + 1; }
-    } else {
-      r0 = 2 * t;
-      r1 = r0 + 1;
-    }
-    has1 = live && r1 < a.N;
-  };
-  W8<WT> w0[U], w1[U];
-  auto issue = [&](int cb) {
-    const WT* w0p = W + (size_t)r0 * K;
-    const WT* w1p = W + (size_t)(has1 ? r1 : r0) * K;
+  const int task = blockIdx.x * TPB + tw;
+  // two register sets: the loads of task t+1 are in flight while task t is consumed
+  W8<WT> wa0[U], wa1[U], wb0[U], wb1[U];
+  auto issue = [&](const GemvTask& t, W8<WT> (&w0)[U], W8<WT> (&w1)[U], int cb) {
+    const WT* w0p = W + (size_t)t.r0 * K;
+    const WT* w1p = W + (size_t)(t.has1 ? t.r1 : t.r0) * K;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = cb + u * 64 + lane;
-      if (live && c < nch_w) {
+      if (t.live && c < nch_w) {
         if (a.nt) {
           w0[u].load_nt(w0p + (size_t)(ch0 + c) * 8);
           w1[u].load_nt(w1p + (size_t)(ch0 + c) * 8);
@@ -306,8 +337,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       }
     }
   };
-  map_task(task);
-  issue(0);  // weights of the first task are in flight while the prologue runs
+  GemvTask ta = gemv_map_task<EPI>(a, task, ntask);
+  GemvTask tb = gemv_map_task<EPI>(a, task + stride, ntask);
+  GemvEpi<KT, EPI, M> ea, eb;
+  issue(ta, wa0, wa1, 0);  // in flight while the prologue runs
+  if (kw == 0) ea.prefetch(a, ta);
+  if (iters > 1) {
+    issue(tb, wb0, wb1, 0);
+    if (kw == 0) eb.prefetch(a, tb);
+  }
 
   // ---- prologue: stage x into LDS (plain | RMS-normalised | short-cache attention output) -----------
   if (PRO == PRO_ATTN) {
@@ -357,12 +395,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     __syncthreads();
   }
 
-  for (int it = 0; it < iters; ++it) {
+  // consume one task from register set (w0, w1); re-arm the set with task `nxt` (if `more`) before reducing
+  auto process = [&](GemvTask& t, GemvEpi<KT, EPI, M>& ep, W8<WT> (&w0)[U], W8<WT> (&w1)[U], bool more) {
     float acc0[M], acc1[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) acc0[m] = acc1[m] = 0.f;
     for (int cb = 0; cb < nch_w; cb += 64 * U) {
-      if (cb > 0) issue(cb);
+      if (cb > 0) issue(t, w0, w1, cb);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int c = cb + u * 64 + lane;
@@ -387,12 +426,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
       }
     }
-    // remember this task's coordinates, then put the next task's loads in flight before reducing
-    const int c_task = task, c_r0 = r0, c_r1 = r1, c_head = head, c_hi = hi;
-    const bool c_live = live, c_has1 = has1;
-    task += stride;
-    map_task(task);
-    if (it + 1 < iters) issue(0);
+    const GemvTask cur = t;
+    const GemvEpi<KT, EPI, M> cep = ep;
+    t = gemv_map_task<EPI>(a, cur.task + 2 * stride, ntask);
+    if (more) {
+      issue(t, w0, w1, 0);
+      if (kw == 0) ep.prefetch(a, t);
+    }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       acc0[m] = wave_sum(acc0[m]);
@@ -418,12 +458,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       }
       __syncthreads();
     }
-    if (lane == 0 && kw == 0 && c_live) {
-      GemvTask ct;
-      ct.task = c_task; ct.r0 = c_r0; ct.r1 = c_r1; ct.head = c_head; ct.hi = c_hi; ct.live = c_live; ct.has1 = c_has1;
+    if (lane == 0 && kw == 0 && cur.live) {
 #pragma unroll
-      for (int m = 0; m < M; ++m) gemv_epilogue<KT, EPI>(a, ct, m, acc0[m], acc1[m]);
+      for (int m = 0; m < M; ++m) cep.store(a, cur, m, acc0[m], acc1[m]);
     }
+  };
+  for (int it = 0; it < iters; it += 2) {
+    process(ta, ea, wa0, wa1, it + 2 < iters);
+    if (it + 1 < iters) process(tb, eb, wb0, wb1, it + 3 < iters);
   }
   if (a.bump_a && blockIdx.x == 0 && tid == 0) {
     *a.bump_a += 1;

@@ -108,7 +108,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_attn_decode.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp]
     lib.csm_rope_scatter.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     lib.csm_bench_gemv.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, vp, i32, vp, f32, vp, i32, i32, i32, i32,
-                                   C.POINTER(f32)]
+                                   C.POINTER(f32), i32, i32, i32]
     lib.csm_sync.argtypes = [vp]
     if path is None:
         _lib = lib
@@ -435,7 +435,8 @@ class Engine:
         self.sync()
         return out
 
-    def bench_gemv(self, N, K, M=1, norm=False, epi=0, nt=1, pool_mb=512, n_launch=200, reps=10, dtype=torch.bfloat16):
+    def bench_gemv(self, N, K, M=1, norm=False, epi=0, nt=1, pool_mb=512, n_launch=200, reps=10, dtype=torch.bfloat16,
+                   grid_cap=0, v2_tasks=0, force_generic=0):
         """us per launch of one GEMV shape inside a dependent hipGraph chain (weights cycle over a pool)."""
         esz = 2 if dtype == torch.bfloat16 else 4
         wbytes = N * K * esz
@@ -447,7 +448,8 @@ class Engine:
         us = C.c_float()
         torch.cuda.synchronize()
         _ck(self.lib, self.lib.csm_bench_gemv(self._h, _ptr(W), wbytes, n_w, DT_BF16 if dtype == torch.bfloat16 else DT_F32,
-                                              N, K, _ptr(x), M, _ptr(ln), 1e-5, _ptr(y), epi, nt, n_launch, reps, C.byref(us)))
+                                              N, K, _ptr(x), M, _ptr(ln), 1e-5, _ptr(y), epi, nt, n_launch, reps, C.byref(us),
+                                              grid_cap, v2_tasks, force_generic))
         return float(us.value), wbytes
 
     def k_rope_scatter(self, which, layer, qkv, row_seq, row_pos):

@@ -173,7 +173,7 @@ int csm_rope_scatter(csm_engine_t* e, int which, int layer, const float* qkv, co
 /* micro-benchmark hook: n_launch dependent launches of one GEMV shape in a hipGraph, us per launch */
 int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, int n_w, int wdtype, int N, int K,
                    const float* x, int M, const float* ln, float eps, float* y, int epi, int nt,
-                   int n_launch, int reps, float* us_per_launch);
+                   int n_launch, int reps, float* us_per_launch, int grid_cap, int v2_tasks, int force_generic);
 
 int csm_sync(csm_engine_t* e);
 const char* csm_last_error(void);

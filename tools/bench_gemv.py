@@ -14,12 +14,13 @@ shapes = [("dec qkv", 1536, 1024, True, 0), ("dec o", 1024, 1024, False, 1), ("d
           ("dec down", 1024, 8192, False, 1), ("bb qkv", 3072, 2048, True, 0), ("bb o", 2048, 2048, False, 1),
           ("bb gate/up", 16384, 2048, True, 2), ("bb down", 2048, 8192, False, 1), ("audio head", 2051, 1024, True, 0),
           ("c0 head+proj", 3075, 2048, True, 0)]
-Ms = [int(a) for a in sys.argv[1:]] or [1]
+Ms = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1]
+kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
 print("| shape | N | K | MB | " + " | ".join(f"M={m} us (TB/s)" for m in Ms) + " |")
 print("|---|---|---|---|" + "---|" * len(Ms))
 for name, N, K, norm, epi in shapes:
     cells = []
     for M in Ms:
-        us, wb = eng.bench_gemv(N, K, M=M, norm=norm, epi=epi)
+        us, wb = eng.bench_gemv(N, K, M=M, norm=norm, epi=epi, **kw)
         cells.append(f"{us:.2f} ({wb / us / 1e6:.2f})")
     print(f"| {name} | {N} | {K} | {N * K * 2 / 1e6:.1f} | " + " | ".join(cells) + " |")
