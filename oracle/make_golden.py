@@ -3,7 +3,7 @@
 Runs only in the build container (needs /root/reference and `transformers`); the reference never
 travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
 
-    python oracle/make_golden.py [--only tiny,sampler,cfg1,prefill512,cfg2] [--frames2 200]
+    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2] [--frames2 200]
 
 What it does
   * imports /root/reference/modeling_csm.py unmodified;
@@ -264,9 +264,41 @@ def gen_1b(which, frames2):
         run_case("csm1b_cfg2_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, frames2, topn_keep=2)
 
 
+def processor_cases():
+    """Inputs shared by make_golden.py (reference processor) and tests/test_processor.py (ours)."""
+    g = torch.Generator().manual_seed(0)
+    wavs = [torch.rand(1920 * 5 + 100, generator=g), torch.rand(1920 * 3, generator=g), torch.rand(1920 * 9, generator=g)]
+    convo1 = [{"role": "speaker_0", "content": [{"type": "text", "text": "Hello there"}, {"type": "audio"}]},
+              {"role": "speaker_1", "content": [{"type": "text", "text": "Hi"}, {"type": "audio"}]},
+              {"role": "speaker_0", "content": [{"type": "text", "text": "How are you today?"}]}]
+    convo2 = [{"role": "speaker_3", "content": [{"type": "text", "text": "Short"}, {"type": "audio"}]}]
+    return {
+        "single": dict(messages=convo1, audios=wavs[:2]),
+        "single_noamort": dict(messages=convo1, audios=wavs[:2], amortize_decoder_training=False, messages_training_mask=[1, 0, 1]),
+        "trunc": dict(messages=convo1, audios=wavs[:2], max_length=20, amortize_decoder_training=False),
+        "batch": dict(messages=[convo1, convo2], audios=[wavs[:2], [wavs[2]]], amortization_ratio=4),
+    }
+
+
+def gen_processor():
+    """the reference CSMProcessor (processor.py) driven with stub tokenizers."""
+    import random
+    import processor as REFP  # the reference, unmodified
+    from oracle.stub_tokenizers import StubTextTokenizer, StubAudioTokenizer
+    ref = REFP.CSMProcessor(StubTextTokenizer(), StubAudioTokenizer())
+    out = {}
+    for name, kw in processor_cases().items():
+        random.seed(5)
+        r = ref(**kw)
+        for k in ("input_ids", "attention_mask", "labels"):
+            out[f"{name}.{k}"] = r[k].numpy()
+    np.savez_compressed(os.path.join(GOLD, "processor.npz"), **out)
+    print("[golden] processor written", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,sampler,cfg1,prefill512,cfg2")
+    ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2")
     ap.add_argument("--frames2", type=int, default=200)
     a = ap.parse_args()
     which = set(a.only.split(","))
@@ -275,6 +307,8 @@ def main():
         gen_tiny()
     if "sampler" in which:
         gen_sampler()
+    if "processor" in which:
+        gen_processor()
     if which & {"cfg1", "prefill512", "cfg2"}:
         gen_1b(which, a.frames2)
 
