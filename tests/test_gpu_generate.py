@@ -311,3 +311,85 @@ def test_csm1b_config2_200_frames(gold, csm1b_bf16):
     safe = margin > 1e-3
     assert np.array_equal(mine[safe], ref[safe])
     assert (mine == ref).mean() > 0.999
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 3 / 4 / 5 shapes
+# ---------------------------------------------------------------------------------------------------
+def test_csm1b_batch16_rows_equal_solo_and_graph_equals_eager(csm1b_bf16):
+    """config 4 per-GPU shape (16 utterances): the matrix-core batched kernels give every row the token stream
+    of its solo (M = 1, fp32-FMA kernels) run wherever the margin allows; eager == hipGraph bit for bit."""
+    m = csm1b_bf16
+    cfg = m.config
+    ids, mask = synth_context(cfg, 16, 16, 48, seed=41)
+    full = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False).cpu()
+    m.use_graph = False
+    eager = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False).cpu()
+    m.use_graph = True
+    assert torch.equal(full, eager)
+    agree = []
+    for b in (0, 7, 15):
+        solo = m.generate(ids[b:b + 1].to(DEV), mask[b:b + 1].to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False).cpu()
+        same = (solo[0] == full[b]).reshape(-1)
+        first_diff = int((~same).nonzero()[0]) if not bool(same.all()) else same.numel()
+        agree.append(first_diff)
+    # fp32-class differences between the two kernel families can flip a near-tie; require long agreement
+    assert min(agree) >= 32 * 2 and sum(a == 32 * 6 for a in agree) >= 2, agree
+
+
+def test_csm1b_batch16_topk50_sampling_distribution(csm1b_bf16):
+    """config 3 (B=16, topk=50, T=1.0, device Philox): codebook-0 samples follow softmax(top-50 logits).
+    All 16 rows share one context, so the 16 x 8 seeds = 128 draws come from the same distribution."""
+    m = csm1b_bf16
+    cfg = m.config
+    ids1, mask1 = synth_context(cfg, 1, 16, 48, seed=43)
+    ids, mask = ids1.repeat(16, 1, 1), mask1.repeat(16, 1, 1)
+    eng = m._ensure_engine(16, 64 + 4, 4, 16 * 64)
+    draws = []
+    for seed in range(8):
+        eng.reset()
+        eng.set_kv_start([0] * 16)
+        lh, lg = eng.prefill(ids, mask)
+        eng.generate(eng.sampling(temperature=1.0, topk=50, seed=1000 + seed), 1, True)
+        draws.append(eng.read_frames(0, 1)[:, 0, 0].cpu())
+    draws = torch.cat(draws)
+    logits = lg[0].cpu()
+    assert float((lg.cpu() - logits).abs().max()) < 1e-4            # identical rows -> identical logits
+    top = torch.topk(logits, 50)
+    p = torch.softmax(top[0], 0)
+    assert bool(torch.isin(draws, top[1]).all())                      # never outside the top-50 set
+    # chi-square against the expected multinomial (bins: top-8 tokens + rest)
+    order = top[1][:8]
+    obs = torch.tensor([float((draws == t).sum()) for t in order] + [float((~torch.isin(draws, order)).sum())])
+    exp = torch.cat([p[:8], (1 - p[:8].sum())[None]]) * len(draws)
+    chi2 = float(((obs - exp) ** 2 / exp.clamp_min(1e-9)).sum())
+    assert chi2 < 27.9, (chi2, obs, exp)                               # chi^2_{8}, p = 0.0005
+
+
+def test_csm1b_long_context_beyond_max_seq_len(csm1b_bf16):
+    """config 5 shape (bf16 weights): a 2048-frame prefill followed by generation past max_seq_len = 2048.
+    Positions are not clamped; split-KV attention with 64 splits == unsplit."""
+    m = csm1b_bf16
+    cfg = m.config
+    ids, mask = synth_context(cfg, 1, 256, 1792, seed=5)
+    m.setup_caches(1, max_seq_len=2048 + 24)
+    out = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
+    assert out.shape == (1, 12, 32) and m._engine.device_counters() == (2048 + 12, 12)
+    m._engine.set_option("nsplit_backbone", 1)
+    ref = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
+    m._engine.set_option("nsplit_backbone", 64)
+    out64 = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
+    m._engine.set_option("nsplit_backbone", 0)
+    same = (out == ref).reshape(-1)
+    assert bool(same[:64].all()) and float(same.float().mean()) > 0.8
+    assert bool((out64 == ref).reshape(-1)[:64].all())
+    # the long prefill agrees with a chunked prefill (4 x 512) of the same context
+    eng = m._engine
+    eng.reset()
+    eng.set_kv_start([0])
+    lh_a, lg_a = eng.prefill(ids, mask)
+    eng.reset()
+    eng.set_kv_start([0])
+    for c in range(4):
+        lh_b, lg_b = eng.prefill(ids[:, c * 512:(c + 1) * 512], mask[:, c * 512:(c + 1) * 512])
+    assert rel_l2(lh_b.cpu(), lh_a.cpu()) < 1e-5
