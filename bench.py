@@ -40,7 +40,7 @@ from csm_hf_amd.synth import synth_state_dict, synth_context  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
-def bytes_step(cfg: CSMConfig, B: int, L: float, wbytes: int = 2, kvbytes: int = 2) -> float:
+def bytes_step(cfg: CSMConfig, B: int, L: float, wbytes: int = 2, kvbytes: int = 2, ebytes: int = 2) -> float:
     """Algorithmic bytes of one frame-step.
     The engine replaces the 31 per-codebook projection GEMVs by a table row read (4 KiB each), so the
     31 x projection term of the SURVEY formula is NOT counted; the position-0 projection is."""
@@ -60,7 +60,7 @@ def bytes_step(cfg: CSMConfig, B: int, L: float, wbytes: int = 2, kvbytes: int =
     kv_bb = bc.num_hidden_layers * 2 * bc.num_key_value_heads * bc.head_dim * kvbytes          # per position
     kv_dec = dc.num_hidden_layers * 2 * dc.num_key_value_heads * dc.head_dim * kvbytes
     dec_reads = kv_dec * sum(range(1, C + 1))
-    emb = (C * bc.hidden_size * wbytes) + (C - 1) * dc.hidden_size * 4
+    emb = (C * bc.hidden_size * ebytes) + (C - 1) * dc.hidden_size * 4   # embedding rows stay bf16 with fp8 linears
     return w_step + B * (kv_bb * L + dec_reads + emb)
 
 
@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--topk", type=int, default=1)
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--kv-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = e4m3fn linears + row scales (config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -156,6 +157,7 @@ def main():
     model.load_state_dict(sd)
     del sd
     model.kv_dtype = torch.float32 if a.kv_dtype == "f32" else torch.bfloat16
+    model.weight_format = "fp8" if a.weights == "fp8" else "native"
     eng = model._ensure_engine(B, a.ctx + W + K + 2, W + K + 1, B * a.ctx)
     for o in a.opt:
         k, v = o.split("=")
@@ -205,7 +207,7 @@ def main():
 
     if rank == 0:
         L_mean = a.ctx + W + (K - 1) / 2.0 + 1          # positions read by the backbone step of timed frame i
-        by = bytes_step(cfg, B, L_mean)
+        by = bytes_step(cfg, B, L_mean, wbytes=1 if a.weights == "fp8" else 2)
         step_s = hip_max / K
         achieved = by / step_s / 1e9
         out = {
@@ -215,8 +217,9 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall_max / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 weights, f32 activations/accumulate, " + a.kv_dtype + " KV", "data": "synthetic",
-            "config": {"workload": f"csm-1b, B={B}/GPU, {a.ctx}-frame synthetic context prefilled (untimed), "
+            "dtype": ("fp8-e4m3 linear weights (per-row scales), bf16 embeddings" if a.weights == "fp8" else "bf16 weights")
+                     + ", f32 activations/accumulate, " + a.kv_dtype + " KV", "data": "synthetic",
+            "config": {"workload": f"csm-1b ({a.weights}), B={B}/GPU, {a.ctx}-frame synthetic context prefilled (untimed), "
                                    f"{K} timed frame-steps after {W} warm-up, topk={a.topk} T={a.temperature}, "
                                    f"hipGraph={'on' if use_graph else 'off'}",
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
@@ -233,14 +236,14 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("ctx") == a.ctx:
+                if rec.get("batch") == B and rec.get("ctx") == a.ctx and a.weights == "bf16":
                     out["roofline"]["traffic"] = rec["hbm_bytes_per_step"]
                     out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, see DESIGN.md)"
             except Exception:
                 pass
         # parity of the benchmarked run against the reference's golden vectors (same context at rank 0, B=1)
         gpath = os.path.join(ROOT, "tests", "golden", "csm1b_cfg2_bf16w_fp32.npz")
-        if B == 1 and a.ctx == 512 and a.topk == 1 and os.path.exists(gpath):
+        if B == 1 and a.ctx == 512 and a.topk == 1 and a.weights == "bf16" and os.path.exists(gpath):
             import numpy as np
             g = np.load(gpath)
             n = min(W + K, g["tokens"].shape[1])

@@ -6,6 +6,8 @@
 #define CSM_WAVE 64
 
 typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic is done in fp32
+struct fp8_t { uint8_t v; };  // OCP e4m3fn byte (gfx950 v_cvt_*_fp8 is OCP, not fnuz); distinct type for overloads
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -53,6 +55,23 @@ struct W8<float> {
   __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
 };
 
+template <>
+struct W8<fp8_t> {  // 8 e4m3 weights = one 8-byte load; widened by v_cvt_pk_f32_fp8 (exact)
+  uint2 r;
+  __device__ __forceinline__ void load(const fp8_t* p) { r = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void load_nt(const fp8_t* p) {
+    const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
+    r.x = (uint32_t)u;
+    r.y = (uint32_t)(u >> 32);
+  }
+  __device__ __forceinline__ void zero() { r.x = 0u; r.y = 0u; }
+  __device__ __forceinline__ float get(int i) const {
+    const int w = (int)(i < 4 ? r.x : r.y);   // word_sel must be a literal
+    const f32x2 f = (i & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+    return (i & 1) ? f[1] : f[0];
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -66,5 +85,6 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+
 __device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_kv(bf16_t* p, float v) { *p = f32_to_bf16(v); }

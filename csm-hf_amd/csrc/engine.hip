@@ -121,6 +121,9 @@ struct csm_engine {
   std::vector<void*> allocs;
 };
 
+static inline int emb_dtype(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? CSM_DTYPE_BF16 : e->cfg.weight_dtype; }
+static inline size_t w_esz(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? 1 : (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4); }
+
 template <typename T>
 static int dalloc(csm_engine* e, T** p, size_t n) {
   void* q = nullptr;
@@ -146,6 +149,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   if (cfg->abi_version != CSM_ABI_VERSION) return fail(CSM_ERR_ARG, "ABI version mismatch: %d vs %d", cfg->abi_version, CSM_ABI_VERSION);
   if (int r = check_stack(cfg->backbone, "backbone")) return r;
   if (int r = check_stack(cfg->decoder, "decoder")) return r;
+  if (cfg->weight_dtype < 0 || cfg->weight_dtype > 2 || cfg->kv_dtype < 0 || cfg->kv_dtype > 1) return fail(CSM_ERR_ARG, "bad dtype");
   if (cfg->max_batch < 1 || cfg->max_len < 1 || cfg->max_frames < 1 || cfg->max_prefill_rows < 1)
     return fail(CSM_ERR_ARG, "max_batch/max_len/max_frames/max_prefill_rows must be >= 1");
   if (cfg->n_codebooks < 2) return fail(CSM_ERR_ARG, "n_codebooks must be >= 2");
@@ -250,6 +254,7 @@ static int bind_stack(Stack& s, const csm_stack_weights_t& w, const char* name) 
 extern "C" int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w) {
   if (!e || !w) return fail(CSM_ERR_ARG, "null argument");
   if (!w->text_emb || !w->audio_emb || !w->proj_head0 || !w->audio_head_t) return fail(CSM_ERR_ARG, "null top-level weight");
+  if (e->cfg.weight_dtype == CSM_DTYPE_FP8 && (!w->s_proj_head0 || !w->s_audio_head)) return fail(CSM_ERR_ARG, "fp8 weights need row scales");
   if (int r = bind_stack(e->bb, w->backbone, "backbone")) return r;
   if (int r = bind_stack(e->dec, w->decoder, "decoder")) return r;
   e->w = *w;
@@ -335,7 +340,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
   GemvArgs a{};
   a.nt = nt;
-  a.W = w.wqkv; a.N = s.nqkv(); a.K = H; a.x = h; a.ldx = ldh; a.ln = w.ln1; a.eps = s.c.rms_eps;
+  a.W = w.wqkv; a.wscale = w.sqkv; a.N = s.nqkv(); a.K = H; a.x = h; a.ldx = ldh; a.ln = w.ln1; a.eps = s.c.rms_eps;
   a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
   a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
   a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
@@ -343,7 +348,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
 
   GemvArgs o{};
   o.nt = nt;
-  o.W = w.wo; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
+  o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
   if (fuse_attn) {
     // short cache (decoder, <= 32 positions): SDPA runs as the prologue of the o_proj launch
     o.x = qb; o.n_q = nq; o.n_kv = nkv; o.hd = hd; o.pos_ptr = pos_ptr; o.pos_const = pos_const;
@@ -361,12 +366,12 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
 
   GemvArgs g{};
   g.nt = nt;
-  g.W = w.wgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
+  g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
   LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
 
   GemvArgs d{};
   d.nt = nt;
-  d.W = w.wd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
+  d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
   LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
 }
@@ -375,7 +380,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
 static int backbone_head(csm_engine* e, const float* h, int ldh, int M, bool bump_len, bool bump_frame) {
   GemvArgs a{};
   a.nt = e->nt_backbone;
-  a.W = e->w.proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = e->cfg.backbone.hidden;
+  a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = e->cfg.backbone.hidden;
   a.x = h; a.ldx = ldh; a.ln = e->bb.final_norm; a.eps = e->bb.c.rms_eps; a.out = e->head_out; a.ldo = e->ld_head;
   if (bump_len) {
     a.bump_a = e->d_len;
@@ -399,7 +404,7 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
     em.max_frames = e->cfg.max_frames;
   }
   em.out = e->h_bb;
-  LCK(launch_embed(e->stream, e->cfg.weight_dtype, B, em));
+  LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
     LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false));
   if (want_last_h) {
@@ -435,7 +440,8 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame
-      a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4);
+      a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * w_esz(e);
+      a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(p - 1) * V : nullptr;
       a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
       a.out = e->logits_dec; a.ldo = (V + 3) & ~3;
       LCK(gemv_rows(e, B, PRO_NORM, EPI_STORE, a));
@@ -505,12 +511,12 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
   EmbedArgs em{};
   em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
   em.ids = ids; em.mask = mask; em.out = e->p_h;
-  LCK(launch_embed(e->stream, wd, (int)R, em));
+  LCK(launch_embed(e->stream, emb_dtype(e), (int)R, em));
   for (int l = 0; l < s.c.layers; ++l) {
     const csm_layer_weights_t& w = s.layers[l];
     LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
     GemmArgs g{};
-    g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
+    g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
     LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
     ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
@@ -522,14 +528,14 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = e->d_kv_start; t.nsplit = 1; t.out = e->p_att;
     LCK(launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t));
     GemmArgs o{};
-    o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
+    o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
     LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
     LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
     GemmArgs gu{};
-    gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
+    gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
-    d.A = e->p_act; d.lda = F; d.W = w.wd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
+    d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
     LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
   }
   // last position of every sequence: rows b*S + S-1
@@ -639,14 +645,14 @@ extern "C" int csm_build_proj_table(csm_engine_t* e, float* out) {
   if (!e || !e->bound || !out) return fail(CSM_ERR_STATE, "weights not bound / null output");
   const int Hb = e->cfg.backbone.hidden, Hd = e->cfg.decoder.hidden;
   const size_t rows = (size_t)e->cfg.n_codebooks * e->cfg.audio_vocab;
-  const size_t esz = e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4;
+  const size_t esz = emb_dtype(e) == CSM_DTYPE_BF16 ? 2 : 4;
   const size_t chunk = e->cfg.max_prefill_rows;
   // projection.weight = first Hd rows of proj_head0
   for (size_t r0 = 0; r0 < rows; r0 += chunk) {
     const size_t n = rows - r0 < chunk ? rows - r0 : chunk;
-    LCK(launch_widen(e->stream, e->cfg.weight_dtype, (const char*)e->w.audio_emb + r0 * Hb * esz, e->p_xn, n * Hb));
+    LCK(launch_widen(e->stream, emb_dtype(e), (const char*)e->w.audio_emb + r0 * Hb * esz, e->p_xn, n * Hb));
     GemmArgs g{};
-    g.A = e->p_xn; g.lda = Hb; g.W = e->w.proj_head0; g.R = (int)n; g.N = Hd; g.K = Hb; g.C = out + r0 * Hd; g.ldc = Hd;
+    g.A = e->p_xn; g.lda = Hb; g.W = e->w.proj_head0; g.wscale = e->w.s_proj_head0; g.R = (int)n; g.N = Hd; g.K = Hb; g.C = out + r0 * Hd; g.ldc = Hd;
     LCK(launch_gemm(e->stream, e->cfg.weight_dtype, GEPI_STORE, g));
   }
   HIPCK(hipStreamSynchronize(e->stream));
@@ -660,7 +666,7 @@ extern "C" int csm_embed_sum(csm_engine_t* e, const int64_t* ids, const uint8_t*
   EmbedArgs em{};
   em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = e->cfg.backbone.hidden; em.C = e->cfg.n_codebooks;
   em.V = e->cfg.audio_vocab; em.ids = ids; em.mask = mask; em.out = out;
-  LCK(launch_embed(e->stream, e->cfg.weight_dtype, rows, em));
+  LCK(launch_embed(e->stream, emb_dtype(e), rows, em));
   return 0;
 }
 
@@ -670,11 +676,11 @@ extern "C" int csm_rmsnorm(csm_engine_t* e, const float* x, const float* w, int 
   return 0;
 }
 
-extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* x, int M, const float* ln,
-                        float eps, float* y) {
+extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, const float* wscale, int N, int K, const float* x,
+                        int M, const float* ln, float eps, float* y) {
   if (!e || M < 1 || M > 64) return fail(CSM_ERR_ARG, "bad gemv arguments");
   GemvArgs a{};
-  a.W = W; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps; a.out = y; a.ldo = N;
+  a.W = W; a.wscale = wscale; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps; a.out = y; a.ldo = N;
   const int save = e->cfg.weight_dtype;
   e->cfg.weight_dtype = wdtype;
   int r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, EPI_STORE, a);
@@ -683,10 +689,11 @@ extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, int N, int K
   return 0;
 }
 
-extern "C" int csm_gemm(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* A, int R, float* C) {
+extern "C" int csm_gemm(csm_engine_t* e, const void* W, int wdtype, const float* wscale, int N, int K, const float* A,
+                        int R, float* C) {
   if (!e) return fail(CSM_ERR_ARG, "null engine");
   GemmArgs g{};
-  g.A = A; g.lda = K; g.W = W; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
+  g.A = A; g.lda = K; g.W = W; g.wscale = wscale; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
   LCK(launch_gemm(e->stream, wdtype, GEPI_STORE, g));
   return 0;
 }

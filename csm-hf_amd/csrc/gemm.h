@@ -17,6 +17,7 @@ struct GemmArgs {
   const float* A;  // [R][lda]
   int lda;
   const void* W;  // [N][K]
+  const float* wscale;  // per-row scale (fp8 weights), nullable
   int R, N, K;
   float* C;  // STORE/RESID: [R][ldc]; SWIGLU: [R][ldc] with N/2 columns
   int ldc;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
       for (int reg = 0; reg < 16; ++reg) {
         const int r = r0 + wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         const int n = n0 + wc * 64 + ni * 32 + (lane & 31);
-        const float v = acc[mi][ni][reg];
+        const float v = acc[mi][ni][reg] * (a.wscale ? a.wscale[n] : 1.f);
         if (EPI == GEPI_SWIGLU) {
           const float o = __shfl_xor(v, 1, 64);  // even lane: gate (own), up (partner)
           if (!(lane & 1) && r < a.R) a.C[(size_t)r * a.ldc + (n >> 1)] = (v / (1.f + __expf(-v))) * o;

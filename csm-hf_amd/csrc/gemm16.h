@@ -1,4 +1,5 @@
-// Skinny GEMM on the matrix cores for batched decode: y[M<=16, N] = f(x)[M,K] @ W[N,K]^T, bf16 weights.
+// Skinny GEMM on the matrix cores for batched decode: y[M<=16, N] = f(x)[M,K] @ W[N,K]^T, bf16 or fp8 weights
+// (fp8 e4m3 is widened to bf16 in registers -- exact -- and scaled per output row in the epilogue).
 //
 // Roofline: HBM (weights N*K*2 bytes read once per launch, independent of M).  Each 16x16x32 MFMA consumes
 // a 16-row x 32-k weight fragment straight from registers (A operand) against the activations (B operand);
@@ -36,6 +37,47 @@ __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
+// A-operand fragment (8 consecutive k of one weight row) as bf16x8, from bf16 or fp8 storage (exact widening)
+template <typename WT>
+struct AFrag;
+template <>
+struct AFrag<bf16_t> {
+  u32x4 r;
+  __device__ __forceinline__ void load(const bf16_t* p, int nt) {
+    if (nt) r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else r = *reinterpret_cast<const u32x4*>(p);
+  }
+  __device__ __forceinline__ bf16x8 get() const {
+    bf16x8 f;
+    *reinterpret_cast<u32x4*>(&f) = r;
+    return f;
+  }
+};
+template <>
+struct AFrag<fp8_t> {
+  uint2 r;
+  __device__ __forceinline__ void load(const fp8_t* p, int nt) {
+    if (nt) {
+      const uint64_t u = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
+      r.x = (uint32_t)u;
+      r.y = (uint32_t)(u >> 32);
+    } else {
+      r = *reinterpret_cast<const uint2*>(p);
+    }
+  }
+  __device__ __forceinline__ bf16x8 get() const {  // e4m3 -> fp32 (exact) -> bf16 by truncation (exact: 4 significant bits)
+    bf16x8 f;
+    uint32_t* pf = reinterpret_cast<uint32_t*>(&f);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int w = (int)(h < 2 ? r.x : r.y);   // word_sel must be a literal
+      const f32x2 v = (h & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+      pf[h] = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+    }
+    return f;
+  }
+};
+
 // panel row of tile t, local row r (0..15).  QKV panels pair the two RoPE halves of a head (PT == 2).
 template <int EPI, int PT>
 __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int r) {
@@ -51,7 +93,7 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // weights) is issued before anything is consumed.  grid = (row panels, KB); KB > 1 splits K across
 // workgroups (K = 8192 down_proj): partial panels go to `slabs`, a per-panel ticket elects the last arriver,
 // which sums them in fixed order (deterministic) and runs the epilogue.  PRO_NORM needs KB == 1.
-template <typename KT, int PRO, int EPI, int NW, int PT>
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag
   float* red = lds;
@@ -59,7 +101,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   int* flag = reinterpret_cast<int*>(panel + PT * 256);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+  const WT* W = reinterpret_cast<const WT*>(a.W);
   const int m = lane & 15, g = lane >> 4;
   const bool mlive = m < M;
   const int k0 = ((int)blockIdx.y * NW + wave) * 128 + g * 32;
@@ -92,17 +134,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       }
     }
   }
-  u32x4 wf[PT][4];
+  AFrag<WT> wf[PT][4];
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
     n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
-    const bf16_t* wr = W + (size_t)n * K + k0;
+    const WT* wr = W + (size_t)n * K + k0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (a.nt) wf[t][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + j * 8));
-      else wf[t][j] = *reinterpret_cast<const u32x4*>(wr + j * 8);
-    }
+    for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 8, a.nt);
   }
   const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
   f32x4 xa[4], xb[4];
@@ -151,8 +190,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     split3(xa[j], xb[j], xh, xm, xl);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-      bf16x8 af;
-      *reinterpret_cast<u32x4*>(&af) = wf[t][j];
+      const bf16x8 af = wf[t][j].get();
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl, acc[t], 0, 0, 0);  // small terms first
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh, acc[t], 0, 0, 0);
@@ -212,14 +250,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     if (mm >= M) continue;
     const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
     if (n >= a.N) continue;
-    const float v = panel[i];
+    const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f);
     if (EPI == EPI_STORE) {
       a.out[(size_t)mm * a.ldo + n] = v;
     } else if (EPI == EPI_RESID) {
       a.out[(size_t)mm * a.ldo + n] = pre0[e] + v;
     } else if (EPI == EPI_SWIGLU) {
       if (!(reg & 1)) {
-        const float u = panel[i + 1];
+        const float u = panel[i + 1] * (a.wscale ? a.wscale[n + 1] : 1.f);
         a.out[(size_t)mm * a.ldo + (n >> 1)] = (v / (1.f + __expf(-v))) * u;
       }
     } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
@@ -232,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       KT* vc = reinterpret_cast<KT*>(a.vcache);
       if (head < a.n_q + a.n_kv) {
         if (t == 0) {
-          const float v0 = v, v1 = panel[256 + (i & 255)];
+          const float v0 = v, v1 = panel[256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f);
           const float c = pre0[e], sn = pre1[e];
           const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
           if (head < a.n_q) {

@@ -1,7 +1,7 @@
 // Instantiations + launcher of the MFMA skinny GEMM (gemm16.h).
 #include "gemm16.h"
 
-template <typename KT, int PRO, int EPI, int NW, int PT>
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
 static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
                       int n_tickets) {
   int gx;
@@ -9,20 +9,20 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16) * sizeof(float);
-  hipLaunchKernelGGL((gemm16_kernel<KT, PRO, EPI, NW, PT>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 
-template <typename KT, int PRO, int EPI, int PT>
+template <typename WT, typename KT, int PRO, int EPI, int PT>
 static int launch_nw(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
-  if (nw == 16) return launch_g16<KT, PRO, EPI, 16, PT>(st, M, KB, a, slabs, sf, tk, nt);
-  if (nw == 8) return launch_g16<KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
-  return launch_g16<KT, PRO, EPI, 4, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  if (nw == 16) return launch_g16<WT, KT, PRO, EPI, 16, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  if (nw == 8) return launch_g16<WT, KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  return launch_g16<WT, KT, PRO, EPI, 4, PT>(st, M, KB, a, slabs, sf, tk, nt);
 }
 
-int launch_gemm16(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
-                  size_t slab_floats, int* tickets, int n_tickets) {
-  if (wdtype != 1 || M < 1 || M > 16 || a.configure_only) return -2;
+template <typename WT>
+static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                           size_t slab_floats, int* tickets, int n_tickets) {
   if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
   if (a.K % 512 != 0 || a.ldx % 4 != 0) return -2;
   // waves per workgroup x workgroup-level K splits: every wave owns exactly one 128-wide chunk
@@ -37,18 +37,25 @@ int launch_gemm16(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int e
   if (nchunks % nw) return -2;
   if (epi == EPI_QKV) {
     if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || KB != 1) return -2;
-    if (kvdtype == 1) return launch_nw<bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-    return launch_nw<float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    if (kvdtype == 1) return launch_nw<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    return launch_nw<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
   // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels
   const int ntiles = (a.N + 15) / 16;
   const bool big = (ntiles / 4) * KB >= 128;
 #define G16(P, E)                                                                                              \
   if (pro == P && epi == E) {                                                                                  \
-    if (big) return launch_nw<float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \
-    return launch_nw<float, P, E, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);                \
+    if (big) return launch_nw<WT, float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \
+    return launch_nw<WT, float, P, E, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);                \
   }
   G16(PRO_PLAIN, EPI_STORE) G16(PRO_NORM, EPI_STORE) G16(PRO_PLAIN, EPI_RESID) G16(PRO_NORM, EPI_SWIGLU)
 #undef G16
   return -2;
+}
+
+int launch_gemm16(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                  size_t slab_floats, int* tickets, int n_tickets) {
+  if ((wdtype != 1 && wdtype != 2) || M < 1 || M > 16 || a.configure_only) return -2;
+  if (wdtype == 2) return launch_gemm16_t<fp8_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
+  return launch_gemm16_t<bf16_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
 }

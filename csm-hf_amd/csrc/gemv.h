@@ -26,6 +26,7 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
 struct GemvArgs {
   const void* W;
+  const float* wscale;  // per-output-row scale (fp8 weights), nullable
   int N, K;
   const float* x;  // [M][ldx]   (PRO_ATTN: q [M][n_q*hd], pre-scaled, rotated)
   int ldx;
@@ -136,8 +137,14 @@ __device__ __forceinline__ GemvTask gemv_map_task(const GemvArgs& a, int t, int 
 template <typename KT, int EPI, int M>
 struct GemvEpi {
   float a0[M], a1[M];
+  float sc0, sc1;  // row scales of the two outputs (fp8 weights), 1 otherwise
   int pos[M];
   __device__ __forceinline__ void prefetch(const GemvArgs& a, const GemvTask& k) {
+    sc0 = sc1 = 1.f;
+    if (a.wscale && k.live) {
+      sc0 = a.wscale[k.r0];
+      if (k.has1) sc1 = a.wscale[k.r1];
+    }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       a0[m] = a1[m] = 0.f;
@@ -158,6 +165,8 @@ struct GemvEpi {
   }
   // one lane writes the two outputs of the task for batch row m
   __device__ __forceinline__ void store(const GemvArgs& a, const GemvTask& k, int m, float v0, float v1) const {
+    v0 *= sc0;
+    v1 *= sc1;
     if (EPI == EPI_STORE) {
       a.out[(size_t)m * a.ldo + k.r0] = v0;
       if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = v1;

@@ -3,7 +3,7 @@
 #include "gemv.h"
 
 #define DECL(w, k) int launch_gemv_w##w##_k##k(hipStream_t st, int kvb, int M, int pro, int epi, const GemvArgs& a);
-DECL(0, 1) DECL(0, 2) DECL(0, 4) DECL(1, 1) DECL(1, 2) DECL(1, 4)
+DECL(0, 1) DECL(0, 2) DECL(0, 4) DECL(1, 1) DECL(1, 2) DECL(1, 4) DECL(2, 1) DECL(2, 2) DECL(2, 4)
 #undef DECL
 
 // K-split heuristic: keep every wave-slice to one batch of loads (<= 256 chunks of 8 weights), then
@@ -17,6 +17,11 @@ static int pick_ks(int ntask, int K) {
 
 static int launch_dispatch(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, int ks, const GemvArgs& a) {
   const int kvb = kvdtype == 1;
+  if (wdtype == 2) {
+    if (ks == 1) return launch_gemv_w2_k1(st, kvb, M, pro, epi, a);
+    if (ks == 2) return launch_gemv_w2_k2(st, kvb, M, pro, epi, a);
+    return launch_gemv_w2_k4(st, kvb, M, pro, epi, a);
+  }
   if (wdtype == 1) {
     if (ks == 1) return launch_gemv_w1_k1(st, kvb, M, pro, epi, a);
     if (ks == 2) return launch_gemv_w1_k2(st, kvb, M, pro, epi, a);
@@ -27,7 +32,7 @@ static int launch_dispatch(hipStream_t st, int wdtype, int kvdtype, int M, int p
   return launch_gemv_w0_k4(st, kvb, M, pro, epi, a);
 }
 
-// wdtype/kvdtype: 0 = fp32, 1 = bf16
+// wdtype: 0 = fp32, 1 = bf16, 2 = fp8 e4m3fn (+ a.wscale); kvdtype: 0 = fp32, 1 = bf16
 int launch_gemv(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a) {
   if (a.K % 8 != 0 || a.K < 8) return -1;
   const int ntask = (epi == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
@@ -40,7 +45,7 @@ int gemv_configure_all() {
   a.configure_only = 1;
   static const int combos[6][2] = {{PRO_PLAIN, EPI_STORE}, {PRO_NORM, EPI_STORE}, {PRO_PLAIN, EPI_RESID},
                                    {PRO_ATTN, EPI_RESID}, {PRO_NORM, EPI_SWIGLU}, {PRO_NORM, EPI_QKV}};
-  for (int wd = 0; wd < 2; ++wd)
+  for (int wd = 0; wd < 3; ++wd)
     for (int kd = 0; kd < 2; ++kd)
       for (int M = 1; M <= 4; ++M)
         for (int ks = 1; ks <= 4; ks *= 2)

@@ -41,6 +41,7 @@ static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
 
 int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.R < 1) return -1;
+  if (wdtype == 2) return launch_gemm_t<fp8_t>(st, epi, a);
   return wdtype == 1 ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_t<float>(st, epi, a);
 }
 

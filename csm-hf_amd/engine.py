@@ -17,8 +17,8 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 1
-DT_F32, DT_BF16 = 0, 1
+ABI_VERSION = 2
+DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
     "csm_engine_create", "csm_engine_destroy", "csm_bind_weights", "csm_build_proj_table", "csm_set_proj_table",
@@ -43,7 +43,8 @@ class EngineCfg(C.Structure):
 
 class LayerW(C.Structure):
     _fields_ = [("wqkv", C.c_void_p), ("wo", C.c_void_p), ("wgu", C.c_void_p), ("wd", C.c_void_p),
-                ("ln1", C.c_void_p), ("ln2", C.c_void_p)]
+                ("ln1", C.c_void_p), ("ln2", C.c_void_p),
+                ("sqkv", C.c_void_p), ("so", C.c_void_p), ("sgu", C.c_void_p), ("sd", C.c_void_p)]
 
 
 class StackW(C.Structure):
@@ -53,7 +54,8 @@ class StackW(C.Structure):
 
 class Weights(C.Structure):
     _fields_ = [("backbone", StackW), ("decoder", StackW), ("text_emb", C.c_void_p), ("audio_emb", C.c_void_p),
-                ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p), ("proj_table", C.c_void_p)]
+                ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p), ("proj_table", C.c_void_p),
+                ("s_proj_head0", C.c_void_p), ("s_audio_head", C.c_void_p)]
 
 
 class Sampling(C.Structure):
@@ -102,8 +104,8 @@ def load_library(path: Optional[str] = None):
     lib.csm_last_generate_ms.argtypes = [vp, C.POINTER(f32)]
     lib.csm_embed_sum.argtypes = [vp, vp, vp, i32, vp]
     lib.csm_rmsnorm.argtypes = [vp, vp, vp, i32, i32, f32, vp]
-    lib.csm_gemv.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f32, vp]
-    lib.csm_gemm.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.csm_gemv.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, vp, f32, vp]
+    lib.csm_gemm.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, vp]
     lib.csm_sample_topk.argtypes = [vp, vp, i32, i32, f32, i32, C.c_uint64, vp, vp]
     lib.csm_attn_decode.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp]
     lib.csm_rope_scatter.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
@@ -152,10 +154,33 @@ def rope_tables(lc, n_pos: int):
     return ang.cos().contiguous(), ang.sin().contiguous()
 
 
-def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: torch.dtype, max_len: int):
-    """Reference checkpoint layout -> engine layout (include/csm_hip.h)."""
+FP8_MAX = 448.0   # OCP e4m3fn
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """Per-output-row symmetric e4m3fn quantisation: w[n,:] ~= q[n,:] * s[n].  Returns (uint8 bytes, fp32 scales)."""
+    w32 = w.float()
+    s = (w32.abs().amax(dim=-1, keepdim=True) / FP8_MAX).clamp_min(1e-12)
+    q = (w32 / s).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), s.squeeze(-1).contiguous()
+
+
+def dequantize_fp8_rows(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    return q.view(torch.float8_e4m3fn).float() * s.unsqueeze(-1)
+
+
+def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: torch.dtype, max_len: int, fp8: bool = False):
+    """Reference checkpoint layout -> engine layout (include/csm_hip.h).
+    `fp8=True` (BASELINE config 5): the linear matrices are stored as e4m3fn + per-row fp32 scales; embedding
+    tables and norm weights keep `wdtype` (bf16)."""
     def mat(t):
         return t.detach().to(device=device, dtype=wdtype).contiguous()
+
+    def qmat(d, key, t):
+        if fp8:
+            d[key], d["s" + key[1:] if key.startswith("w") else "s_" + key] = quantize_fp8_rows(t)
+        else:
+            d[key] = t
 
     def vec(t):
         return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -171,16 +196,26 @@ def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: to
             g, u = mat(sd[f"{p}.mlp.gate_proj.weight"]), mat(sd[f"{p}.mlp.up_proj.weight"])
             wgu = torch.stack([g, u], dim=1).reshape(2 * g.shape[0], g.shape[1]).contiguous()
             del g, u
-            layers.append(dict(wqkv=wqkv, wo=mat(sd[f"{p}.self_attn.o_proj.weight"]), wgu=wgu,
-                               wd=mat(sd[f"{p}.mlp.down_proj.weight"]), ln1=vec(sd[f"{p}.input_layernorm.weight"]),
-                               ln2=vec(sd[f"{p}.post_attention_layernorm.weight"])))
+            L = dict(ln1=vec(sd[f"{p}.input_layernorm.weight"]), ln2=vec(sd[f"{p}.post_attention_layernorm.weight"]))
+            qmat(L, "wqkv", wqkv)
+            qmat(L, "wo", mat(sd[f"{p}.self_attn.o_proj.weight"]))
+            qmat(L, "wgu", wgu)
+            qmat(L, "wd", mat(sd[f"{p}.mlp.down_proj.weight"]))
+            del wqkv, wgu
+            layers.append(L)
         cos, sin = rope_tables(lc, npos)
         packed[prefix] = dict(layers=layers, final_norm=vec(sd[f"{prefix}.norm.weight"]), cos=cos.to(device),
                               sin=sin.to(device), npos=npos)
     packed["text_emb"] = mat(sd["text_embeddings.weight"])
     packed["audio_emb"] = mat(sd["audio_embeddings.weight"])
-    packed["proj_head0"] = torch.cat([mat(sd["projection.weight"]), mat(sd["codebook0_head.weight"])], 0).contiguous()
-    packed["audio_head_t"] = mat(sd["audio_head"]).transpose(1, 2).contiguous()
+    qmat(packed, "proj_head0", torch.cat([mat(sd["projection.weight"]), mat(sd["codebook0_head.weight"])], 0).contiguous())
+    aht = mat(sd["audio_head"]).transpose(1, 2).contiguous()
+    if fp8:
+        q, sc = quantize_fp8_rows(aht.reshape(-1, aht.shape[-1]))
+        packed["audio_head_t"], packed["s_audio_head_t"] = q.view(aht.shape), sc
+    else:
+        packed["audio_head_t"] = aht
+    packed["fp8"] = fp8
     return packed
 
 
@@ -189,11 +224,16 @@ class Engine:
 
     def __init__(self, cfg: CSMConfig, state_dict: Dict[str, torch.Tensor], device, dtype: torch.dtype,
                  max_batch: int = 1, max_len: int = 2048, max_frames: int = 512, max_prefill_rows: int = 2048,
-                 kv_dtype: torch.dtype = torch.float32, packed=None):
+                 kv_dtype: torch.dtype = torch.float32, packed=None, weight_format: str = "native"):
         if not torch.cuda.is_available():
             raise RuntimeError("csm_hf_amd needs an AMD GPU (gfx950); no CPU fallback exists")
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"unsupported model dtype {dtype}: use torch.float32 or torch.bfloat16")
+        if weight_format not in ("native", "fp8"):
+            raise ValueError(f"unknown weight_format {weight_format!r}")
+        self.fp8 = weight_format == "fp8"
+        if self.fp8 and dtype != torch.bfloat16:
+            raise ValueError("weight_format='fp8' needs a bf16 model (embeddings and norms stay bf16)")
         self.lib = load_library()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -211,7 +251,7 @@ class Engine:
             dst.hidden, dst.ffn, dst.layers = lc.hidden_size, lc.intermediate_size, lc.num_hidden_layers
             dst.n_q, dst.n_kv, dst.head_dim = lc.num_attention_heads, lc.num_key_value_heads, lc.head_dim
             dst.rms_eps = lc.rms_norm_eps
-        ec.weight_dtype = DT_BF16 if dtype == torch.bfloat16 else DT_F32
+        ec.weight_dtype = DT_FP8 if self.fp8 else (DT_BF16 if dtype == torch.bfloat16 else DT_F32)
         ec.kv_dtype = DT_BF16 if kv_dtype == torch.bfloat16 else DT_F32
         ec.max_batch, ec.max_len, ec.max_frames = max_batch, max_len, max_frames
         ec.max_prefill_rows = self.max_prefill_rows
@@ -219,7 +259,9 @@ class Engine:
         torch.cuda.set_device(self.device)
         torch.cuda.current_stream().synchronize()
         _ck(self.lib, self.lib.csm_engine_create(C.byref(ec), self.device.index or 0, None, C.byref(self._h)))
-        self.packed = packed if packed is not None else pack_weights(cfg, state_dict, self.device, dtype, max_len)
+        self.packed = packed if packed is not None else pack_weights(cfg, state_dict, self.device, dtype, max_len, fp8=self.fp8)
+        if bool(self.packed.get("fp8", False)) != self.fp8:
+            raise ValueError("packed weights were built for a different weight_format")
         if self.packed["backbone"]["npos"] < max_len:
             cos, sin = rope_tables(cfg.backbone_config, max_len)
             self.packed["backbone"].update(cos=cos.to(self.device), sin=sin.to(self.device), npos=max_len)
@@ -245,6 +287,9 @@ class Engine:
                 arr[i].wqkv, arr[i].wo, arr[i].wgu, arr[i].wd = (l["wqkv"].data_ptr(), l["wo"].data_ptr(),
                                                                  l["wgu"].data_ptr(), l["wd"].data_ptr())
                 arr[i].ln1, arr[i].ln2 = l["ln1"].data_ptr(), l["ln2"].data_ptr()
+                if self.fp8:
+                    arr[i].sqkv, arr[i].so, arr[i].sgu, arr[i].sd = (l["sqkv"].data_ptr(), l["so"].data_ptr(),
+                                                                     l["sgu"].data_ptr(), l["sd"].data_ptr())
             self._layer_arrays.append(arr)
             dst.layers = arr
             dst.final_norm = st["final_norm"].data_ptr()
@@ -255,6 +300,9 @@ class Engine:
         w.proj_head0 = self.packed["proj_head0"].data_ptr()
         w.audio_head_t = self.packed["audio_head_t"].data_ptr()
         w.proj_table = None
+        if self.fp8:
+            w.s_proj_head0 = self.packed["s_proj_head0"].data_ptr()
+            w.s_audio_head = self.packed["s_audio_head_t"].data_ptr()
         _ck(self.lib, self.lib.csm_bind_weights(self._h, C.byref(w)))
 
     def close(self):
@@ -403,25 +451,27 @@ class Engine:
         self.sync()
         return out
 
-    def k_gemv(self, W, x, ln=None, eps=1e-5):
+    def k_gemv(self, W, x, ln=None, eps=1e-5, scale=None):
         W = W.to(self.device).contiguous()
+        sc = None if scale is None else scale.to(self.device, torch.float32).contiguous()
         x = x.to(self.device, torch.float32).contiguous()
         lnw = None if ln is None else ln.to(self.device, torch.float32).contiguous()
         y = torch.empty(x.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
         torch.cuda.current_stream().synchronize()
-        wd = DT_BF16 if W.dtype == torch.bfloat16 else DT_F32
-        _ck(self.lib, self.lib.csm_gemv(self._h, _ptr(W), wd, W.shape[0], W.shape[1], _ptr(x), x.shape[0], _ptr(lnw),
-                                        eps, _ptr(y)))
+        wd = {torch.bfloat16: DT_BF16, torch.uint8: DT_FP8}.get(W.dtype, DT_F32)
+        _ck(self.lib, self.lib.csm_gemv(self._h, _ptr(W), wd, _ptr(sc), W.shape[0], W.shape[1], _ptr(x), x.shape[0],
+                                        _ptr(lnw), eps, _ptr(y)))
         self.sync()
         return y
 
-    def k_gemm(self, W, A):
+    def k_gemm(self, W, A, scale=None):
         W = W.to(self.device).contiguous()
+        sc = None if scale is None else scale.to(self.device, torch.float32).contiguous()
         A = A.to(self.device, torch.float32).contiguous()
         out = torch.empty(A.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
         torch.cuda.current_stream().synchronize()
-        wd = DT_BF16 if W.dtype == torch.bfloat16 else DT_F32
-        _ck(self.lib, self.lib.csm_gemm(self._h, _ptr(W), wd, W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out)))
+        wd = {torch.bfloat16: DT_BF16, torch.uint8: DT_FP8}.get(W.dtype, DT_F32)
+        _ck(self.lib, self.lib.csm_gemm(self._h, _ptr(W), wd, _ptr(sc), W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out)))
         self.sync()
         return out
 

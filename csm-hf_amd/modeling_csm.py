@@ -144,6 +144,7 @@ class CSMModel(nn.Module):
         self._frame_pending = False
         self._caps = dict(max_batch=1, max_len=0, max_frames=0, max_prefill_rows=0)
         self.kv_dtype = torch.float32
+        self.weight_format = "native"   # "fp8": linear weights as e4m3fn + per-row scales (BASELINE config 5)
         self.use_graph = True
         self.seed = 0
 
@@ -220,6 +221,8 @@ class CSMModel(nn.Module):
         if p.device.type != "cuda":
             raise RuntimeError("CSMModel must be on an AMD GPU (model.to('cuda')): csm_hf_amd has no CPU path")
         c = self._caps
+        if self._engine is not None and self._engine.fp8 != (self.weight_format == "fp8"):
+            self._drop_engine()
         grow = (self._engine is None or batch > self._engine.max_batch or need_len > self._engine.max_len or
                 need_frames > self._engine.max_frames or prefill_rows > self._engine.max_prefill_rows)
         if grow:
@@ -234,7 +237,8 @@ class CSMModel(nn.Module):
                 self._epoch += 1
             self._engine = Engine(self.config, self.state_dict(), p.device, p.dtype, max_batch=c["max_batch"],
                                   max_len=c["max_len"], max_frames=c["max_frames"],
-                                  max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed)
+                                  max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed,
+                                  weight_format=self.weight_format)
         return self._engine
 
     # ---- helpers -----------------------------------------------------------------------------------------------

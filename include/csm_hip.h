@@ -27,9 +27,9 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 1
+#define CSM_ABI_VERSION 2
 
-enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1 };
+enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
 enum {
   CSM_OK = 0,
@@ -50,7 +50,7 @@ typedef struct {
   int32_t abi_version;   /* must be CSM_ABI_VERSION */
   int32_t text_vocab, audio_vocab, n_codebooks;
   csm_llama_cfg_t backbone, decoder;
-  int32_t weight_dtype;  /* CSM_DTYPE_*: dtype of all matrices and embedding tables */
+  int32_t weight_dtype;  /* CSM_DTYPE_*: dtype of all matrices; embedding tables use it too, except FP8 -> bf16 tables */
   int32_t kv_dtype;      /* CSM_DTYPE_*: backbone/decoder KV-cache storage */
   int32_t max_batch;     /* sequences per engine (per GPU) */
   int32_t max_len;       /* backbone KV positions per sequence (context + generated frames) */
@@ -64,10 +64,13 @@ typedef struct {
  *   wgu  [2*ffn, hidden]                  row 2i = gate_proj row i, row 2i+1 = up_proj row i
  *   wd   [hidden, ffn]
  *   ln1, ln2 [hidden]  fp32 always
+ *   sqkv, so, sgu, sd  per-output-row fp32 scales of the four matrices (CSM_DTYPE_FP8 only, else NULL):
+ *                      W[n,k] = fp8[n,k] * s[n]
  */
 typedef struct {
   const void *wqkv, *wo, *wgu, *wd;
   const float *ln1, *ln2;
+  const float *sqkv, *so, *sgu, *sd;
 } csm_layer_weights_t;
 
 typedef struct {
@@ -87,6 +90,8 @@ typedef struct {
   const void* audio_head_t;  /* [n_codebooks-1, audio_vocab, Hd] = audio_head.transpose(1,2) */
   const float* proj_table;   /* [n_codebooks*audio_vocab, Hd] fp32 = projection(audio_emb); may be NULL at
                                 bind time and supplied later by csm_build_proj_table / csm_set_proj_table */
+  const float* s_proj_head0;   /* [Hd + audio_vocab] row scales (FP8 only) */
+  const float* s_audio_head;   /* [(n_codebooks-1) * audio_vocab] row scales (FP8 only) */
 } csm_weights_t;
 
 typedef struct csm_engine csm_engine_t;
@@ -155,10 +160,11 @@ int csm_embed_sum(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int 
 /* K2 RMSNorm (transformers LlamaRMSNorm): out = w * (x * rsqrt(mean(x^2)+eps)) */
 int csm_rmsnorm(csm_engine_t* e, const float* x, const float* w, int rows, int hidden, float eps, float* out);
 /* K3/K8/K9 skinny GEMM y[M,N] = x[M,K] @ W[N,K]^T, M <= 16, optional fused RMSNorm prologue */
-int csm_gemv(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* x, int M,
-             const float* ln /* nullable */, float eps, float* y);
+int csm_gemv(csm_engine_t* e, const void* W, int wdtype, const float* wscale /* fp8 row scales, nullable */, int N,
+             int K, const float* x, int M, const float* ln /* nullable */, float eps, float* y);
 /* prefill GEMM C[R,N] = A[R,K] @ W[N,K]^T on the MFMA path */
-int csm_gemm(csm_engine_t* e, const void* W, int wdtype, int N, int K, const float* A, int R, float* C);
+int csm_gemm(csm_engine_t* e, const void* W, int wdtype, const float* wscale, int N, int K, const float* A, int R,
+             float* C);
 /* K12 sampler on a [rows,V] logits matrix; noise nullable; returns int32 indices */
 int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, int V, float temperature, int topk,
                     uint64_t seed, const float* noise, int32_t* out_idx);

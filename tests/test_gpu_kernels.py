@@ -191,3 +191,24 @@ def test_rope_scatter_and_attention(tiny, tiny_bf16, which):
             refp = torch.nn.functional.scaled_dot_product_attention(qr[1:2, :, -1:], kr[1:2, :, 37:], v[1:2, :, 37:], enable_gqa=True)
             torch.testing.assert_close(op[1], refp.reshape(-1), atol=3e-5, rtol=3e-5)
             torch.testing.assert_close(op[0], o1[0], atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("N,K", [(64, 256), (2051, 1024), (3075, 2048), (1024, 8192), (16384, 1024)])
+def test_gemv_and_gemm_fp8_weights(tiny, N, K):
+    """e4m3fn weights + per-row scales (BASELINE config 5): every kernel family against the dequantised fp64
+    product -- the widening is exact, so the only error is fp32 summation order."""
+    from csm_hf_amd.engine import quantize_fp8_rows, dequantize_fp8_rows
+    _, _, eng = tiny
+    W = rnd("W8", N, K, scale=0.05)
+    q, s = quantize_fp8_rows(W)
+    Wd = dequantize_fp8_rows(q, s).double()
+    assert float((Wd - W.double()).abs().max()) < 0.05 * 0.07          # e4m3: <= 2^-4 relative per weight
+    for M in (1, 3, 16):
+        x = rnd(f"x8{M}", M, K)
+        torch.testing.assert_close(eng.k_gemv(q, x, scale=s).cpu().double(), x.double() @ Wd.T, atol=3e-5, rtol=1e-5)
+        ln = rnd("ln8", K) + 1.0
+        ref = O.rmsnorm(x, ln, 1e-5).double() @ Wd.T
+        torch.testing.assert_close(eng.k_gemv(q, x, ln=ln, eps=1e-5, scale=s).cpu().double(), ref, atol=6e-5, rtol=1e-5)
+    if N % 128 == 0 and K % 32 == 0:
+        A = rnd("A8", 70, K)
+        torch.testing.assert_close(eng.k_gemm(q, A, scale=s).cpu().double(), A.double() @ Wd.T, atol=3e-5, rtol=1e-5)
