@@ -102,8 +102,10 @@ struct csm_engine {
   int h_len = 0, h_frame = 0;
   bool ready = false;   // head_out holds valid c0 logits
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
-  int fuse_dec_attn = 1;
+  int fuse_dec_attn = 0;  // measured (round 1): separate 2-workgroup attention + register-path o_proj is 4 % faster per frame
   int use_mfma = 1;
+  int fuse_sample = 1;   // B == 1 greedy: argmax folded into the head launch + next QKV prologue
+  float2* am_part = nullptr;
   float* g16_slabs = nullptr;
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
@@ -209,6 +211,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->p_att, R * nqb)) || (r = dalloc(e, &e->p_act, R * cfg->backbone.ffn)) ||
       (r = dalloc(e, &e->p_row_seq, R)) || (r = dalloc(e, &e->p_row_pos, R)))
     return r;
+  if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
   e->g16_slab_floats = (size_t)1 << 20;
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
@@ -297,6 +300,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
+  else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else return fail(CSM_ERR_ARG, "unknown option %s", name);
   drop_graphs(e);
   return 0;
@@ -335,7 +339,8 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
 
 // one Llama layer on M single-token rows (decode)
 static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
-                        float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn) {
+                        float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn,
+                        const GemvArgs* tok = nullptr) {
   const csm_layer_weights_t& w = s.layers[l];
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
   GemvArgs a{};
@@ -344,7 +349,14 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
   a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
   a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
-  LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
+  if (tok) {  // the row comes from (partials -> token -> projected-embedding table); h is written by workgroup 0
+    a.am_in = tok->am_in; a.am_n = tok->am_n; a.tok_table = tok->tok_table; a.tok_row_base = tok->tok_row_base;
+    a.tok_forced = tok->tok_forced; a.tok_ring = tok->tok_ring; a.tok_frame_ptr = tok->tok_frame_ptr;
+    a.tok_max_frames = tok->tok_max_frames; a.tok_C = tok->tok_C; a.tok_cb = tok->tok_cb; a.tok_x_out = h;
+    LCK(gemv_rows(e, M, PRO_TOKNORM, EPI_QKV, a));
+  } else {
+    LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
+  }
 
   GemvArgs o{};
   o.nt = nt;
@@ -431,13 +443,34 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     a.logits_trace = s->logits_trace;
     return launch_sample(e->stream, B, a);
   };
+  // B == 1 greedy without traces: codebooks 1..C-2 need no sampler launch -- the head writes per-task argmax
+  // pairs and the next pass's first QKV launch turns them into the token and its input row
+  const bool greedy = s->topk <= 1 || s->temperature == 0.f;
+  const bool fused = e->fuse_sample && B == 1 && greedy && !s->noise && !s->logits_trace && Hd % 512 == 0 && Hd <= 1024 &&
+                     (V + 1) / 2 <= 1088;
   LCK(sample(0, e->head_out + Hd, e->ld_head));
   for (int p = 0; p < C; ++p) {
     float* h = p == 0 ? e->head_out : e->dec_x;
     const int ldh = p == 0 ? e->ld_head : Hd;
+    GemvArgs tok{};
+    const bool use_tok = fused && p >= 2;   // input of pass p = token of codebook p-1 (sampled by head p-1)
+    if (use_tok) {
+      tok.am_in = e->am_part; tok.am_n = (V + 1) / 2; tok.tok_table = e->w.proj_table; tok.tok_row_base = (p - 1) * V;
+      tok.tok_forced = s->forced; tok.tok_ring = e->ring; tok.tok_frame_ptr = e->d_frame;
+      tok.tok_max_frames = e->cfg.max_frames; tok.tok_C = C; tok.tok_cb = p - 1;
+    }
     for (int l = 0; l < e->dec.c.layers; ++l)
-      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder, e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1));
-    if (p >= 1) {
+      LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder,
+                       e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr));
+    if (p >= 1 && fused && p < C - 1) {
+      GemvArgs a{};
+      a.nt = e->nt_backbone;
+      a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * w_esz(e);
+      a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(p - 1) * V : nullptr;
+      a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
+      a.out = e->logits_dec; a.ldo = (V + 3) & ~3; a.am_out = e->am_part; a.am_from = 0;
+      LCK(gemv_rows(e, B, PRO_NORM, EPI_ARGMAX, a));
+    } else if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame
       a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * w_esz(e);

@@ -21,8 +21,8 @@
 #include "attn_tile.h"
 #endif
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2, PRO_TOKNORM = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
 
 struct GemvArgs {
   const void* W;
@@ -53,6 +53,20 @@ struct GemvArgs {
   int* bump_a;
   int* bump_b;
   int nt;  // non-temporal weight loads
+  // ---- fused greedy sampling (B == 1): EPI_ARGMAX writes one (max value, row index) pair per task instead of the
+  // logits; PRO_TOKNORM (the next pass's first QKV launch) reduces the pairs to the token, takes its input row
+  // from the projected-embedding table and records the token -- replacing sample_kernel for codebooks 1..30.
+  float2* am_out;          // EPI_ARGMAX: [ceil((N - am_from) / 2)] partials
+  int am_from;             // rows below am_from are stored normally (EPI_STORE semantics)
+  const float2* am_in;     // PRO_TOKNORM: partials of the previous head launch
+  int am_n;
+  const float* tok_table;  // [C*V][K] fp32 projected audio embeddings
+  int tok_row_base;        // cb * V
+  const int64_t* tok_forced;  // teacher-forced tokens [B][max_frames][C], nullable
+  int64_t* tok_ring;          // generated-frame ring  [B][max_frames][C]
+  const int* tok_frame_ptr;
+  int tok_max_frames, tok_C, tok_cb;
+  float* tok_x_out;        // [K] residual stream of the new pass (written by workgroup 0)
   int configure_only;  // host-side: only set the kernel's dynamic-LDS attribute, do not launch
   int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
@@ -175,6 +189,17 @@ struct GemvEpi {
       if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = a1[m] + v1;
     } else if (EPI == EPI_SWIGLU) {
       a.out[(size_t)m * a.ldo + k.task] = (v0 / (1.f + __expf(-v0))) * v1;
+    } else if (EPI == EPI_ARGMAX) {  // M == 1
+      if (k.r0 < a.am_from) {
+        a.out[k.r0] = v0;
+        if (k.has1) a.out[k.r1] = v1;
+      } else {
+        const int i0 = k.r0 - a.am_from;
+        float bv = v0;
+        int bi = i0;
+        if (k.has1 && v1 > v0) { bv = v1; bi = i0 + 1; }   // tie -> lower index
+        a.am_out[i0 >> 1] = make_float2(bv, __int_as_float(bi));
+      }
     } else {  // EPI_QKV
       const int half = a.hd >> 1;
       const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
@@ -234,13 +259,50 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
     }
   }
+  const float* xsrc = a.x;
+  if (PRO == PRO_TOKNORM) {
+    // greedy token of the previous codebook = argmax over the head launch's per-task (value, index) pairs
+    constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
+    float2 pv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int idx = lane + 64 * j;
+      pv[j] = idx < a.am_n ? a.am_in[idx] : make_float2(-INFINITY, __int_as_float(0x7fffffff));
+    }
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int ci = __float_as_int(pv[j].y);
+      if (pv[j].x > bv || (pv[j].x == bv && ci < bi)) { bv = pv[j].x; bi = ci; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int f = *a.tok_frame_ptr;
+    const size_t slot = (size_t)f * a.tok_C + a.tok_cb;   // B == 1: row 0
+    int64_t feed = bi;
+    if (a.tok_forced) feed = a.tok_forced[slot];
+    if (blockIdx.x == 0 && tid == 0) a.tok_ring[slot] = bi;
+    xsrc = a.tok_table + ((size_t)feed + (size_t)a.tok_row_base) * K;
+  }
   f32x4 xa[U], xb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    xa[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512);
-    xb[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512 + 4);
+    xa[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512);
+    xb[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
   }
-  if (PRO == PRO_NORM) {  // KS == 1 here: the wave holds the whole row
+  if (PRO == PRO_TOKNORM && blockIdx.x == 0 && wave == 0) {   // the new pass's residual stream
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512) = xa[u];
+      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512 + 4) = xb[u];
+    }
+  }
+  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
     f32x4 la[U], lb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {

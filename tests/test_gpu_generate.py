@@ -457,3 +457,29 @@ def test_csm1b_fp8_weights(csm1b_bf16):
     low = (margin < 1e-4).nonzero()
     stop = int(low[0]) if len(low) else margin.numel()
     assert stop >= 32 and torch.equal(toks8.reshape(-1)[:stop], toks_r.reshape(-1)[:stop])
+
+
+def test_csm1b_fused_greedy_sampling_equals_sampler_kernel(gold, csm1b_bf16):
+    """B=1 greedy fast path (argmax folded into the head launch + next QKV prologue) == the sampler-kernel path,
+    free-running against the reference golden stream and under teacher forcing."""
+    m = csm1b_bf16
+    g = gold("csm1b_cfg1_bf16w_fp32")
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    eng = m._ensure_engine(1, 64 + 9, 8, 64)
+    outs = {}
+    for fuse in (1, 0):
+        eng.set_option("fuse_sample", fuse)
+        for forced in (None, torch.from_numpy(gold("csm1b_cfg1_bf16")["tokens"])):
+            eng.reset()
+            eng.set_kv_start([0])
+            eng.prefill(ids, mask)
+            fz = None
+            if forced is not None:
+                fz = torch.zeros(1, eng.max_frames, 32, dtype=torch.int64, device=DEV)
+                fz[:, :8] = forced.to(DEV)
+            eng.generate(eng.sampling(temperature=1.0, topk=1, forced=fz), 8, True)
+            outs[(fuse, forced is not None)] = eng.read_frames(0, 8).cpu()
+    eng.set_option("fuse_sample", 1)
+    assert np.array_equal(outs[(1, False)].numpy(), g["tokens"])
+    assert torch.equal(outs[(1, False)], outs[(0, False)])
+    assert torch.equal(outs[(1, True)], outs[(0, True)])
