@@ -65,7 +65,7 @@ struct Stack {
 };
 
 struct GraphKey {
-  int B, topk;
+  int B, topk, nsplit;
   float temperature;
   uint64_t seed;
   const void *noise, *forced, *ltrace, *htrace;
@@ -110,11 +110,16 @@ struct csm_engine {
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
   int nt_backbone = 1, nt_decoder = 0;
+  // KV splits of the backbone decode attention: the kernel is latency-bound per 32-key tile, so aim for
+  // <= 2 tiles per workgroup at the current length (+ headroom for the frames of this generate call) while
+  // keeping at least ~256 workgroups; frozen into the graph at capture time.
   int nsplit_eff() const {
     if (nsplit_bb > 0) return nsplit_bb;
-    int ns = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
+    const int by_len = (h_len + 256 + 63) / 64;
+    const int by_fill = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
+    const int ns = by_len > by_fill ? by_len : by_fill;
     int p = 1;
-    while (p * 2 <= ns && p < 64) p *= 2;
+    while (p < ns && p < 64) p *= 2;
     return p;
   }
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -606,7 +611,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
   HIPCK(hipEventRecord(e->ev0, e->stream));
   if (use_graph && n_frames > 0) {
     GraphKey k{};
-    k.B = e->B; k.topk = s->topk; k.temperature = s->temperature; k.seed = s->seed;
+    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature; k.seed = s->seed;
     k.noise = s->noise; k.forced = s->forced; k.ltrace = s->logits_trace; k.htrace = s->last_h_trace;
     auto it = e->graphs.find(k);
     if (it == e->graphs.end()) {
@@ -790,7 +795,8 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
     GemvArgs a{};
     a.W = (const char*)W + (size_t)(i % n_w) * w_stride; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps;
     a.out = y; a.ldo = (epi == EPI_SWIGLU) ? N / 2 : N; a.nt = nt;
-    a.grid_cap = grid_cap; a.v2_tasks = v2_tasks; a.force_generic = force_generic;
+    a.grid_cap = grid_cap & 0xffff; a.v2_tasks = v2_tasks; a.force_generic = force_generic;
+    a.g16_nw = (grid_cap >> 16) & 0xff; a.g16_kb = (grid_cap >> 24) & 0x3f; a.g16_pt = (grid_cap >> 30) & 1 ? 4 : ((grid_cap >> 16) ? 1 : 0);
     r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, epi, a);
   }
   e->cfg.weight_dtype = save_wd;

@@ -28,11 +28,15 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
   // waves per workgroup x workgroup-level K splits: every wave owns exactly one 128-wide chunk
   const int nchunks = a.K / 128;
   int nw = nchunks >= 16 ? 16 : (nchunks >= 8 ? 8 : 4), KB = 1;
-  if (nchunks > 16) {  // K = 8192: 4 waves x 16 splits keeps x traffic per workgroup small and fills the chip
+  if (nchunks > 16) {  // K = 8192: 8 waves x 8 workgroup-level splits (measured best of {4x16, 8x8, 16x4})
     if (pro == PRO_NORM) return -2;
-    nw = 4;
-    KB = nchunks / 4;
-    if (KB > 16) return -2;
+    nw = 8;
+    KB = nchunks / 8;
+    if (KB > 16 || nchunks % 8) return -2;
+  }
+  if (a.g16_nw > 0 && a.g16_kb > 0 && a.g16_nw * a.g16_kb == nchunks && (pro != PRO_NORM || a.g16_kb == 1)) {
+    nw = a.g16_nw;
+    KB = a.g16_kb;
   }
   if (nchunks % nw) return -2;
   if (epi == EPI_QKV) {
@@ -42,7 +46,7 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
   }
   // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels
   const int ntiles = (a.N + 15) / 16;
-  const bool big = (ntiles / 4) * KB >= 128;
+  const bool big = a.g16_pt ? a.g16_pt == 4 : (KB > 1 ? ntiles >= 128 : ntiles / 4 >= 128);
 #define G16(P, E)                                                                                              \
   if (pro == P && epi == E) {                                                                                  \
     if (big) return launch_nw<WT, float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \

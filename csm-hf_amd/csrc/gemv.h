@@ -71,6 +71,7 @@ struct GemvArgs {
   int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
+  int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
 };
 
 #ifndef CSM_ARGS_ONLY

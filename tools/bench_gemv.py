@@ -16,9 +16,16 @@ shapes = [("dec qkv", 1536, 1024, True, 0), ("dec o", 1024, 1024, False, 1), ("d
           ("c0 head+proj", 3075, 2048, True, 0)]
 Ms = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1]
 kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
+# MFMA overrides: g16=NW,KB,PT  (packed into grid_cap's upper bits)
+if "g16" in "".join(sys.argv):
+    nw, kb, pt = [int(v) for v in [a for a in sys.argv if a.startswith("g16:")][0][4:].split(",")]
+    kw["grid_cap"] = (nw << 16) | (kb << 24) | ((1 << 30) if pt == 4 else 0)
+only = [a[5:] for a in sys.argv if a.startswith("only:")]
 print("| shape | N | K | MB | " + " | ".join(f"M={m} us (TB/s)" for m in Ms) + " |")
 print("|---|---|---|---|" + "---|" * len(Ms))
 for name, N, K, norm, epi in shapes:
+    if only and not any(o in name for o in only):
+        continue
     cells = []
     for M in Ms:
         us, wb = eng.bench_gemv(N, K, M=M, norm=norm, epi=epi, **kw)
