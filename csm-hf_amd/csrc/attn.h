@@ -62,11 +62,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   Tile tile;
   if (t_lo < t_hi) tile.load(kc, vc, a.lmax, t_lo, min(32, t_hi - t_lo), lane);  // in flight during the q staging
 
-  for (int i = tid * 4; i < G * HD; i += 1024)
-    *reinterpret_cast<f32x4*>(qs + i) = *reinterpret_cast<const f32x4*>(a.q + (size_t)row * a.n_q * HD + (size_t)j * G * HD + i);
-  __syncthreads();
-
   for (int g = wave; g < G; g += 4) {
+    // this wave's query head goes through a wave-private LDS strip (no workgroup barrier)
+    const float* qsrc = a.q + (size_t)row * a.n_q * HD + (size_t)(j * G + g) * HD;
+#pragma unroll
+    for (int i = 0; i < HD / 64; ++i) qs[g * HD + lane + 64 * i] = qsrc[lane + 64 * i];
+    __builtin_amdgcn_wave_barrier();
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 acc = (f32x4)(0.f);
     for (int t0 = t_lo; t0 < t_hi; t0 += 32) {

@@ -313,11 +313,6 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
 
 // ---- decode-side GEMV with row grouping (M <= 4 per launch) -----------------------------------------
 static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
-  if (M >= 2 && M <= 16 && e->use_mfma) {  // batched decode: matrix-core path (bf16 weights, eligible shapes)
-    const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, M, pro, epi, a, e->g16_slabs,
-                                e->g16_slab_floats, e->g16_tickets, 4096);
-    if (r != -2) return r;
-  }
   const float* x = a.x;
   float* out = a.out;
   float* q = a.qbuf;
@@ -325,19 +320,38 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
   const int* rp = a.row_pos;
   int* ba = a.bump_a;
   int* bbp = a.bump_b;
-  for (int m0 = 0; m0 < M; m0 += 4) {
-    const int m = (M - m0) < 4 ? (M - m0) : 4;
-    a.x = x + (size_t)m0 * a.ldx;
-    a.out = out ? out + (size_t)m0 * a.ldo : nullptr;
-    a.qbuf = q ? q + (size_t)m0 * a.n_q * a.hd : nullptr;
-    a.row_seq = rs ? rs + m0 : nullptr;
-    a.row_pos = rp ? rp + m0 : nullptr;
-    a.seq_base = m0;
-    const bool last = m0 + 4 >= M;
-    a.bump_a = last ? ba : nullptr;
-    a.bump_b = last ? bbp : nullptr;
-    int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
+  // rows are processed in groups: up to 16 on the matrix-core kernel (bf16 / fp8 weights, eligible shapes),
+  // otherwise up to 4 on the fp32-FMA kernels; every group re-streams the weights
+  int m0 = 0;
+  while (m0 < M) {
+    const int left = M - m0;
+    auto slice = [&](int m) {
+      a.x = x + (size_t)m0 * a.ldx;
+      a.out = out ? out + (size_t)m0 * a.ldo : nullptr;
+      a.qbuf = q ? q + (size_t)m0 * a.n_q * a.hd : nullptr;
+      a.row_seq = rs ? rs + m0 : nullptr;
+      a.row_pos = rp ? rp + m0 : nullptr;
+      a.seq_base = m0;
+      const bool last = m0 + m >= M;
+      a.bump_a = last ? ba : nullptr;
+      a.bump_b = last ? bbp : nullptr;
+    };
+    if (left >= 2 && e->use_mfma) {
+      const int m = left < 16 ? left : 16;
+      slice(m);
+      const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
+                                  e->g16_slab_floats, e->g16_tickets, 4096);
+      if (r != -2) {
+        if (r) return r;
+        m0 += m;
+        continue;
+      }
+    }
+    const int m = left < 4 ? left : 4;
+    slice(m);
+    const int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
     if (r) return r;
+    m0 += m;
   }
   return 0;
 }
@@ -716,7 +730,7 @@ extern "C" int csm_rmsnorm(csm_engine_t* e, const float* x, const float* w, int 
 
 extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, const float* wscale, int N, int K, const float* x,
                         int M, const float* ln, float eps, float* y) {
-  if (!e || M < 1 || M > 64) return fail(CSM_ERR_ARG, "bad gemv arguments");
+  if (!e || M < 1 || M > 256) return fail(CSM_ERR_ARG, "bad gemv arguments");
   GemvArgs a{};
   a.W = W; a.wscale = wscale; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps; a.out = y; a.ldo = N;
   const int save = e->cfg.weight_dtype;

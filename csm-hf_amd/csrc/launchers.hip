@@ -47,8 +47,10 @@ int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
   if (a.H % 8 != 0) return -1;
-  if (wdtype == 1) hipLaunchKernelGGL((embed_sum_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((embed_sum_kernel<float>), dim3(rows), dim3(256), 0, st, a);
+  if (a.C + 1 > 64) return -1;
+  const dim3 grid(rows, (a.H + 511) / 512);
+  if (wdtype == 1) hipLaunchKernelGGL((embed_sum_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((embed_sum_kernel<float>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 

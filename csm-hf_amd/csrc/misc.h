@@ -24,57 +24,63 @@ struct EmbedArgs {
 };
 
 #ifndef CSM_ARGS_ONLY
+// grid = (rows, H / 512): one workgroup sums a 512-column slab of one frame; its 4 waves split the 33 tokens
+// (9 + 8 + 8 + 8), every row load of a wave is issued before any is consumed, partial sums meet in LDS in a
+// fixed order (wave 0 first: codebook order is only approximately the reference's, fp32 accumulate either way).
 template <typename WT>
 __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
-  const int row = blockIdx.x;
+  __shared__ float part[4][512];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y * 512 + lane * 8;
   const WT* te = reinterpret_cast<const WT*>(a.text_emb);
   const WT* ae = reinterpret_cast<const WT*>(a.audio_emb);
   const int f = a.ids ? 0 : *a.frame_ptr;
-  for (int k = threadIdx.x * 8; k < a.H; k += 256 * 8) {
-    float acc[8];
+  const int nt = a.C + 1;                       // tokens of a frame (32 audio + text)
+  const int per = (nt + 3) / 4;                 // 9 for 33
+  const int c0 = wave * per, c1 = min(nt, c0 + per);
+  float acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    // 8 independent row loads in flight per step (the token ids are read first, then all rows)
-    for (int c0 = 0; c0 < a.C; c0 += 8) {
-      W8<WT> w[8];
-      bool lv[8];
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (k < a.H) {
+    constexpr int MAXT = 16;
+    W8<WT> w[MAXT];
+    bool lv[MAXT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = c0 + u;
-        int64_t tok = 0;
-        lv[u] = false;
+    for (int u = 0; u < MAXT; ++u) {
+      const int c = c0 + u;
+      lv[u] = false;
+      const WT* src = ae + k;
+      if (c < c1) {
         if (c < a.C) {
+          int64_t tok;
           if (a.ids) {
-            tok = a.ids[(size_t)row * (a.C + 1) + c];
-            lv[u] = a.mask ? a.mask[(size_t)row * (a.C + 1) + c] != 0 : true;
+            tok = a.ids[(size_t)row * nt + c];
+            lv[u] = a.mask ? a.mask[(size_t)row * nt + c] != 0 : true;
           } else {
             tok = a.ring[((size_t)row * a.max_frames + f) * a.C + c];
             lv[u] = true;
           }
+          if (lv[u]) src = ae + ((size_t)tok + (size_t)c * a.V) * a.H + k;
+        } else if (a.ids) {                     // text column (masked out in ring mode)
+          lv[u] = a.mask ? a.mask[(size_t)row * nt + c] != 0 : true;
+          if (lv[u]) src = te + (size_t)a.ids[(size_t)row * nt + c] * a.H + k;
         }
-        const size_t r = lv[u] ? (size_t)tok + (size_t)c * a.V : 0;
-        w[u].load(ae + r * a.H + k);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (lv[u]) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] += w[u].get(i);
-        }
+      w[u].load(src);
     }
-    if (a.ids) {
-      const bool live = a.mask ? a.mask[(size_t)row * (a.C + 1) + a.C] != 0 : true;
-      if (live) {
-        const int64_t tok = a.ids[(size_t)row * (a.C + 1) + a.C];
-        W8<WT> w;
-        w.load(te + (size_t)tok * a.H + k);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += w.get(i);
+    for (int u = 0; u < MAXT; ++u)
+      if (lv[u]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += w[u].get(i);
       }
-    }
-    f32x4 o0 = {acc[0], acc[1], acc[2], acc[3]}, o1 = {acc[4], acc[5], acc[6], acc[7]};
-    *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.H + k) = o0;
-    *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.H + k + 4) = o1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part[wave][lane * 8 + i] = acc[i];
+  __syncthreads();
+  for (int i = tid; i < 512; i += 256) {
+    const int kk = blockIdx.y * 512 + i;
+    if (kk < a.H) a.out[(size_t)row * a.H + kk] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
   }
 }
 

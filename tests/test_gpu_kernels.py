@@ -61,7 +61,7 @@ def test_rmsnorm(tiny):
 def test_gemv(tiny, dtype, N, K):
     _, _, eng = tiny
     W = rnd("W", N, K, scale=0.05).to(dtype)
-    for M in (1, 2, 3, 4, 7, 16):
+    for M in (1, 2, 3, 4, 7, 16, 21):
         x = rnd(f"x{M}", M, K)
         ref = x.double() @ W.double().T
         y = eng.k_gemv(W, x).cpu()
