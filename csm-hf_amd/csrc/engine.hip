@@ -807,9 +807,9 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
   int r = 0;
   for (int i = 0; i < n_launch && !r; ++i) {
     GemvArgs a{};
-    a.W = (const char*)W + (size_t)(i % n_w) * w_stride; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps;
+    a.W = (const char*)W + (size_t)(i % n_w) * w_stride; a.N = N; a.K = K; a.x = x; a.ldx = K + (force_generic >> 8); a.ln = ln; a.eps = eps;
     a.out = y; a.ldo = (epi == EPI_SWIGLU) ? N / 2 : N; a.nt = nt;
-    a.grid_cap = grid_cap & 0xffff; a.v2_tasks = v2_tasks; a.force_generic = force_generic;
+    a.grid_cap = grid_cap & 0xffff; a.v2_tasks = v2_tasks; a.force_generic = force_generic & 0xff;
     a.g16_nw = (grid_cap >> 16) & 0xff; a.g16_kb = (grid_cap >> 24) & 0x3f; a.g16_pt = (grid_cap >> 30) & 1 ? 4 : ((grid_cap >> 16) ? 1 : 0);
     r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, epi, a);
   }

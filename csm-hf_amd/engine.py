@@ -492,7 +492,7 @@ class Engine:
         wbytes = N * K * esz
         n_w = max(1, (pool_mb << 20) // wbytes)
         W = (torch.randn(n_w * N * K // 4 + 16, device=self.device) * 0.02).to(dtype).repeat(4)[: n_w * N * K].contiguous()
-        x = torch.randn(M, K, device=self.device)
+        x = torch.randn(M, K + (force_generic >> 8), device=self.device)   # bits 8.. of force_generic = row-stride pad (floats)
         ln = torch.ones(K, device=self.device) if norm else None
         y = torch.zeros(M, N, device=self.device)
         us = C.c_float()
