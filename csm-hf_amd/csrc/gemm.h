@@ -1,6 +1,6 @@
 // Prefill GEMM on the matrix cores: C[R,N] (+)= A[R,K] @ W[N,K]^T with fp32 activations.
 //
-// v1 uses the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TFLOP/s peak) so
+// Two kernels: gemm_bf16x3_kernel (bf16 / fp8 weights, below) and, for fp32 weights, gemm_f32mfma_kernel which uses the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TFLOP/s peak) so
 // that prefill hidden states carry fp32-class error for BOTH weight dtypes (bf16 weights are widened
 // while staging to LDS).  Roofline: MFMA (f32 rate).  Algorithmic flops = 2*R*N*K.
 // Tile 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32;
@@ -21,6 +21,7 @@ struct GemmArgs {
   int R, N, K;
   float* C;  // STORE/RESID: [R][ldc]; SWIGLU: [R][ldc] with N/2 columns
   int ldc;
+  int f32_mfma;  // force the fp32-MFMA kernel also for bf16 / fp8 weights (A/B measurements)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -91,6 +92,132 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
         const float v = acc[mi][ni][reg] * (a.wscale ? a.wscale[n] : 1.f);
         if (EPI == GEPI_SWIGLU) {
           const float o = __shfl_xor(v, 1, 64);  // even lane: gate (own), up (partner)
+          if (!(lane & 1) && r < a.R) a.C[(size_t)r * a.ldc + (n >> 1)] = (v / (1.f + __expf(-v))) * o;
+        } else if (r < a.R) {
+          if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
+          else a.C[(size_t)r * a.ldc + n] = v;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 / fp8 weights: the same GEMM on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2.5 PFLOP/s dense).
+// fp32 activations are split EXACTLY into three bf16 planes (8 + 8 + 8 mantissa bits, truncation, no rounding)
+// while they are staged into LDS; every weight fragment is multiplied by the three planes, small terms first,
+// so the result carries fp32 summation-order error only (bf16 x bf16 products are exact in the fp32
+// accumulator) at 1/3 of the bf16 MFMA rate = 5x the fp32-MFMA rate.  LDS rows are padded to 80 bytes:
+// the four 16-lane groups of a ds_read_b128 then cover all 64 banks exactly once.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short g_bf16x8;
+
+template <typename WT>
+__device__ __forceinline__ u32x4 load_w8_as_bf16(const WT* p);
+template <>
+__device__ __forceinline__ u32x4 load_w8_as_bf16<bf16_t>(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+template <>
+__device__ __forceinline__ u32x4 load_w8_as_bf16<fp8_t>(const fp8_t* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  u32x4 o;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int w = (int)(h < 2 ? r.x : r.y);
+    const f32x2 v = (h & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+    o[h] = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+  }
+  return o;
+}
+
+// BT = square block tile (128 or 64); 4 waves as 2x2, each wave (BT/2)x(BT/2) = (BT/64)^2 MFMA tiles of 32x32.
+// The 64x64 tile is used when the 128x128 grid would leave most of the chip idle (prefill of one utterance
+// through the N = 2048 projections: 4 x 16 tiles).
+template <typename WT, int EPI, int BT>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
+  constexpr int BM = BT, BN = BT, BK = 32, LDK = BK + 8;   // bf16 elements per LDS row (80 bytes)
+  constexpr int TI = BT / 64;                              // MFMA tiles per wave per dimension
+  __shared__ __attribute__((aligned(16))) bf16_t Ap[3][BM * LDK];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nbn = a.N / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+  const int r0 = bm * BM, n0 = bn * BN;
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+
+  f32x16 acc[TI][TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = (f32x16)(0.f);
+
+  for (int k0 = 0; k0 < a.K; k0 += BK) {
+    // ---- stage A: fp32 -> three bf16 planes ------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, c4 = idx & 7;
+      f32x4 v = (f32x4)(0.f);
+      if (r0 + row < a.R) v = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
+      uint32_t h[2], m[2], l[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float v0 = v[2 * p], v1 = v[2 * p + 1];
+        const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+        const float q0 = v0 - __uint_as_float(h0), q1 = v1 - __uint_as_float(h1);
+        const uint32_t m0 = __float_as_uint(q0) & 0xffff0000u, m1 = __float_as_uint(q1) & 0xffff0000u;
+        const float s0 = q0 - __uint_as_float(m0), s1 = q1 - __uint_as_float(m1);
+        h[p] = (h0 >> 16) | h1;
+        m[p] = (m0 >> 16) | m1;
+        l[p] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+      }
+      const int off = row * LDK + c4 * 4;
+      *reinterpret_cast<uint2*>(&Ap[0][off]) = make_uint2(h[0], h[1]);
+      *reinterpret_cast<uint2*>(&Ap[1][off]) = make_uint2(m[0], m[1]);
+      *reinterpret_cast<uint2*>(&Ap[2][off]) = make_uint2(l[0], l[1]);
+    }
+    // ---- stage W (bf16 as is, fp8 widened exactly) -------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < BN / 64; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 2, c8 = idx & 3;
+      *reinterpret_cast<u32x4*>(&Ws[row * LDK + c8 * 8]) = load_w8_as_bf16<WT>(W + (size_t)(n0 + row) * a.K + k0 + c8 * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const int ko = kk + (lane >> 5) * 8;
+      g_bf16x8 af[TI][3], bf[TI];
+#pragma unroll
+      for (int mi = 0; mi < TI; ++mi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<u32x4*>(&af[mi][p]) =
+              *reinterpret_cast<const u32x4*>(&Ap[p][(wr * (BM / 2) + mi * 32 + (lane & 31)) * LDK + ko]);
+#pragma unroll
+      for (int ni = 0; ni < TI; ++ni)
+        *reinterpret_cast<u32x4*>(&bf[ni]) = *reinterpret_cast<const u32x4*>(&Ws[(wc * (BN / 2) + ni * 32 + (lane & 31)) * LDK + ko]);
+#pragma unroll
+      for (int mi = 0; mi < TI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][2], bf[ni], acc[mi][ni], 0, 0, 0);  // lo
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[ni], acc[mi][ni], 0, 0, 0);  // mid
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni], acc[mi][ni], 0, 0, 0);  // hi
+        }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue (same C/D layout as the fp32 kernel) ------------------------------------------------
+#pragma unroll
+  for (int mi = 0; mi < TI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TI; ++ni)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = r0 + wr * (BM / 2) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int n = n0 + wc * (BN / 2) + ni * 32 + (lane & 31);
+        const float v = acc[mi][ni][reg] * (a.wscale ? a.wscale[n] : 1.f);
+        if (EPI == GEPI_SWIGLU) {
+          const float o = __shfl_xor(v, 1, 64);
           if (!(lane & 1) && r < a.R) a.C[(size_t)r * a.ldc + (n >> 1)] = (v / (1.f + __expf(-v))) * o;
         } else if (r < a.R) {
           if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;

@@ -27,6 +27,25 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   return e;
 }
 
+template <typename WT, int BT>
+static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
+  const int grid = ((a.R + BT - 1) / BT) * (a.N / BT);
+  switch (epi) {
+    case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT>), dim3(grid), dim3(256), 0, st, a); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename WT>
+static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
+  // 128x128 tiles unless they would occupy fewer than 256 workgroups
+  if (((a.R + 127) / 128) * (a.N / 128) < 256) return launch_gemm_x3_bt<WT, 64>(st, epi, a);
+  return launch_gemm_x3_bt<WT, 128>(st, epi, a);
+}
+
 template <typename WT>
 static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
   const int grid = ((a.R + 127) / 128) * (a.N / 128);
@@ -41,8 +60,9 @@ static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
 
 int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.R < 1) return -1;
-  if (wdtype == 2) return launch_gemm_t<fp8_t>(st, epi, a);
-  return wdtype == 1 ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_t<float>(st, epi, a);
+  if (wdtype == 2) return a.f32_mfma ? launch_gemm_t<fp8_t>(st, epi, a) : launch_gemm_x3<fp8_t>(st, epi, a);
+  if (wdtype == 1) return a.f32_mfma ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_x3<bf16_t>(st, epi, a);
+  return launch_gemm_t<float>(st, epi, a);
 }
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {

@@ -108,6 +108,12 @@ def test_gemm_transpose_detecting(tiny):
     W = torch.arange(128 * 128, dtype=torch.float32).view(128, 128) / 1000.0
     out = eng.k_gemm(W, torch.eye(128)).cpu()
     torch.testing.assert_close(out, W.T.contiguous(), atol=0, rtol=0)
+    Wb = (torch.arange(128 * 128, dtype=torch.float32).view(128, 128) % 251 - 125).to(torch.bfloat16)   # bf16 x3 kernel
+    out = eng.k_gemm(Wb, torch.eye(128)).cpu()
+    torch.testing.assert_close(out, Wb.float().T.contiguous(), atol=0, rtol=0)
+    A = rnd("Asym", 200, 128) * 3.0                                 # exactness of the 3-way split on non-trivial A
+    ref = A.double() @ Wb.double().T
+    assert float((eng.k_gemm(Wb, A).cpu().double() - ref).abs().max()) < 1e-3 * 1e-2 * float(ref.abs().max()) + 1e-4
 
 
 def test_sampler_against_reference_vectors(tiny, gold):
