@@ -18,6 +18,7 @@
 #include "../../include/csm_hip.h"
 #define CSM_ARGS_ONLY 1  // kernel definitions live in gemv.hip / launchers.hip
 #include "attn.h"
+#include "attn_prefill.h"
 #include "gemm.h"
 #include "gemm16.h"
 #include "gemv.h"
@@ -32,6 +33,7 @@ int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, i
 int launch_set_int(hipStream_t st, int* p, int v);
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
+int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -104,6 +106,7 @@ struct csm_engine {
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
   int fuse_dec_attn = 0;  // measured (round 1): separate 2-workgroup attention + register-path o_proj is 4 % faster per frame
   int use_mfma = 1;
+  int flash_prefill = 1;
   int fuse_sample = 1;   // B == 1 greedy: argmax folded into the head launch + next QKV prologue
   float2* am_part = nullptr;
   float* g16_slabs = nullptr;
@@ -305,6 +308,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
+  else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else return fail(CSM_ERR_ARG, "unknown option %s", name);
   drop_graphs(e);
@@ -575,10 +579,17 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
     ra.qbuf = e->p_q; ra.kcache = s.kc[l]; ra.vcache = s.vc[l]; ra.lmax = s.lmax;
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
-    AttnArgs t{};
-    t.q = e->p_q; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
-    t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = e->d_kv_start; t.nsplit = 1; t.out = e->p_att;
-    LCK(launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t));
+    PrefillAttnArgs fa{};
+    fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;
+    fa.S = S; fa.past = e->h_len; fa.kv_start = e->d_kv_start; fa.out = e->p_att;
+    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa) : -2;
+    if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
+      AttnArgs t{};
+      t.q = e->p_q; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+      t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = e->d_kv_start; t.nsplit = 1; t.out = e->p_att;
+      fr = launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t);
+    }
+    LCK(fr);
     GemmArgs o{};
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
     LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
