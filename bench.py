@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = e4m3fn linears + row scales (config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: no cpu_baseline leg and no dominant-kernel chain "
+                    "(its launches would be counted with the step's own kernels)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
     a = ap.parse_args()
@@ -231,6 +233,20 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
                          "algorithmic_bytes_per_step": int(by), "traffic": None},
         }
+        # the dominant kernel of the step by time: the decoder gate/up GEMV (128 launches per step, 33.55 MB each).
+        # Its launch time is measured here with HIP events on the engine stream as a dependent chain of 200
+        # launches in a hipGraph cycling over 512 MiB of weights (so it includes the launch boundary, like the step).
+        if B == 1 and a.weights == "bf16" and not a.lean:
+            try:
+                dc = cfg.decoder_config
+                us, wb = eng.bench_gemv(2 * dc.intermediate_size, dc.hidden_size, M=1, norm=True, epi=2)
+                out["roofline"]["dominant_kernel"] = {
+                    "name": "gemv1_kernel<bf16, NORM, SWIGLU> (decoder gate/up, 128 launches/step)",
+                    "algorithmic_bytes_per_launch": wb, "us_per_launch_chain": round(us, 3),
+                    "achieved": round(wb / us / 1e3, 1), "unit": "GB/s", "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4),
+                    "share_of_step_time": round(128 * us / (step_s * 1e6), 3)}
+            except Exception as ex:      # never let the side measurement break the bench line
+                out["roofline"]["dominant_kernel"] = {"error": str(ex)[:200]}
         # static PMC measurement of the same command, if one was committed for this configuration
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
@@ -255,7 +271,7 @@ def main():
             out["parity"] = {"vs": "reference golden tokens (fp32 arithmetic, same weights)",
                              "samples_compared": stop, "equal": bool((mine[:stop] == ref[:stop]).all()),
                              "equal_all": bool((mine == ref).all())}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.lean:
             out["cpu_baseline"] = cpu_baseline(cfg, model, ids, mask, a.cpu_frames, toks)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -24,3 +24,17 @@ q = ("select name, grid_x, lds_size, vgpr_count, count(*), avg(end-start)/1000.0
 for r in cur.execute(q):
     cpf = f"{r[4]/frames:.1f}" if frames else ""
     print(f"| `{r[0][:70]}` | {r[1]} | {r[2]} | {r[3]} | {r[4]} | {cpf} | {r[5]:.2f} | {r[6]:.2f} |")
+
+# ---- frame-step consistency: kernels between two consecutive decode embed_sum launches ----------------------
+ks = list(cur.execute("select start, end, name, grid_x from kernels order by start"))
+idx = [i for i, k in enumerate(ks) if "embed_sum" in k[2] and k[3] <= 1024]
+if len(idx) >= 3:
+    spans, sums, counts = [], [], []
+    for a_, b_ in zip(idx[-4:-1], idx[-3:]):
+        fr = ks[a_:b_]
+        spans.append((fr[-1][1] - fr[0][0]) / 1e6)
+        sums.append(sum(k[1] - k[0] for k in fr) / 1e6)
+        counts.append(len(fr))
+    print(f"\nframe-step consistency (last {len(spans)} steps, UNDER THE PROFILER): {counts[0]} launches per step, "
+          f"sum of kernel durations {sum(sums)/len(sums):.3f} ms, first-start-to-last-end span {sum(spans)/len(spans):.3f} ms "
+          f"(bench.py's un-profiled HIP-event time per step is reported in profiles/r01_bench.json)")
