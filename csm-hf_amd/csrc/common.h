@@ -83,6 +83,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Workgroup barrier that only waits for the LDS counter.  __syncthreads() also drains vmcnt, i.e. it would wait
+// for every weight load in flight; use this one between a prologue's LDS exchange and the weight consumption.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
 

@@ -89,16 +89,17 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
   return (panel * PT + t) * 16 + r;
 }
 
-// One 128-wide k chunk per wave: every load of the wave (PT*4 weight fragments, its x slice, the norm
-// weights) is issued before anything is consumed.  grid = (row panels, KB); KB > 1 splits K across
+// One 128-wide k chunk per wave: every load of the wave (its x slice, the norm weights, PT*4 weight
+// fragments, epilogue inputs) is issued before anything is consumed, in the order of consumption.  grid = (row panels, KB); KB > 1 splits K across
 // workgroups (K = 8192 down_proj): partial panels go to `slabs`, a per-panel ticket elects the last arriver,
 // which sums them in fixed order (deterministic) and runs the epilogue.  PRO_NORM needs KB == 1.
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag[16] | stat[NW][16]
   float* red = lds;
   float* panel = lds + NW * PT * 256;
   int* flag = reinterpret_cast<int*>(panel + PT * 256);
+  float* stat = panel + PT * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
   const WT* W = reinterpret_cast<const WT*>(a.W);
@@ -106,32 +107,55 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   const bool mlive = m < M;
   const int k0 = ((int)blockIdx.y * NW + wave) * 128 + g * 32;
 
-  // epilogue inputs of this thread's elements (residual value, or position + cos/sin) are requested now,
-  // not at the tail of the kernel
+  // Load order matters: vmcnt retires in issue order, so whatever is consumed first must be requested first.
+  // 1. the x slice (+ norm weights): L2 hits, consumed by the RMS statistic and the bf16 split while the weights
+  //    are still in flight;  2. the weight fragments (HBM);  3. the residual values, consumed last.
+  // Epilogue inputs of this thread's elements.  EPI_QKV: requested first of all (the cos/sin addresses depend on the
+  // position loaded here).  EPI_RESID: requested LAST, behind the weights -- the residual values were written by
+  // another XCD a few launches ago and come from HBM; requested first they would hold up the x slice behind them
+  // (measured at M = 16: backbone down_proj 17.7 us first vs 12.3 us last).
   constexpr int NE = (PT * 256 + 64 * NW - 1) / (64 * NW);
   float pre0[NE], pre1[NE];
   int ppos[NE];
+  auto prefetch_epi = [&]() {
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    pre0[e] = pre1[e] = 0.f;
-    ppos[e] = 0;
-    const int i = tid + e * 64 * NW;
-    if (i < PT * 256) {
-      const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
-      const int mm = l & 15, r = (l >> 4) * 4 + reg;
-      const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
-      if (mm < M && n < a.N) {
-        if (EPI == EPI_RESID) pre0[e] = a.out[(size_t)mm * a.ldo + n];
-        if (EPI == EPI_QKV) {
-          ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
-          const int half = a.hd >> 1, spp = half / 16;
-          const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
-          if (t == 0 && head < a.n_q + a.n_kv) {
-            pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
-            pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+    for (int e = 0; e < NE; ++e) {
+      pre0[e] = pre1[e] = 0.f;
+      ppos[e] = 0;
+      const int i = tid + e * 64 * NW;
+      if (i < PT * 256) {
+        const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
+        const int mm = l & 15, r = (l >> 4) * 4 + reg;
+        const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+        if (mm < M && n < a.N) {
+          if (EPI == EPI_RESID) pre0[e] = a.out[(size_t)mm * a.ldo + n];
+          if (EPI == EPI_QKV) {
+            ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+            const int half = a.hd >> 1, spp = half / 16;
+            const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
+            if (t == 0 && head < a.n_q + a.n_kv) {
+              pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+              pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+            }
           }
         }
       }
+    }
+  };
+  if (EPI == EPI_QKV) prefetch_epi();
+  const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
+  f32x4 xa[4], xb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
+    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8 + 4);
+  }
+  f32x4 la[4], lb[4];
+  if (PRO == PRO_NORM) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8);
+      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8 + 4);
     }
   }
   AFrag<WT> wf[PT][4];
@@ -143,21 +167,11 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 8, a.nt);
   }
-  const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
-  f32x4 xa[4], xb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
-    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8 + 4);
-  }
+  if (EPI != EPI_QKV) prefetch_epi();
   if (PRO == PRO_NORM) {
-    f32x4 la[4], lb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8);
-      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8 + 4);
-    }
-    // RMS statistic of row m from the registers: lanes (m, g) of all NW waves cover the whole row
+    // RMS statistic of row m from the registers: lanes (m, g) of all NW waves cover the whole row.
+    // The exchange uses a bare s_barrier (LDS counter only): __syncthreads() would also drain vmcnt, i.e. wait
+    // for the weight fragments before any of this arithmetic could start.
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -165,13 +179,12 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       for (int i = 0; i < 4; ++i) ss += xa[j][i] * xa[j][i] + xb[j][i] * xb[j][i];
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    if (lane < 16) red[wave * 16 + lane] = ss;
-    __syncthreads();
+    if (lane < 16) stat[wave * 16 + lane] = ss;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) tot += red[w * 16 + m];
+    for (int w = 0; w < NW; ++w) tot += stat[w * 16 + m];
     const float sc = rsqrtf(tot / (float)K + a.eps);
-    __syncthreads();  // red is reused below
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -180,20 +193,24 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         xb[j][i] = (xb[j][i] * sc) * lb[j][i];
       }
   }
+  // exact 3-way bf16 split of the whole slice, still ahead of the first use of a weight fragment
+  bf16x8 xh[4], xm[4], xl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
+    split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
+  }
   f32x4 acc[PT];
 #pragma unroll
   for (int t = 0; t < PT; ++t) acc[t] = (f32x4)(0.f);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
-    bf16x8 xh, xm, xl;
-    split3(xa[j], xb[j], xh, xm, xl);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const bf16x8 af = wf[t][j].get();
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl, acc[t], 0, 0, 0);  // small terms first
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[j], acc[t], 0, 0, 0);  // small terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[j], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[j], acc[t], 0, 0, 0);
     }
   }
 

@@ -8,7 +8,7 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
-  const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16) * sizeof(float);
+  const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16 + NW * 16) * sizeof(float);
   hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }

@@ -248,10 +248,33 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   GemvTask k[T];
   GemvEpi<KT, EPI, 1> epi[T];
   W8<WT> w0[T][U], w1[T][U];
+  // vmcnt retires in issue order: the x slice and the norm weights (L2 hits, consumed first by the RMS
+  // prologue) are requested ahead of the weight stream so the prologue runs while the weights are in flight.
+  // PRO_TOKNORM cannot: its x row address depends on the argmax below, so there the weights go first.
+  // The epilogue prefetch goes first of all: EPI_QKV's cos/sin addresses depend on the position it loads, and at
+  // M = 1 the residual values requested behind the weights arrive too late (dec o_proj 3.13 vs 2.94 us).
+  f32x4 xa[U], xb[U], la[U], lb[U];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {  // T tasks per wave share one x slice; every weight load is issued up front
+  for (int t = 0; t < T; ++t) {
     k[t] = gemv_map_task<EPI>(a, (blockIdx.x * TPB + tw) * T + t, ntask);
     if (kw == 0) epi[t].prefetch(a, k[t]);
+  }
+  if (PRO != PRO_TOKNORM) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xa[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512);
+      xb[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512 + 4);
+    }
+  }
+  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      la[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512);
+      lb[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512 + 4);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {  // T tasks per wave share one x slice; every weight load is issued up front
     const WT* w0p = W + (size_t)(k[t].live ? k[t].r0 : 0) * K + e0;
     const WT* w1p = W + (size_t)(k[t].has1 ? k[t].r1 : (k[t].live ? k[t].r0 : 0)) * K + e0;
 #pragma unroll
@@ -260,7 +283,6 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
     }
   }
-  const float* xsrc = a.x;
   if (PRO == PRO_TOKNORM) {
     // greedy token of the previous codebook = argmax over the head launch's per-task (value, index) pairs
     constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
@@ -288,13 +310,12 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     int64_t feed = bi;
     if (a.tok_forced) feed = a.tok_forced[slot];
     if (blockIdx.x == 0 && tid == 0) a.tok_ring[slot] = bi;
-    xsrc = a.tok_table + ((size_t)feed + (size_t)a.tok_row_base) * K;
-  }
-  f32x4 xa[U], xb[U];
+    const float* xsrc = a.tok_table + ((size_t)feed + (size_t)a.tok_row_base) * K;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    xa[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512);
-    xb[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
+    for (int u = 0; u < U; ++u) {
+      xa[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512);
+      xb[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
+    }
   }
   if (PRO == PRO_TOKNORM && blockIdx.x == 0 && wave == 0) {   // the new pass's residual stream
 #pragma unroll
@@ -304,12 +325,6 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     }
   }
   if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
-    f32x4 la[U], lb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      la[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512);
-      lb[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512 + 4);
-    }
     float ss = 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -412,12 +427,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   GemvTask ta = gemv_map_task<EPI>(a, task, ntask);
   GemvTask tb = gemv_map_task<EPI>(a, task + stride, ntask);
   GemvEpi<KT, EPI, M> ea, eb;
-  issue(ta, wa0, wa1, 0);  // in flight while the prologue runs
-  if (kw == 0) ea.prefetch(a, ta);
-  if (iters > 1) {
-    issue(tb, wb0, wb1, 0);
-    if (kw == 0) eb.prefetch(a, tb);
+  // Issue order = consumption order (vmcnt retires in order): epilogue inputs (EPI_QKV: a dependent chain),
+  // then the first 2048 columns of x and of the norm weight (L2 hits, staged by the prologue), then the two
+  // weight register sets, which stay in flight across the prologue's LDS-only barriers.
+  if (kw == 0) {
+    ea.prefetch(a, ta);
+    if (iters > 1) eb.prefetch(a, tb);
   }
+  constexpr int XR = 2;  // x column blocks of 1024 held in registers (K <= 2048: every normed input of the model)
+  f32x4 xv[M][XR], lnw[XR];
+  if (PRO != PRO_ATTN) {
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      const int kk = tid * 4 + r * 1024;
+      lnw[r] = (f32x4)(1.f);
+      if (PRO == PRO_NORM && kk < K) lnw[r] = *reinterpret_cast<const f32x4*>(a.ln + kk);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        xv[m][r] = (f32x4)(0.f);
+        if (kk < K) xv[m][r] = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + kk);
+      }
+    }
+  }
+  issue(ta, wa0, wa1, 0);  // in flight while the prologue runs
+  if (iters > 1) issue(tb, wb0, wb1, 0);
 
   // ---- prologue: stage x into LDS (plain | RMS-normalised | short-cache attention output) -----------
   if (PRO == PRO_ATTN) {
@@ -427,16 +460,51 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       else attn_short_to_lds<KT, 64>(a, m, xs + (size_t)m * K, part + 4 * 2 * M + 128, part + 4 * 2 * M);
       __syncthreads();
     }
+  } else if (PRO == PRO_NORM && K <= XR * 1024) {
+    // normed inputs: statistic and scaling entirely from registers, one LDS-only barrier for the wave exchange
+    float ss[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      ss[m] = 0.f;
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const f32x4 v = xv[m][r];
+        ss[m] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      }
+      const float s = wave_sum(ss[m]);
+      if (lane == 0) red[m * 4 + wave] = s;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float s = red[m * 4 + 0] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
+      const float sc = rsqrtf(s / (float)K + a.eps);
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const int kk = tid * 4 + r * 1024;
+        f32x4 v = xv[m][r];
+        v[0] = (v[0] * sc) * lnw[r][0];
+        v[1] = (v[1] * sc) * lnw[r][1];
+        v[2] = (v[2] * sc) * lnw[r][2];
+        v[3] = (v[3] * sc) * lnw[r][3];
+        if (kk < K) *reinterpret_cast<f32x4*>(xs + (size_t)m * K + kk) = v;
+      }
+    }
+    lds_barrier();
   } else {
     float ss[M];
-    // norm weight for this thread's first column block is fetched together with x (one latency, not two)
-    f32x4 lnw = (f32x4)(1.f);
-    if (PRO == PRO_NORM && tid * 4 < K) lnw = *reinterpret_cast<const f32x4*>(a.ln + tid * 4);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       ss[m] = 0.f;
       const float* xr = a.x + (size_t)m * a.ldx;
-      for (int k = tid * 4; k < K; k += 1024) {
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const int kk = tid * 4 + r * 1024;
+        const f32x4 v = xv[m][r];
+        if (kk < K) *reinterpret_cast<f32x4*>(xs + (size_t)m * K + kk) = v;
+        if (PRO == PRO_NORM) ss[m] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      }
+      for (int k = tid * 4 + XR * 1024; k < K; k += 1024) {   // K > 2048 (down_proj): these wait behind the weights
         f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
         *reinterpret_cast<f32x4*>(xs + (size_t)m * K + k) = v;
         if (PRO == PRO_NORM) ss[m] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -455,7 +523,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         float sc = rsqrtf(s / (float)K + a.eps);
         for (int k = tid * 4; k < K; k += 1024) {
           f32x4 v = *reinterpret_cast<f32x4*>(xs + (size_t)m * K + k);
-          const f32x4 w = (k == tid * 4) ? lnw : *reinterpret_cast<const f32x4*>(a.ln + k);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(a.ln + k);
           v[0] = (v[0] * sc) * w[0];
           v[1] = (v[1] * sc) * w[1];
           v[2] = (v[2] * sc) * w[2];
@@ -464,7 +532,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         }
       }
     }
-    __syncthreads();
+    if (K <= XR * 1024) lds_barrier();
+    else __syncthreads();
   }
 
   // consume one task from register set (w0, w1); re-arm the set with task `nxt` (if `more`) before reducing
@@ -518,7 +587,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
           part[wave * 2 * M + 2 * m + 1] = acc1[m];
         }
       }
-      __syncthreads();
+      lds_barrier();  // LDS-only: the next task's weight loads (issued above) stay in flight
       if (kw == 0 && lane == 0) {
 #pragma unroll
         for (int m = 0; m < M; ++m)
@@ -528,7 +597,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
             acc1[m] += part[(wave + s) * 2 * M + 2 * m + 1];
           }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (lane == 0 && kw == 0 && cur.live) {
 #pragma unroll
