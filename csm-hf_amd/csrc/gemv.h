@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
     }
   }
+  // (The machine scheduler sinks half of these loads below the RMS prologue to stay at 63 VGPRs = 8 waves per
+  // SIMD; pinning them here with __builtin_amdgcn_sched_barrier(0) costs 69 VGPRs and measured the same: with
+  // every wave of the launch resident at once the other waves cover.)
   if (PRO == PRO_TOKNORM) {
     // greedy token of the previous codebook = argmax over the head launch's per-task (value, index) pairs
     constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
