@@ -72,15 +72,31 @@ struct W8<fp8_t> {  // 8 e4m3 weights = one 8-byte load; widened by v_cvt_pk_f32
   }
 };
 
+// Wavefront reductions on the DPP path (row = 16 lanes): quad swaps, half-row and row mirrors, then the two
+// cross-row broadcasts of gfx9 (row_bcast15/31); the total lands in lane 63 and is returned wave-uniform through
+// v_readlane.  Six dependent VALU ops instead of six ds_bpermute round trips through the LDS crossbar -- these
+// reductions sit on the critical path of every latency-bound decode kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1, 0xf>(v, v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v, v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xf>(v, v);   // row_half_mirror
+  v += dpp_mov<0x140, 0xf>(v, v);   // row_mirror: every lane of a row holds the row sum
+  v += dpp_mov<0x142, 0xa>(0.f, v); // row_bcast15 -> rows 1, 3
+  v += dpp_mov<0x143, 0xc>(0.f, v); // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x142, 0xa>(-INFINITY, v));
+  v = fmaxf(v, dpp_mov<0x143, 0xc>(-INFINITY, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Workgroup barrier that only waits for the LDS counter.  __syncthreads() also drains vmcnt, i.e. it would wait

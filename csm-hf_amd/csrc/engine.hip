@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
 int launch_set_int(hipStream_t st, int* p, int v);
+int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz);
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a);
@@ -129,8 +131,13 @@ struct csm_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::vector<void*> allocs;
+  // fragment-order copies of the linear weights for the MFMA skinny GEMM (batched decode), keyed by the bound pointer
+  std::unordered_map<const void*, void*> tiled;
+  std::vector<void*> tiled_allocs;
+  int tile_weights = 1;
 };
 
+static void drop_tiled(csm_engine* e);
 static inline int emb_dtype(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? CSM_DTYPE_BF16 : e->cfg.weight_dtype; }
 static inline size_t w_esz(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? 1 : (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4); }
 
@@ -242,6 +249,7 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   hipStreamSynchronize(e->stream);
   drop_graphs(e);
   for (void* p : e->allocs) hipFree(p);
+  drop_tiled(e);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->own_stream) hipStreamDestroy(e->stream);
@@ -262,6 +270,46 @@ static int bind_stack(Stack& s, const csm_stack_weights_t& w, const char* name) 
   return 0;
 }
 
+// Batched decode (2 <= B) runs on the MFMA skinny GEMM, which streams the weights in fragment order: one extra
+// copy of every linear (2.3 GB for csm-1b in bf16 -- HBM capacity is not the constraint on this part) buys fully
+// coalesced 1 KiB wavefront loads instead of 64 sixteen-byte pieces spread over 32 cache lines.
+static void drop_tiled(csm_engine* e) {
+  for (void* p : e->tiled_allocs) hipFree(p);
+  e->tiled_allocs.clear();
+  e->tiled.clear();
+}
+static int tile_one(csm_engine* e, const void* W, int N, int K) {
+  if (!W || K % 128 || e->tiled.count(W)) return 0;
+  const size_t esz = w_esz(e);
+  const size_t bytes = (size_t)((N + 15) / 16) * 16 * K * esz;
+  void* q = nullptr;
+  hipError_t r = hipMalloc(&q, bytes + 256);
+  if (r != hipSuccess) return fail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) for a fragment-order weight copy failed: %s", bytes, hipGetErrorString(r));
+  e->tiled_allocs.push_back(q);
+  LCK(launch_tile16(e->stream, W, q, N, K, (int)esz));
+  e->tiled[W] = q;
+  return 0;
+}
+static int build_tiled(csm_engine* e) {
+  drop_tiled(e);
+  if (!e->tile_weights || e->cfg.max_batch < 2 || e->cfg.weight_dtype == CSM_DTYPE_F32) return 0;
+  for (Stack* s : {&e->bb, &e->dec}) {
+    const int H = s->c.hidden, F = s->c.ffn;
+    for (auto& l : s->layers) {
+      if (int r = tile_one(e, l.wqkv, s->nqkv(), H)) return r;
+      if (int r = tile_one(e, l.wo, H, s->c.n_q * s->c.head_dim)) return r;
+      if (int r = tile_one(e, l.wgu, 2 * F, H)) return r;
+      if (int r = tile_one(e, l.wd, H, F)) return r;
+    }
+  }
+  const int Hb = e->bb.c.hidden, Hd = e->dec.c.hidden, V = e->cfg.audio_vocab, C = e->cfg.n_codebooks;
+  if (int r = tile_one(e, e->w.proj_head0, Hd + V, Hb)) return r;
+  for (int i = 0; i < C - 1; ++i)
+    if (int r = tile_one(e, (const char*)e->w.audio_head_t + (size_t)i * V * Hd * w_esz(e), V, Hd)) return r;
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 extern "C" int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w) {
   if (!e || !w) return fail(CSM_ERR_ARG, "null argument");
   if (!w->text_emb || !w->audio_emb || !w->proj_head0 || !w->audio_head_t) return fail(CSM_ERR_ARG, "null top-level weight");
@@ -273,7 +321,7 @@ extern "C" int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w) {
   e->w.decoder.layers = e->dec.layers.data();
   e->bound = true;
   drop_graphs(e);
-  return 0;
+  return build_tiled(e);
 }
 
 extern "C" int csm_set_proj_table(csm_engine_t* e, const float* t) {
@@ -310,6 +358,10 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
   else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
+  else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
+    e->tile_weights = value;
+    if (e->bound) { if (int r = build_tiled(e)) return r; }
+  }
   else return fail(CSM_ERR_ARG, "unknown option %s", name);
   drop_graphs(e);
   return 0;
@@ -343,6 +395,8 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     if (left >= 2 && e->use_mfma) {
       const int m = left < 16 ? left : 16;
       slice(m);
+      const auto tl = e->tiled.find(a.W);
+      a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       if (r != -2) {
@@ -812,6 +866,22 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
   if (!e || !W || !x || !y || !us_per_launch || M < 1 || M > 16 || n_w < 1) return fail(CSM_ERR_ARG, "bad bench arguments");
   const int save_wd = e->cfg.weight_dtype;
   e->cfg.weight_dtype = wdtype;
+  // the pool's matrices get temporary fragment-order copies, like bound weights (batched rows only)
+  std::vector<const void*> tmp_keys;
+  const size_t tiled_before = e->tiled_allocs.size();
+  if (M >= 2 && e->tile_weights && e->use_mfma && (wdtype == CSM_DTYPE_BF16 || wdtype == CSM_DTYPE_FP8)) {
+    for (int i = 0; i < n_w; ++i) {
+      const void* wi = (const char*)W + (size_t)i * w_stride;
+      if (e->tiled.count(wi)) continue;
+      if (int tr = tile_one(e, wi, N, K)) { e->cfg.weight_dtype = save_wd; return tr; }
+      tmp_keys.push_back(wi);
+    }
+    HIPCK(hipStreamSynchronize(e->stream));
+  }
+  auto drop_tmp = [&]() {
+    for (const void* k : tmp_keys) e->tiled.erase(k);
+    while (e->tiled_allocs.size() > tiled_before) { hipFree(e->tiled_allocs.back()); e->tiled_allocs.pop_back(); }
+  };
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
   HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -826,7 +896,7 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
   }
   e->cfg.weight_dtype = save_wd;
   hipError_t ce = hipStreamEndCapture(e->stream, &g);
-  if (r) { if (g) hipGraphDestroy(g); return fail(CSM_ERR_ARG, "bench launch failed (%d)", r); }
+  if (r) { if (g) hipGraphDestroy(g); drop_tmp(); return fail(CSM_ERR_ARG, "bench launch failed (%d)", r); }
   HIPCK(ce);
   HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   HIPCK(hipGraphLaunch(ge, e->stream));
@@ -840,5 +910,6 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
   *us_per_launch = ms * 1000.f / ((float)reps * n_launch);
   hipGraphExecDestroy(ge);
   hipGraphDestroy(g);
+  drop_tmp();
   return 0;
 }

@@ -93,7 +93,11 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // fragments, epilogue inputs) is issued before anything is consumed, in the order of consumption.  grid = (row panels, KB); KB > 1 splits K across
 // workgroups (K = 8192 down_proj): partial panels go to `slabs`, a per-panel ticket elects the last arriver,
 // which sums them in fixed order (deterministic) and runs the epilogue.  PRO_NORM needs KB == 1.
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
+// TL = weights read from the fragment-order copy a.Wt (launchers.hip: tile16_kernel) and k taken in natural
+// order (lane group g, step j -> k = j*32 + g*8 + 0..7): a fragment load is then one contiguous 1 KiB (bf16)
+// block per wavefront and an x load touches 16 half-lines; the row-major variant (TL = false, permuted k) is kept
+// for unbound weights (csm_gemv / csm_gemm hooks) and as the A/B baseline.
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag[16] | stat[NW][16]
   float* red = lds;
@@ -105,7 +109,9 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const int m = lane & 15, g = lane >> 4;
   const bool mlive = m < M;
-  const int k0 = ((int)blockIdx.y * NW + wave) * 128 + g * 32;
+  const int chunk = (int)blockIdx.y * NW + wave;          // 128-wide k chunk of this wave
+  const int k0 = chunk * 128 + (TL ? g * 8 : g * 32);     // first k of this lane; step j adds (TL ? 32 : 8) * j
+  constexpr int KJ = TL ? 32 : 8;
 
   // Load order matters: vmcnt retires in issue order, so whatever is consumed first must be requested first.
   // 1. the x slice (+ norm weights): L2 hits, consumed by the RMS statistic and the bf16 split while the weights
@@ -147,25 +153,33 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   f32x4 xa[4], xb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
-    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8 + 4);
+    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ);
+    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ + 4);
   }
   f32x4 la[4], lb[4];
   if (PRO == PRO_NORM) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8);
-      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * 8 + 4);
+      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ);
+      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ + 4);
     }
   }
   AFrag<WT> wf[PT][4];
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
-    n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
-    const WT* wr = W + (size_t)n * K + k0;
+    if (TL) {
+      // tile index of this panel tile (its first row is a multiple of 16); rows >= N are zero in the copy
+      const size_t tile = (size_t)(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4);
+      const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 8, a.nt);
+      for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
+    } else {
+      int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
+      n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
+      const WT* wr = W + (size_t)n * K + k0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 8, a.nt);
+    }
   }
   if (EPI != EPI_QKV) prefetch_epi();
   if (PRO == PRO_NORM) {
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += stat[w * 16 + m];
     const float sc = rsqrtf(tot / (float)K + a.eps);
+#ifndef CSM_G16_ABLATE
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -192,13 +207,22 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         xa[j][i] = (xa[j][i] * sc) * la[j][i];
         xb[j][i] = (xb[j][i] * sc) * lb[j][i];
       }
+#else
+    xa[0][0] += sc + la[0][0] + lb[3][3];
+#endif
   }
   // exact 3-way bf16 split of the whole slice, still ahead of the first use of a weight fragment
   bf16x8 xh[4], xm[4], xl[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
+#ifdef CSM_G16_ABLATE   // timing experiment only: no split arithmetic (results are wrong)
+    *reinterpret_cast<f32x4*>(&xh[j]) = xa[j];
+    *reinterpret_cast<f32x4*>(&xm[j]) = xb[j];
+    *reinterpret_cast<f32x4*>(&xl[j]) = xa[j];
+#else
     split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
+#endif
   }
   f32x4 acc[PT];
 #pragma unroll

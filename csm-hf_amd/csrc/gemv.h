@@ -53,6 +53,7 @@ struct GemvArgs {
   int* bump_a;
   int* bump_b;
   int nt;  // non-temporal weight loads
+  const void* Wt;  // MFMA kernel only: the same weights in 16-row x 32-k fragment order (tile16_kernel), nullable
   // ---- fused greedy sampling (B == 1): EPI_ARGMAX writes one (max value, row index) pair per task instead of the
   // logits; PRO_TOKNORM (the next pass's first QKV launch) reduces the pairs to the token, takes its input row
   // from the projected-embedding table and records the token -- replacing sample_kernel for codebooks 1..30.

@@ -124,6 +124,39 @@ __global__ void widen_rows_kernel(const WT* src, float* dst, size_t n) {
   }
 }
 
+// Fragment-order copy of a row-major [N][K] weight matrix for the MFMA skinny GEMM (gemm16.h): 16-row tiles,
+// 128-wide k chunks, and inside a chunk four 1 KiB (bf16) blocks -- block j holds, for lane l, the 8 weights
+// W[tile*16 + (l & 15)][chunk*128 + j*32 + (l >> 4)*8 ..+8], i.e. exactly the A operand of one 16x16x32 MFMA, so a
+// wavefront's fragment load is one fully coalesced stream.  Rows >= N are zero.  ES = element bytes (2 | 1).
+template <typename V>
+__global__ __launch_bounds__(256) void tile16_kernel(const V* __restrict__ W, V* __restrict__ Wt, int N, int K) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 8-weight fragment piece
+  const int lane = (int)(i & 63);
+  const size_t blk = i >> 6;            // (tile * K/128 + chunk) * 4 + j
+  const int j = (int)(blk & 3);
+  const size_t tc = blk >> 2;
+  const int nchunk = K >> 7;
+  const int chunk = (int)(tc % nchunk);
+  const size_t tile = tc / nchunk;
+  if (tile * 16 >= (size_t)((N + 15) & ~15)) return;
+  const size_t n = tile * 16 + (lane & 15);
+  const int k = chunk * 128 + j * 32 + (lane >> 4) * 8;
+  V v = V{};
+  if (n < (size_t)N) v = W[(n * K + k) / 8];
+  Wt[i] = v;
+}
+
+// W, Wt: device pointers; esz = bytes per weight (2 = bf16, 1 = fp8); K % 128 == 0
+int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz) {
+  if (K % 128) return -1;
+  const size_t pieces = (size_t)((N + 15) / 16) * 16 * (K / 8);
+  const int grid = (int)((pieces + 255) / 256);
+  if (esz == 2) hipLaunchKernelGGL((tile16_kernel<uint4>), dim3(grid), dim3(256), 0, st, (const uint4*)W, (uint4*)Wt, N, K);
+  else if (esz == 1) hipLaunchKernelGGL((tile16_kernel<uint2>), dim3(grid), dim3(256), 0, st, (const uint2*)W, (uint2*)Wt, N, K);
+  else return -1;
+  return (int)hipGetLastError();
+}
+
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past) {
   hipLaunchKernelGGL(rows_iota_kernel, dim3((R + 255) / 256), dim3(256), 0, st, row_seq, row_pos, R, S, past);
   return (int)hipGetLastError();

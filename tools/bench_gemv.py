@@ -15,12 +15,16 @@ shapes = [("dec qkv", 1536, 1024, True, 0), ("dec o", 1024, 1024, False, 1), ("d
           ("bb gate/up", 16384, 2048, True, 2), ("bb down", 2048, 8192, False, 1), ("audio head", 2051, 1024, True, 0),
           ("c0 head+proj", 3075, 2048, True, 0)]
 Ms = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1]
-kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a)}
+kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("opt:"))}
 # MFMA overrides: g16=NW,KB,PT  (packed into grid_cap's upper bits)
 if "g16" in "".join(sys.argv):
     nw, kb, pt = [int(v) for v in [a for a in sys.argv if a.startswith("g16:")][0][4:].split(",")]
     kw["grid_cap"] = (nw << 16) | (kb << 24) | ((1 << 30) if pt == 4 else 0)
 only = [a[5:] for a in sys.argv if a.startswith("only:")]
+for a in sys.argv:   # engine options, e.g. opt:tile_weights=0
+    if a.startswith("opt:"):
+        k_, v_ = a[4:].split("=")
+        eng.set_option(k_, int(v_))
 print("| shape | N | K | MB | " + " | ".join(f"M={m} us (TB/s)" for m in Ms) + " |")
 print("|---|---|---|---|" + "---|" * len(Ms))
 for name, N, K, norm, epi in shapes:
