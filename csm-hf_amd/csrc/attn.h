@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int
   for (int i = 0; i < HD / 64; ++i) {
     float num = 0.f;
 #pragma unroll
-    for (int s = 0; s < 64; ++s) num = fmaf(__shfl(w, s, 64), pv[i][s], num);
+    for (int s = 0; s < 64; ++s) num = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), s)), pv[i][s], num);
     out[(size_t)rh * HD + lane + 64 * i] = num * inv;
   }
 }

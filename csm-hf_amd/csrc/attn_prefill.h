@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
       sc[r] = valid ? sc[r] : -INFINITY;
       mx = fmaxf(mx, sc[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const bool any = m_new > -INFINITY;
     const float alpha = any ? __expf(m_run - m_new) : 1.f;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
       sc[r] = any ? __expf(sc[r] - m_new) : 0.f;   // exp(-inf) = 0 for masked keys
       sum += sc[r];
     }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = xor32_sum(sum);
     l_run = l_run * alpha + sum;
     m_run = m_new;
     o0 *= alpha;

@@ -54,7 +54,7 @@ struct AttnTile32 {
       s = fmaf(qv[2], k[i][2], s);
       s = fmaf(qv[3], k[i][3], s);
     }
-    s += __shfl_xor(s, 32, 64);
+    s = xor32_sum(s);
     const bool valid = t < cnt;
     if (!valid) s = -INFINITY;
     const float m_new = fmaxf(m_run, wave_max(s));
@@ -80,13 +80,12 @@ struct AttnTile32 {
 
   // sum the key phases; afterwards lanes < LPR hold dims 4*lane .. 4*lane+3
   static __device__ __forceinline__ f32x4 reduce(f32x4 acc) {
+    if (LPR == 16) {
 #pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) {
-      acc[0] += __shfl_xor(acc[0], o, 64);
-      acc[1] += __shfl_xor(acc[1], o, 64);
-      acc[2] += __shfl_xor(acc[2], o, 64);
-      acc[3] += __shfl_xor(acc[3], o, 64);
+      for (int i = 0; i < 4; ++i) acc[i] = xor16_sum(acc[i]);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = xor32_sum(acc[i]);
     return acc;
   }
 };

@@ -99,6 +99,42 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ __forceinline__ int wave_min_i32(int v) {
+  auto mv = [](auto tag, int old, int x) {
+    return __builtin_amdgcn_update_dpp(old, x, decltype(tag)::ctrl, decltype(tag)::mask, 0xf, false);
+  };
+  struct Q1 { enum { ctrl = 0xB1, mask = 0xf }; }; struct Q2 { enum { ctrl = 0x4E, mask = 0xf }; };
+  struct HM { enum { ctrl = 0x141, mask = 0xf }; }; struct RM { enum { ctrl = 0x140, mask = 0xf }; };
+  struct B15 { enum { ctrl = 0x142, mask = 0xa }; }; struct B31 { enum { ctrl = 0x143, mask = 0xc }; };
+  v = min(v, mv(Q1{}, v, v));
+  v = min(v, mv(Q2{}, v, v));
+  v = min(v, mv(HM{}, v, v));
+  v = min(v, mv(RM{}, v, v));
+  v = min(v, mv(B15{}, 0x7fffffff, v));
+  v = min(v, mv(B31{}, 0x7fffffff, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// wave-uniform argmax with lowest-index tie-break: max value first, then the smallest index that attains it
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  const float m = wave_max(v);
+  idx = wave_min_i32(v == m ? idx : 0x7fffffff);
+  v = m;
+}
+// butterfly partner sums across the two halves / across odd-even rows of 16 lanes (gfx950 v_permlane*_swap):
+// every lane ends with x[l] + x[l ^ 32] (resp. x[l] + x[l ^ 16]) without the LDS crossbar
+__device__ __forceinline__ float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // Workgroup barrier that only waits for the LDS counter.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for every weight load in flight; use this one between a prologue's LDS exchange and the weight consumption.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -191,8 +191,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) ss += xa[j][i] * xa[j][i] + xb[j][i] * xb[j][i];
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss = xor32_sum(xor16_sum(ss));
     if (lane < 16) stat[wave * 16 + lane] = ss;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float tot = 0.f;

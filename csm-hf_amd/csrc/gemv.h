@@ -303,12 +303,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       const int ci = __float_as_int(pv[j].y);
       if (pv[j].x > bv || (pv[j].x == bv && ci < bi)) { bv = pv[j].x; bi = ci; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    wave_argmax(bv, bi);
     const int f = *a.tok_frame_ptr;
     const size_t slot = (size_t)f * a.tok_C + a.tok_cb;   // B == 1: row 0
     int64_t feed = bi;

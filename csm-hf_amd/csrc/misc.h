@@ -233,12 +233,7 @@ __device__ __forceinline__ uint32_t f32_key(float x) {  // monotone float -> uin
 
 // block-wide argmax with lowest-index tie-break; result broadcast through LDS
 __device__ __forceinline__ int block_argmax(float v, int idx, float* s_val, int* s_idx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
+  wave_argmax(v, idx);
   const int tid = threadIdx.x;
   __syncthreads();
   if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = idx; }
