@@ -10,6 +10,8 @@ struct fp8_t { uint8_t v; };  // OCP e4m3fn byte (gfx950 v_cvt_*_fp8 is OCP, not
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// fused multiply-add on a float pair (v_pk_fma_f32): explicit, so the rounding does not hang on -ffp-contract
+#define PKFMA(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -39,6 +41,12 @@ struct W8<bf16_t> {
     uint32_t u = r[i >> 1];
     return (i & 1) ? bf16_hi(u) : bf16_lo(u);
   }
+  __device__ __forceinline__ f32x2 pair(int i) const {  // weights 2i, 2i+1 (one dword): two unpack ops
+    f32x2 p;
+    p[0] = bf16_lo(r[i]);
+    p[1] = bf16_hi(r[i]);
+    return p;
+  }
 };
 template <>
 struct W8<float> {
@@ -53,6 +61,12 @@ struct W8<float> {
   }
   __device__ __forceinline__ void zero() { a = (f32x4)(0.f); b = (f32x4)(0.f); }
   __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+  __device__ __forceinline__ f32x2 pair(int i) const {
+    f32x2 p;
+    p[0] = get(2 * i);
+    p[1] = get(2 * i + 1);
+    return p;
+  }
 };
 
 template <>
@@ -70,6 +84,10 @@ struct W8<fp8_t> {  // 8 e4m3 weights = one 8-byte load; widened by v_cvt_pk_f32
     const f32x2 f = (i & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
     return (i & 1) ? f[1] : f[0];
   }
+  __device__ __forceinline__ f32x2 pair(int i) const {  // one v_cvt_pk_f32_fp8 per pair
+    const int w = (int)(i < 2 ? r.x : r.y);
+    return (i & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+  }
 };
 
 // Wavefront reductions on the DPP path (row = 16 lanes): quad swaps, half-row and row mirrors, then the two
@@ -80,20 +98,37 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float old, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_all(float v) {  // every lane has a valid source: lets the move fold into its user
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  v += dpp_mov<0xB1, 0xf>(v, v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E, 0xf>(v, v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141, 0xf>(v, v);   // row_half_mirror
-  v += dpp_mov<0x140, 0xf>(v, v);   // row_mirror: every lane of a row holds the row sum
+  v += dpp_all<0xB1>(v);            // quad_perm [1,0,3,2]
+  v += dpp_all<0x4E>(v);            // quad_perm [2,3,0,1]
+  v += dpp_all<0x141>(v);           // row_half_mirror
+  v += dpp_all<0x140>(v);           // row_mirror: every lane of a row holds the row sum
   v += dpp_mov<0x142, 0xa>(0.f, v); // row_bcast15 -> rows 1, 3
   v += dpp_mov<0x143, 0xc>(0.f, v); // row_bcast31 -> rows 2, 3
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// two independent sums for the price of one: fold a's and b's upper halves onto the lower ones with one
+// v_permlane32_swap (lanes 0-31 carry a, lanes 32-63 carry b), reduce the 32-lane halves, read lanes 31 and 63
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  v += dpp_all<0xB1>(v);
+  v += dpp_all<0x4E>(v);
+  v += dpp_all<0x141>(v);
+  v += dpp_all<0x140>(v);
+  v += dpp_mov<0x142, 0xa>(0.f, v);
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
-  v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
-  v = fmaxf(v, dpp_mov<0x141, 0xf>(v, v));
-  v = fmaxf(v, dpp_mov<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_all<0xB1>(v));
+  v = fmaxf(v, dpp_all<0x4E>(v));
+  v = fmaxf(v, dpp_all<0x141>(v));
+  v = fmaxf(v, dpp_all<0x140>(v));
   v = fmaxf(v, dpp_mov<0x142, 0xa>(-INFINITY, v));
   v = fmaxf(v, dpp_mov<0x143, 0xc>(-INFINITY, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

@@ -420,8 +420,11 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
                         const GemvArgs* tok = nullptr) {
   const csm_layer_weights_t& w = s.layers[l];
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
+  // nt: 0 = plain loads, 1 = every matrix non-temporal, 2 = only the large streams (gate/up, down) non-temporal so
+  // that the small per-pass matrices (qkv, o) can stay in the XCD-local L2 between decoder passes
+  const int nt_small = nt == 1, nt_big = nt >= 1;
   GemvArgs a{};
-  a.nt = nt;
+  a.nt = nt_small;
   a.W = w.wqkv; a.wscale = w.sqkv; a.N = s.nqkv(); a.K = H; a.x = h; a.ldx = ldh; a.ln = w.ln1; a.eps = s.c.rms_eps;
   a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
   a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
@@ -436,7 +439,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   }
 
   GemvArgs o{};
-  o.nt = nt;
+  o.nt = nt_small;
   o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
   if (fuse_attn) {
     // short cache (decoder, <= 32 positions): SDPA runs as the prologue of the o_proj launch
@@ -454,12 +457,12 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   }
 
   GemvArgs g{};
-  g.nt = nt;
+  g.nt = nt_big;
   g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
   LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
 
   GemvArgs d{};
-  d.nt = nt;
+  d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
   LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;

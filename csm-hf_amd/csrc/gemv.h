@@ -323,40 +323,49 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512 + 4) = xb[u];
     }
   }
+  // The arithmetic below is written on float pairs (v_pk_mul_f32 / v_pk_fma_f32): the gate/up launch is VALU-issue
+  // bound once its weights arrive (SQ counters: 52 % of wave time stalled at issue), so instructions per weight matter.
+  f32x2 xp[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    xp[u][0] = f32x2{xa[u][0], xa[u][1]};
+    xp[u][1] = f32x2{xa[u][2], xa[u][3]};
+    xp[u][2] = f32x2{xb[u][0], xb[u][1]};
+    xp[u][3] = f32x2{xb[u][2], xb[u][3]};
+  }
   if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
-    float ss = 0.f;
+    f32x2 ss2 = f32x2{0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ss += xa[u][i] * xa[u][i] + xb[u][i] * xb[u][i];
-    const float sc = rsqrtf(wave_sum(ss) / (float)K + a.eps);
+      for (int i = 0; i < 4; ++i) ss2 = PKFMA(xp[u][i], xp[u][i], ss2);
+    // mean = sum * rcp(K): identical to sum / K for the power-of-two widths of this model family; raw v_rsq_f32
+    // (the argument is >= eps, far from the denormal range the library wrapper rescales for)
+    const float sc = __builtin_amdgcn_rsqf(wave_sum(ss2[0] + ss2[1]) * __builtin_amdgcn_rcpf((float)K) + a.eps);
+    const f32x2 sc2 = f32x2{sc, sc};
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xa[u][i] = (xa[u][i] * sc) * la[u][i];
-        xb[u][i] = (xb[u][i] * sc) * lb[u][i];
-      }
+    for (int u = 0; u < U; ++u) {
+      xp[u][0] = (xp[u][0] * sc2) * f32x2{la[u][0], la[u][1]};
+      xp[u][1] = (xp[u][1] * sc2) * f32x2{la[u][2], la[u][3]};
+      xp[u][2] = (xp[u][2] * sc2) * f32x2{lb[u][0], lb[u][1]};
+      xp[u][3] = (xp[u][3] * sc2) * f32x2{lb[u][2], lb[u][3]};
+    }
   }
   float s0[T], s1[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    float c0 = 0.f, c1 = 0.f;
+    f32x2 c0 = f32x2{0.f, 0.f}, c1 = f32x2{0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        c0 = fmaf(w0[t][u].get(i), xa[u][i], c0);
-        c1 = fmaf(w1[t][u].get(i), xa[u][i], c1);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        c0 = fmaf(w0[t][u].get(4 + i), xb[u][i], c0);
-        c1 = fmaf(w1[t][u].get(4 + i), xb[u][i], c1);
+        c0 = PKFMA(w0[t][u].pair(i), xp[u][i], c0);
+        c1 = PKFMA(w1[t][u].pair(i), xp[u][i], c1);
       }
     }
-    s0[t] = wave_sum(c0);
-    s1[t] = wave_sum(c1);
+    s0[t] = c0[0] + c0[1];
+    s1[t] = c1[0] + c1[1];
+    wave_sum2(s0[t], s1[t]);
   }
   if (KS > 1) {
     if (lane == 0) {
@@ -537,9 +546,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 
   // consume one task from register set (w0, w1); re-arm the set with task `nxt` (if `more`) before reducing
   auto process = [&](GemvTask& t, GemvEpi<KT, EPI, M>& ep, W8<WT> (&w0)[U], W8<WT> (&w1)[U], bool more) {
-    float acc0[M], acc1[M];
+    // same arithmetic as gemv1_kernel (pair accumulators, ascending chunks, wave_sum2), so a row's result is
+    // bit-identical whichever of the two fp32-FMA kernels -- i.e. whichever batch size -- computes it
+    f32x2 c0[M], c1[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc0[m] = acc1[m] = 0.f;
+    for (int m = 0; m < M; ++m) c0[m] = c1[m] = f32x2{0.f, 0.f};
     for (int cb = 0; cb < nch_w; cb += 64 * U) {
       if (cb > 0) issue(t, w0, w1, cb);
 #pragma unroll
@@ -550,21 +561,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         for (int m = 0; m < M; ++m) {
           const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (size_t)m * K + c * 8);
           const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + (size_t)m * K + c * 8 + 4);
-          float s0 = acc0[m], s1 = acc1[m];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s0 = fmaf(w0[u].get(i), xa[i], s0);
-            s1 = fmaf(w1[u].get(i), xa[i], s1);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s0 = fmaf(w0[u].get(4 + i), xb[i], s0);
-            s1 = fmaf(w1[u].get(4 + i), xb[i], s1);
-          }
-          acc0[m] = s0;
-          acc1[m] = s1;
+          const f32x2 x0 = f32x2{xa[0], xa[1]}, x1 = f32x2{xa[2], xa[3]}, x2 = f32x2{xb[0], xb[1]}, x3 = f32x2{xb[2], xb[3]};
+          c0[m] = PKFMA(w0[u].pair(0), x0, c0[m]);
+          c1[m] = PKFMA(w1[u].pair(0), x0, c1[m]);
+          c0[m] = PKFMA(w0[u].pair(1), x1, c0[m]);
+          c1[m] = PKFMA(w1[u].pair(1), x1, c1[m]);
+          c0[m] = PKFMA(w0[u].pair(2), x2, c0[m]);
+          c1[m] = PKFMA(w1[u].pair(2), x2, c1[m]);
+          c0[m] = PKFMA(w0[u].pair(3), x3, c0[m]);
+          c1[m] = PKFMA(w1[u].pair(3), x3, c1[m]);
         }
       }
+    }
+    float acc0[M], acc1[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      acc0[m] = c0[m][0] + c0[m][1];
+      acc1[m] = c1[m][0] + c1[m][1];
     }
     const GemvTask cur = t;
     const GemvEpi<KT, EPI, M> cep = ep;
@@ -574,10 +587,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       if (kw == 0) ep.prefetch(a, t);
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      acc0[m] = wave_sum(acc0[m]);
-      acc1[m] = wave_sum(acc1[m]);
-    }
+    for (int m = 0; m < M; ++m) wave_sum2(acc0[m], acc1[m]);
     if (KS > 1) {
       if (lane == 0) {
 #pragma unroll
