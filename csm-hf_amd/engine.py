@@ -71,7 +71,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("CSM_HIP_LIB") or LIB_PATH   # CSM_HIP_LIB: A/B builds of the same ABI
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build it with `python -m csm_hf_amd.build` (hipcc, gfx950); "
                            "csm_hf_amd has no CPU fallback")
