@@ -27,6 +27,8 @@ struct AttnArgs {
   int pos_const;        // constant
   const int* kv_start;  // nullable: per-sequence first valid key (left padding)
   int nsplit;
+  int one_wave;  // 1 = one 64-thread workgroup per (row, q-head, split): the tile loads of the G heads of a kv-head
+                 // go through G texture units instead of one (the short decoder caches are issue-, not byte-bound)
   float* out;   // [rows][n_q*hd]                  (nsplit == 1)
   float* part;  // [rows][n_q][nsplit][hd+4]       (nsplit > 1): acc[hd], m, l, pad
 };
@@ -43,6 +45,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = a.n_q / a.n_kv;
   int blk = blockIdx.x;
+  int g0 = wave, gstep = 4;
+  if (a.one_wave) {
+    g0 = blk % G;
+    blk /= G;
+    gstep = G;
+  }
   const int sp = blk % a.nsplit;
   blk /= a.nsplit;
   const int j = blk % a.n_kv;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   Tile tile;
   if (t_lo < t_hi) tile.load(kc, vc, a.lmax, t_lo, min(32, t_hi - t_lo), lane);  // in flight during the q staging
 
-  for (int g = wave; g < G; g += 4) {
+  for (int g = g0; g < G; g += gstep) {
     // this wave's query head goes through a wave-private LDS strip (no workgroup barrier)
     const float* qsrc = a.q + (size_t)row * a.n_q * HD + (size_t)(j * G + g) * HD;
 #pragma unroll
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     f32x4 acc = (f32x4)(0.f);
     for (int t0 = t_lo; t0 < t_hi; t0 += 32) {
       const int cnt = min(32, t_hi - t0);
-      if (t0 != t_lo || g != wave) tile.load(kc, vc, a.lmax, t0, cnt, lane);
+      if (t0 != t_lo || g != g0) tile.load(kc, vc, a.lmax, t0, cnt, lane);
       tile.accumulate(qs + g * HD, pb[wave], cnt, lane, m_run, l_run, acc);
     }
     acc = Tile::reduce(acc);

@@ -135,6 +135,8 @@ struct csm_engine {
   std::unordered_map<const void*, void*> tiled;
   std::vector<void*> tiled_allocs;
   int tile_weights = 1;
+  int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
+                          // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
 };
 
 static void drop_tiled(csm_engine* e);
@@ -358,6 +360,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
   else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
+  else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -451,6 +454,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
     t.nsplit = nsplit; t.out = att; t.part = part;
+    t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
     LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
     LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));

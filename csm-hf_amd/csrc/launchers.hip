@@ -7,13 +7,15 @@
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
   if (a.nsplit < 1) return -1;
-  const int grid = rows * a.n_kv * a.nsplit;
+  const int G = a.n_q / a.n_kv;
+  const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
+  const int bd = a.one_wave ? 64 : 256;
   if (a.hd == 64) {
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(256), 0, st, a);
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(bd), 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(bd), 0, st, a);
   } else if (a.hd == 128) {
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, 128>), dim3(grid), dim3(256), 0, st, a);
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(bd), 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 128>), dim3(grid), dim3(bd), 0, st, a);
   } else {
     return -1;
   }
