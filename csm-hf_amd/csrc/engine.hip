@@ -420,7 +420,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
 // one Llama layer on M single-token rows (decode)
 static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
                         float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn,
-                        const GemvArgs* tok = nullptr) {
+                        const GemvArgs* tok = nullptr, bool kv_only = false) {
   const csm_layer_weights_t& w = s.layers[l];
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
   // nt: 0 = plain loads, 1 = every matrix non-temporal, 2 = only the large streams (gate/up, down) non-temporal so
@@ -440,6 +440,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   } else {
     LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
   }
+  if (kv_only) return 0;  // this position's hidden state is never read again: only its K/V had to be appended
 
   GemvArgs o{};
   o.nt = nt_small;
@@ -545,7 +546,10 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     }
     for (int l = 0; l < e->dec.c.layers; ++l)
       LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder,
-                       e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr));
+                       e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr,
+                       // pass 0 (the backbone state at position 0) produces no logits: its last layer only has to
+                       // append K/V -- the attention, o_proj and MLP of that layer are dead work
+                       p == 0 && l == e->dec.c.layers - 1));
     if (p >= 1 && fused && p < C - 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;
