@@ -120,7 +120,8 @@ struct csm_engine {
   // keeping at least ~256 workgroups; frozen into the graph at capture time.
   int nsplit_eff() const {
     if (nsplit_bb > 0) return nsplit_bb;
-    const int by_len = (h_len + 256 + 63) / 64;
+    int by_len = (h_len + 256 + 63) / 64;
+    if (B >= 8) by_len = (by_len + 1) / 2;  // enough rows to fill the chip: fewer, longer splits (less combine work)
     const int by_fill = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
     const int ns = by_len > by_fill ? by_len : by_fill;
     int p = 1;
