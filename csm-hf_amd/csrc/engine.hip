@@ -812,8 +812,21 @@ extern "C" int csm_gemv(csm_engine_t* e, const void* W, int wdtype, const float*
   a.W = W; a.wscale = wscale; a.N = N; a.K = K; a.x = x; a.ldx = K; a.ln = ln; a.eps = eps; a.out = y; a.ldo = N;
   const int save = e->cfg.weight_dtype;
   e->cfg.weight_dtype = wdtype;
+  // batched rows take the same route as bound weights: a (temporary) fragment-order copy for the MFMA kernel
+  bool tmp_tile = false;
+  if (M >= 2 && e->tile_weights && e->use_mfma && (wdtype == CSM_DTYPE_BF16 || wdtype == CSM_DTYPE_FP8) && K % 128 == 0 &&
+      !e->tiled.count(W)) {
+    if (int tr = tile_one(e, W, N, K)) { e->cfg.weight_dtype = save; return tr; }
+    tmp_tile = true;
+  }
   int r = gemv_rows(e, M, ln ? PRO_NORM : PRO_PLAIN, EPI_STORE, a);
   e->cfg.weight_dtype = save;
+  if (tmp_tile) {
+    hipStreamSynchronize(e->stream);
+    e->tiled.erase(W);
+    hipFree(e->tiled_allocs.back());
+    e->tiled_allocs.pop_back();
+  }
   if (r) return fail(r > 0 ? r : CSM_ERR_ARG, "gemv launch failed (%d): N=%d K=%d M=%d", r, N, K, M);
   return 0;
 }

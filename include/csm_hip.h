@@ -119,7 +119,11 @@ int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w);
 int csm_build_proj_table(csm_engine_t* e, float* proj_table_out);
 int csm_set_proj_table(csm_engine_t* e, const float* proj_table);
 int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; graphs stay */
-/* engine knobs: "nt_backbone", "nt_decoder" (non-temporal weight loads), "nsplit_backbone" */
+/* engine knobs (A/B measurements; defaults are the measured best): "nt_backbone", "nt_decoder" (non-temporal weight
+ * loads: 0 none, 1 all, 2 large streams only), "nsplit_backbone" (KV splits of the backbone decode attention, 0 = by
+ * length), "use_mfma" (batched rows on the matrix-core kernel), "tile_weights" (fragment-order weight copies for that
+ * kernel; 0 frees them), "attn_one_wave" (bit 0 decoder / bit 1 backbone attention as one-wave workgroups),
+ * "fuse_sample" (greedy arg-max folded into the head launch), "fuse_decoder_attention", "flash_prefill" */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).

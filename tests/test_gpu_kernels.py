@@ -92,6 +92,30 @@ def test_gemv_rows_are_batch_invariant(tiny):
     assert float((y16.double() - ref).abs().max()) < 2e-6 and float((y1.double() - ref).abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("N,K", [(83, 256), (2051, 1024), (1024, 8192), (3075, 2048)])
+def test_gemv_fragment_order_weights(tiny, N, K):
+    """batched rows read the weights from the 16-row x 32-k fragment-order copy (tile16_kernel); the row-major variant
+    of the same matrix-core kernel must agree to fp32 summation order, ragged last tiles (N % 16 != 0) included."""
+    from csm_hf_amd.engine import quantize_fp8_rows
+    _, _, eng = tiny
+    Wb = rnd("Wt", N, K, scale=0.05).to(torch.bfloat16)
+    q, sc = quantize_fp8_rows(rnd("Wt8", N, K, scale=0.05))
+    ln = rnd("lnt", K) + 1.0
+    try:
+        for M in (2, 5, 16, 19):
+            x = rnd(f"xt{M}", M, K)
+            outs = {}
+            for tile in (1, 0):
+                eng.set_option("tile_weights", tile)
+                outs[tile] = (eng.k_gemv(Wb, x).cpu(), eng.k_gemv(Wb, x, ln=ln, eps=1e-5).cpu(),
+                              eng.k_gemv(q, x, scale=sc).cpu())
+            for a, b in zip(outs[1], outs[0]):
+                torch.testing.assert_close(a, b, atol=3e-6, rtol=3e-6)
+            torch.testing.assert_close(outs[1][0].double(), x.double() @ Wb.double().T, atol=2e-5, rtol=1e-5)
+    finally:
+        eng.set_option("tile_weights", 1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R,N,K", [(1, 128, 32), (70, 384, 256), (257, 256, 512), (512, 1024, 256)])
 def test_gemm_prefill(tiny, dtype, R, N, K):
