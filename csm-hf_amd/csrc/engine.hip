@@ -7,6 +7,7 @@
 // index and the backbone length live in device memory so a replay takes no parameters.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -136,11 +137,16 @@ struct csm_engine {
   std::unordered_map<const void*, void*> tiled;
   std::vector<void*> tiled_allocs;
   int tile_weights = 1;
+  // activations handed between the batched-decode launches as ready-made MFMA B operands (gemv.h: xplanes)
+  bf16_t *pl_h = nullptr, *pl_act = nullptr;
+  float* pl_ss = nullptr;
+  int use_planes = 1;
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
 };
 
 static void drop_tiled(csm_engine* e);
+constexpr int PL_SS_LD = 512;   // partial-sum columns per row: hidden / 16 tiles, hidden <= 8192
 static inline int emb_dtype(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? CSM_DTYPE_BF16 : e->cfg.weight_dtype; }
 static inline size_t w_esz(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? 1 : (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4); }
 
@@ -231,6 +237,13 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     return r;
   if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
+  {
+    const size_t Hm = std::max(cfg->backbone.hidden, cfg->decoder.hidden), Fm = std::max(cfg->backbone.ffn, cfg->decoder.ffn);
+    if ((r = dalloc(e, &e->pl_h, 3 * 16 * Hm)) || (r = dalloc(e, &e->pl_act, 3 * 16 * Fm)) || (r = dalloc(e, &e->pl_ss, (size_t)16 * PL_SS_LD))) return r;
+    HIPCK(hipMemsetAsync(e->pl_h, 0, 3 * 16 * Hm * sizeof(bf16_t), e->stream));
+    HIPCK(hipMemsetAsync(e->pl_act, 0, 3 * 16 * Fm * sizeof(bf16_t), e->stream));
+    HIPCK(hipMemsetAsync(e->pl_ss, 0, (size_t)16 * PL_SS_LD * sizeof(float), e->stream));
+  }
   e->g16_slab_floats = (size_t)1 << 20;
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
   HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
@@ -362,6 +375,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
+  else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -401,6 +415,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       slice(m);
       const auto tl = e->tiled.find(a.W);
       a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
+      if (!a.Wt) a.xplanes = nullptr;   // unbound weights (hooks): fp32 activations
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       if (r != -2) {
@@ -409,6 +424,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
         continue;
       }
     }
+    if (a.xplanes || a.oplanes) return fail(CSM_ERR_STATE, "activation planes requested but the matrix-core kernel does not cover N=%d K=%d M=%d", a.N, a.K, M);
     const int m = left < 4 ? left : 4;
     slice(m);
     const int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
@@ -418,12 +434,23 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
   return 0;
 }
 
+// activation planes are used when every launch of the stack runs on the matrix-core kernel with fragment-order weights
+static bool planes_on(const csm_engine* e, const Stack& s, int M) {
+  const int H = s.c.hidden, F = s.c.ffn, A = s.c.n_q * s.c.head_dim;
+  return e->use_planes && e->use_mfma && M >= 2 && M <= 16 && !e->tiled.empty() && H % 512 == 0 && F % 512 == 0 &&
+         A % 512 == 0 && H <= 16 * PL_SS_LD && (e->cfg.weight_dtype == CSM_DTYPE_BF16 || e->cfg.weight_dtype == CSM_DTYPE_FP8);
+}
+
 // one Llama layer on M single-token rows (decode)
 static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
                         float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn,
-                        const GemvArgs* tok = nullptr, bool kv_only = false) {
+                        const GemvArgs* tok = nullptr, bool kv_only = false, bool in_planes = false,
+                        const float* next_ln = nullptr) {
   const csm_layer_weights_t& w = s.layers[l];
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
+  // planes: o_proj and down_proj emit the residual stream as B operands for the next normed launch (folded with that
+  // launch's norm weight, plus per-tile sums of squares); gate/up emits the SwiGLU output the same way for down_proj
+  const bool planes = planes_on(e, s, M);
   // nt: 0 = plain loads, 1 = every matrix non-temporal, 2 = only the large streams (gate/up, down) non-temporal so
   // that the small per-pass matrices (qkv, o) can stay in the XCD-local L2 between decoder passes
   const int nt_small = nt == 1, nt_big = nt >= 1;
@@ -433,6 +460,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
   a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
   a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
+  if (planes && in_planes) { a.xplanes = e->pl_h; a.xss = e->pl_ss; a.xss_n = H / 16; a.xss_ld = PL_SS_LD; }
   if (tok) {  // the row comes from (partials -> token -> projected-embedding table); h is written by workgroup 0
     a.am_in = tok->am_in; a.am_n = tok->am_n; a.tok_table = tok->tok_table; a.tok_row_base = tok->tok_row_base;
     a.tok_forced = tok->tok_forced; a.tok_ring = tok->tok_ring; a.tok_frame_ptr = tok->tok_frame_ptr;
@@ -459,17 +487,20 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
     LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
+    if (planes) { o.oplanes = e->pl_h; o.oln = w.ln2; o.oss = e->pl_ss; o.oss_ld = PL_SS_LD; }
     LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
   }
 
   GemvArgs g{};
   g.nt = nt_big;
   g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
+  if (planes) { g.xplanes = e->pl_h; g.xss = e->pl_ss; g.xss_n = H / 16; g.xss_ld = PL_SS_LD; g.oplanes = e->pl_act; }
   LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
 
   GemvArgs d{};
   d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
+  if (planes) { d.xplanes = e->pl_act; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
   LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
 }
@@ -480,6 +511,9 @@ static int backbone_head(csm_engine* e, const float* h, int ldh, int M, bool bum
   a.nt = e->nt_backbone;
   a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = e->cfg.backbone.hidden;
   a.x = h; a.ldx = ldh; a.ln = e->bb.final_norm; a.eps = e->bb.c.rms_eps; a.out = e->head_out; a.ldo = e->ld_head;
+  if (planes_on(e, e->bb, M) && h == e->h_bb) {   // the last layer's down_proj left the planes (final norm folded in)
+    a.xplanes = e->pl_h; a.xss = e->pl_ss; a.xss_n = e->cfg.backbone.hidden / 16; a.xss_ld = PL_SS_LD;
+  }
   if (bump_len) {
     a.bump_a = e->d_len;
     a.bump_b = bump_frame ? e->d_frame : nullptr;
@@ -504,7 +538,8 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   em.out = e->h_bb;
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
-    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false));
+    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false,
+                     nullptr, false, l > 0, l + 1 < e->bb.c.layers ? e->bb.layers[l + 1].ln1 : e->bb.final_norm));
   if (want_last_h) {
     LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
     if (s && s->last_h_trace)
@@ -550,7 +585,8 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
                        e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr,
                        // pass 0 (the backbone state at position 0) produces no logits: its last layer only has to
                        // append K/V -- the attention, o_proj and MLP of that layer are dead work
-                       p == 0 && l == e->dec.c.layers - 1));
+                       p == 0 && l == e->dec.c.layers - 1, l > 0,
+                       l + 1 < e->dec.c.layers ? e->dec.layers[l + 1].ln1 : e->dec.final_norm));
     if (p >= 1 && fused && p < C - 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;
@@ -566,6 +602,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(p - 1) * V : nullptr;
       a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
       a.out = e->logits_dec; a.ldo = (V + 3) & ~3;
+      if (planes_on(e, e->dec, B)) { a.xplanes = e->pl_h; a.xss = e->pl_ss; a.xss_n = Hd / 16; a.xss_ld = PL_SS_LD; }
       LCK(gemv_rows(e, B, PRO_NORM, EPI_STORE, a));
       LCK(sample(p, e->logits_dec, (V + 3) & ~3));
     }

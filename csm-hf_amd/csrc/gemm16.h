@@ -78,6 +78,19 @@ struct AFrag<fp8_t> {
   }
 };
 
+// One activation value into the three planes of the next launch's B operand: exact truncation split, element
+// (row m, column k) at fragment position ((k/128 * 4 + (k/32)%4) * 64 + ((k/8)%4) * 16 + m) * 8 + k%8.
+__device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride, int k, int m, float v) {
+  const uint32_t h = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(h);
+  const uint32_t md = __float_as_uint(r) & 0xffff0000u;
+  const float l = r - __uint_as_float(md);
+  const size_t off = ((size_t)((k >> 7) * 4 + ((k >> 5) & 3)) * 64 + ((k >> 3) & 3) * 16 + m) * 8 + (k & 7);
+  planes[off] = (bf16_t)(h >> 16);
+  planes[plane_stride + off] = (bf16_t)(md >> 16);
+  planes[2 * plane_stride + off] = (bf16_t)(__float_as_uint(l) >> 16);
+}
+
 // panel row of tile t, local row r (0..15).  QKV panels pair the two RoPE halves of a head (PT == 2).
 template <int EPI, int PT>
 __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int r) {
@@ -97,7 +110,12 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // order (lane group g, step j -> k = j*32 + g*8 + 0..7): a fragment load is then one contiguous 1 KiB (bf16)
 // block per wavefront and an x load touches 16 half-lines; the row-major variant (TL = false, permuted k) is kept
 // for unbound weights (csm_gemv / csm_gemm hooks) and as the A/B baseline.
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL>
+// XP = activations arrive as planes (GemvArgs::xplanes): the B operands are loaded ready-made (12 coalesced 1 KiB
+// loads per wave instead of 8 + 8 half-line loads of x and norm weights), there is no RMS exchange, no scaling and no
+// split arithmetic ahead of the MFMAs; the RMS scale of row m is applied in the epilogue from the producer's per-tile
+// sums of squares.  An ablation without the x / norm-weight loads and their arithmetic ran the B = 16 step in 4.57 ms
+// instead of 5.75 ms -- that chain, not the weight stream, was the critical path of the small launches.  XP needs TL.
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL, bool XP>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag[16] | stat[NW][16]
   float* red = lds;
@@ -134,7 +152,10 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         const int mm = l & 15, r = (l >> 4) * 4 + reg;
         const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
         if (mm < M && n < a.N) {
-          if (EPI == EPI_RESID) pre0[e] = a.out[(size_t)mm * a.ldo + n];
+          if (EPI == EPI_RESID) {
+            pre0[e] = a.out[(size_t)mm * a.ldo + n];
+            pre1[e] = (a.oplanes && a.oln) ? a.oln[n] : 1.f;   // the consumer's norm weight for the output planes
+          }
           if (EPI == EPI_QKV) {
             ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
             const int half = a.hd >> 1, spp = half / 16;
@@ -149,19 +170,30 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     }
   };
   if (EPI == EPI_QKV) prefetch_epi();
-  const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
-  f32x4 xa[4], xb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ);
-    xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ + 4);
-  }
-  f32x4 la[4], lb[4];
-  if (PRO == PRO_NORM) {
+  bf16x8 xh[4], xm[4], xl[4];
+  f32x4 xa[4], xb[4], la[4], lb[4];
+  if (XP) {
+    const bf16_t* pp = a.xplanes + ((size_t)chunk * 256 + lane) * 8;
+    const size_t ps = (size_t)K * 16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ);
-      lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ + 4);
+      xh[j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
+      xm[j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
+      xl[j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+    }
+  } else {
+    const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xa[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ);
+      xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * KJ + 4);
+    }
+    if (PRO == PRO_NORM) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        la[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ);
+        lb[j] = *reinterpret_cast<const f32x4*>(a.ln + k0 + j * KJ + 4);
+      }
     }
   }
   AFrag<WT> wf[PT][4];
@@ -182,7 +214,23 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     }
   }
   if (EPI != EPI_QKV) prefetch_epi();
-  if (PRO == PRO_NORM) {
+  if (XP && PRO == PRO_NORM && wave == 0) {
+    // RMS scale of row m from the producer's per-tile sums of squares (fixed order); used only by the epilogue
+    const float* sp = a.xss + (size_t)m * a.xss_ld;
+    f32x4 pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = g * 4 + 16 * i;
+      pv[i] = (f32x4)(0.f);
+      if (t < a.xss_n) pv[i] = *reinterpret_cast<const f32x4*>(sp + t);
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]);
+    q = xor32_sum(xor16_sum(q));
+    if (lane < 16) stat[lane] = __builtin_amdgcn_rsqf(q * __builtin_amdgcn_rcpf((float)K) + a.eps);
+  }
+  if (!XP && PRO == PRO_NORM) {
     // RMS statistic of row m from the registers: lanes (m, g) of all NW waves cover the whole row.
     // The exchange uses a bare s_barrier (LDS counter only): __syncthreads() would also drain vmcnt, i.e. wait
     // for the weight fragments before any of this arithmetic could start.
@@ -193,12 +241,11 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       for (int i = 0; i < 4; ++i) ss += xa[j][i] * xa[j][i] + xb[j][i] * xb[j][i];
     ss = xor32_sum(xor16_sum(ss));
     if (lane < 16) stat[wave * 16 + lane] = ss;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    lds_barrier();
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += stat[w * 16 + m];
     const float sc = rsqrtf(tot / (float)K + a.eps);
-#ifndef CSM_G16_ABLATE
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -206,22 +253,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         xa[j][i] = (xa[j][i] * sc) * la[j][i];
         xb[j][i] = (xb[j][i] * sc) * lb[j][i];
       }
-#else
-    xa[0][0] += sc + la[0][0] + lb[3][3];
-#endif
   }
-  // exact 3-way bf16 split of the whole slice, still ahead of the first use of a weight fragment
-  bf16x8 xh[4], xm[4], xl[4];
+  if (!XP) {
+    // exact 3-way bf16 split of the whole slice, still ahead of the first use of a weight fragment
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
-#ifdef CSM_G16_ABLATE   // timing experiment only: no split arithmetic (results are wrong)
-    *reinterpret_cast<f32x4*>(&xh[j]) = xa[j];
-    *reinterpret_cast<f32x4*>(&xm[j]) = xb[j];
-    *reinterpret_cast<f32x4*>(&xl[j]) = xa[j];
-#else
-    split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
-#endif
+    for (int j = 0; j < 4; ++j) {
+      if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
+      split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
+    }
   }
   f32x4 acc[PT];
 #pragma unroll
@@ -292,15 +331,24 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     if (mm >= M) continue;
     const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
     if (n >= a.N) continue;
-    const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f);
+    // XP + norm: the planes carry x * norm_weight, the RMS scale of the row multiplies the finished dot product
+    const float rs = (XP && PRO == PRO_NORM) ? stat[mm] : 1.f;
+    const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f) * rs;
     if (EPI == EPI_STORE) {
       a.out[(size_t)mm * a.ldo + n] = v;
     } else if (EPI == EPI_RESID) {
-      a.out[(size_t)mm * a.ldo + n] = pre0[e] + v;
+      const float xn = pre0[e] + v;
+      a.out[(size_t)mm * a.ldo + n] = xn;
+      if (a.oplanes) {
+        store_planes(a.oplanes, (size_t)a.N * 16, n, mm, xn * pre1[e]);
+        if (a.oss) red[i] = xn * xn;   // red is free after the panel sum; tile sums are formed below
+      }
     } else if (EPI == EPI_SWIGLU) {
       if (!(reg & 1)) {
-        const float u = panel[i + 1] * (a.wscale ? a.wscale[n + 1] : 1.f);
-        a.out[(size_t)mm * a.ldo + (n >> 1)] = (v / (1.f + __expf(-v))) * u;
+        const float u = panel[i + 1] * (a.wscale ? a.wscale[n + 1] : 1.f) * rs;
+        const float hv = (v / (1.f + __expf(-v))) * u;
+        a.out[(size_t)mm * a.ldo + (n >> 1)] = hv;
+        if (a.oplanes) store_planes(a.oplanes, (size_t)(a.N >> 1) * 16, n >> 1, mm, hv);
       }
     } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
       const int half = a.hd >> 1, spp = half / 16;
@@ -312,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       KT* vc = reinterpret_cast<KT*>(a.vcache);
       if (head < a.n_q + a.n_kv) {
         if (t == 0) {
-          const float v0 = v, v1 = panel[256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f);
+          const float v0 = v, v1 = panel[256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f) * rs;
           const float c = pre0[e], sn = pre1[e];
           const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
           if (head < a.n_q) {
@@ -328,6 +376,23 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       } else {
         const int j = head - a.n_q - a.n_kv;
         store_kv(vc + v_index(b, j, pos, t * half + hi, a.n_kv, a.hd, a.lmax), v);
+      }
+    }
+  }
+  if (EPI == EPI_RESID && a.oplanes && a.oss) {
+    // per-tile sums of x_new^2 for the consumer's RMS scale: thread (t, mm) adds its tile's 16 columns in fixed order
+    __syncthreads();
+    if (tid < PT * 16) {
+      const int t = tid >> 4, mm = tid & 15;
+      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
+      if (mm < M && n0 < a.N) {
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sq = red[t * 256 + ((r >> 2) * 16 + mm) * 4 + (r & 3)];
+          q += (n0 + r < a.N) ? sq : 0.f;
+        }
+        a.oss[(size_t)mm * a.oss_ld + (n0 >> 4)] = q;
       }
     }
   }

@@ -9,8 +9,10 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16 + NW * 16) * sizeof(float);
-  if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  if (a.xplanes && !a.Wt) return -2;   // planes are laid out for the fragment-order k order
+  if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 

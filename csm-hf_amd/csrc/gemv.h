@@ -54,6 +54,16 @@ struct GemvArgs {
   int* bump_b;
   int nt;  // non-temporal weight loads
   const void* Wt;  // MFMA kernel only: the same weights in 16-row x 32-k fragment order (tile16_kernel), nullable
+  // MFMA kernel only -- activations handed from launch to launch as ready-made B operands ("planes"): the exact
+  // 3-way bf16 split of x (* the consumer's norm weight), in fragment order [3][K/128][4][64 lanes][8], plus per-tile
+  // partial sums of x^2 [16][xss_ld] from which the consumer derives the RMS scale in its epilogue.
+  const bf16_t* xplanes;   // input planes (nullable: then x is read as fp32 and normed / split in the kernel)
+  const float* xss;        // input partial sums of squares (PRO_NORM with planes)
+  int xss_n, xss_ld;
+  bf16_t* oplanes;         // output planes for the next launch (EPI_RESID / EPI_SWIGLU), nullable
+  const float* oln;        // norm weight of the consumer folded into the output planes (nullable = 1)
+  float* oss;              // output partial sums of squares [16][oss_ld], one column per 16-row tile (EPI_RESID)
+  int oss_ld;
   // ---- fused greedy sampling (B == 1): EPI_ARGMAX writes one (max value, row index) pair per task instead of the
   // logits; PRO_TOKNORM (the next pass's first QKV launch) reduces the pairs to the token, takes its input row
   // from the projected-embedding table and records the token -- replacing sample_kernel for codebooks 1..30.
