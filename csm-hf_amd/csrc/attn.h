@@ -31,6 +31,7 @@ struct AttnArgs {
                  // go through G texture units instead of one (the short decoder caches are issue-, not byte-bound)
   float* out;   // [rows][n_q*hd]                  (nsplit == 1)
   float* part;  // [rows][n_q][nsplit][hd+4]       (nsplit > 1): acc[hd], m, l, pad
+  bf16_t* oplanes;  // nullable: the output also as MFMA B-operand planes for a batched o_proj (rows <= 16)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -87,8 +88,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     const int h = j * G + g;
     if (a.nsplit == 1) {
       const float inv = 1.f / l_run;
-      if (lane < Tile::LPR)
-        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.n_q * HD + (size_t)h * HD + 4 * lane) = acc * inv;
+      if (lane < Tile::LPR) {
+        const f32x4 o = acc * inv;
+        *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.n_q * HD + (size_t)h * HD + 4 * lane) = o;
+        if (a.oplanes) store_planes4(a.oplanes, (size_t)a.n_q * HD * 16, h * HD + 4 * lane, row, o);
+      }
     } else {
       float* pp = a.part + (((size_t)row * a.n_q + h) * a.nsplit + sp) * (HD + 4);
       if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(pp + 4 * lane) = acc;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // one wave per (row, head); lane s owns split s (nsplit <= 64), then lane = output dim; all partial
 // loads are issued up front (predicated full unroll).
 template <int HD>
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out) {
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out, bf16_t* oplanes) {
   const int rh = blockIdx.x, lane = threadIdx.x;
   const float* pp = part + (size_t)rh * nsplit * (HD + 4);
   float pv[HD / 64][64];
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int
 #pragma unroll
     for (int s = 0; s < 64; ++s) num = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), s)), pv[i][s], num);
     out[(size_t)rh * HD + lane + 64 * i] = num * inv;
+    if (oplanes) store_planes(oplanes, (size_t)n_q * HD * 16, (rh % n_q) * HD + lane + 64 * i, rh / n_q, num * inv);
   }
 }
 

@@ -170,6 +170,39 @@ __device__ __forceinline__ float xor32_max(float x) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// One activation value into the three planes of the next launch's B operand: exact truncation split, element
+// (row m, column k) at fragment position ((k/128 * 4 + (k/32)%4) * 64 + ((k/8)%4) * 16 + m) * 8 + k%8.
+__device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride, int k, int m, float v) {
+  const uint32_t h = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(h);
+  const uint32_t md = __float_as_uint(r) & 0xffff0000u;
+  const float l = r - __uint_as_float(md);
+  const size_t off = ((size_t)((k >> 7) * 4 + ((k >> 5) & 3)) * 64 + ((k >> 3) & 3) * 16 + m) * 8 + (k & 7);
+  planes[off] = (bf16_t)(h >> 16);
+  planes[plane_stride + off] = (bf16_t)(md >> 16);
+  planes[2 * plane_stride + off] = (bf16_t)(__float_as_uint(l) >> 16);
+}
+
+// four consecutive columns k0..k0+3 (k0 % 4 == 0) of row m: one 8-byte store per plane
+__device__ __forceinline__ void store_planes4(bf16_t* planes, size_t plane_stride, int k0, int m, const f32x4& v) {
+  uint32_t hw[2], mw[2], lw[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float v0 = v[2 * p], v1 = v[2 * p + 1];
+    const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+    const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+    hw[p] = (h0 >> 16) | h1;
+    mw[p] = (m0 >> 16) | m1;
+    lw[p] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+  const size_t off = ((size_t)((k0 >> 7) * 4 + ((k0 >> 5) & 3)) * 64 + ((k0 >> 3) & 3) * 16 + m) * 8 + (k0 & 7);
+  *reinterpret_cast<uint2*>(planes + off) = make_uint2(hw[0], hw[1]);
+  *reinterpret_cast<uint2*>(planes + plane_stride + off) = make_uint2(mw[0], mw[1]);
+  *reinterpret_cast<uint2*>(planes + 2 * plane_stride + off) = make_uint2(lw[0], lw[1]);
+}
+
 // Workgroup barrier that only waits for the LDS counter.  __syncthreads() also drains vmcnt, i.e. it would wait
 // for every weight load in flight; use this one between a prologue's LDS exchange and the weight consumption.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -140,7 +140,7 @@ struct csm_engine {
   // activations handed between the batched-decode launches as ready-made MFMA B operands (gemv.h: xplanes)
   bf16_t *pl_h = nullptr, *pl_act = nullptr;
   float* pl_ss = nullptr;
-  int use_planes = 1;
+  int use_planes = 15;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
 };
@@ -485,8 +485,12 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
     t.nsplit = nsplit; t.out = att; t.part = part;
     t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
+    // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)
+    const bool att_planes = planes && (e->use_planes & 4);
+    t.oplanes = att_planes ? e->pl_act : nullptr;
     LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
+    if (att_planes) o.xplanes = e->pl_act;
     if (planes) { o.oplanes = e->pl_h; o.oln = w.ln2; o.oss = e->pl_ss; o.oss_ld = PL_SS_LD; }
     LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
   }
@@ -494,13 +498,14 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   GemvArgs g{};
   g.nt = nt_big;
   g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
-  if (planes) { g.xplanes = e->pl_h; g.xss = e->pl_ss; g.xss_n = H / 16; g.xss_ld = PL_SS_LD; g.oplanes = e->pl_act; }
+  const bool act_planes = planes && (e->use_planes & 2);   // A/B: bit 1 = SwiGLU output handed over as planes too
+  if (planes) { g.xplanes = e->pl_h; g.xss = e->pl_ss; g.xss_n = H / 16; g.xss_ld = PL_SS_LD; g.oplanes = act_planes ? e->pl_act : nullptr; }
   LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
 
   GemvArgs d{};
   d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
-  if (planes) { d.xplanes = e->pl_act; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
+  if (planes) { d.xplanes = act_planes ? e->pl_act : nullptr; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
   LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
 }
@@ -562,6 +567,9 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     a.cb = cb; a.C = C; a.B = B; a.frame_ptr = e->d_frame; a.max_frames = e->cfg.max_frames;
     a.ring = e->ring; a.forced = s->forced; a.proj_table = e->w.proj_table; a.Hd = Hd; a.dec_x = e->dec_x;
     a.logits_trace = s->logits_trace;
+    if (planes_on(e, e->dec, B) && (e->use_planes & 8)) {
+      a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16;
+    }
     return launch_sample(e->stream, B, a);
   };
   // B == 1 greedy without traces: codebooks 1..C-2 need no sampler launch -- the head writes per-task argmax
@@ -585,7 +593,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
                        e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr,
                        // pass 0 (the backbone state at position 0) produces no logits: its last layer only has to
                        // append K/V -- the attention, o_proj and MLP of that layer are dead work
-                       p == 0 && l == e->dec.c.layers - 1, l > 0,
+                       p == 0 && l == e->dec.c.layers - 1, l > 0 || (p >= 2 && (e->use_planes & 8) && !use_tok),   // p == 1: codebook 0 was sampled before pass 0 overwrote the planes
                        l + 1 < e->dec.c.layers ? e->dec.layers[l + 1].ln1 : e->dec.final_norm));
     if (p >= 1 && fused && p < C - 1) {
       GemvArgs a{};

@@ -78,19 +78,6 @@ struct AFrag<fp8_t> {
   }
 };
 
-// One activation value into the three planes of the next launch's B operand: exact truncation split, element
-// (row m, column k) at fragment position ((k/128 * 4 + (k/32)%4) * 64 + ((k/8)%4) * 16 + m) * 8 + k%8.
-__device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride, int k, int m, float v) {
-  const uint32_t h = __float_as_uint(v) & 0xffff0000u;
-  const float r = v - __uint_as_float(h);
-  const uint32_t md = __float_as_uint(r) & 0xffff0000u;
-  const float l = r - __uint_as_float(md);
-  const size_t off = ((size_t)((k >> 7) * 4 + ((k >> 5) & 3)) * 64 + ((k >> 3) & 3) * 16 + m) * 8 + (k & 7);
-  planes[off] = (bf16_t)(h >> 16);
-  planes[plane_stride + off] = (bf16_t)(md >> 16);
-  planes[2 * plane_stride + off] = (bf16_t)(__float_as_uint(l) >> 16);
-}
-
 // panel row of tile t, local row r (0..15).  QKV panels pair the two RoPE halves of a head (PT == 2).
 template <int EPI, int PT>
 __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int r) {

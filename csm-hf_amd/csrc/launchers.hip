@@ -7,6 +7,7 @@
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
   if (a.nsplit < 1) return -1;
+  if (a.oplanes && rows > 16) return -1;
   const int G = a.n_q / a.n_kv;
   const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
   const int bd = a.one_wave ? 64 : 256;
@@ -23,8 +24,8 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (e) return e;
   if (a.nsplit > 1) {
     if (a.nsplit > 64) return -1;
-    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out);
-    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out);
+    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes);
+    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes);
     e = (int)hipGetLastError();
   }
   return e;

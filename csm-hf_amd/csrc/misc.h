@@ -206,6 +206,12 @@ struct SampleArgs {
   int Hd;
   float* dec_x;         // [rows][Hd]
   float* logits_trace;  // [max_frames][B][C][V] nullable
+  // batched decode: the fed-back row also goes out as MFMA B-operand planes (gemv.h: xplanes), folded with the norm
+  // weight of the decoder's first layer, with its sum of squares in column 0 of the row's partial sums
+  bf16_t* oplanes;      // nullable
+  const float* oln;
+  float* oss;
+  int oss_ld, oss_n;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -370,8 +376,25 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   if (a.proj_table && a.cb < a.C - 1) {
     const float* src = a.proj_table + ((size_t)feed + (size_t)a.cb * V) * a.Hd;
     float* dst = a.dec_x + (size_t)row * a.Hd;
-    for (int k = tid * 4; k < a.Hd; k += 1024)
-      *reinterpret_cast<f32x4*>(dst + k) = *reinterpret_cast<const f32x4*>(src + k);
+    float sq = 0.f;
+    for (int k = tid * 4; k < a.Hd; k += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + k);
+      *reinterpret_cast<f32x4*>(dst + k) = v;
+      if (a.oplanes && row < 16) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.oln + k);
+        f32x4 t;
+        t[0] = v[0] * w[0]; t[1] = v[1] * w[1]; t[2] = v[2] * w[2]; t[3] = v[3] * w[3];
+        store_planes4(a.oplanes, (size_t)a.Hd * 16, k, row, t);
+        sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+    }
+    if (a.oplanes && row < 16) {   // block-uniform
+      sq = wave_sum(sq);
+      __syncthreads();
+      if ((tid & 63) == 0) s_val[tid >> 6] = sq;
+      __syncthreads();
+      if (tid < a.oss_n) a.oss[(size_t)row * a.oss_ld + tid] = tid == 0 ? (s_val[0] + s_val[1]) + (s_val[2] + s_val[3]) : 0.f;
+    }
   }
 }
 #endif  // CSM_ARGS_ONLY
