@@ -141,6 +141,7 @@ struct csm_engine {
   bf16_t *pl_h = nullptr, *pl_act = nullptr;
   float* pl_ss = nullptr;
   int use_planes = 15;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row
+  int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
 };
@@ -376,6 +377,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
+  else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -505,6 +507,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   GemvArgs d{};
   d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
+  if (e->g16_down) { d.g16_nw = e->g16_down & 0xff; d.g16_kb = (e->g16_down >> 8) & 0xff; d.g16_pt = (e->g16_down >> 16) & 0xff; }
   if (planes) { d.xplanes = act_planes ? e->pl_act : nullptr; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
   LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
