@@ -183,6 +183,17 @@ __device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride
   planes[2 * plane_stride + off] = (bf16_t)(__float_as_uint(l) >> 16);
 }
 
+// two consecutive columns k0, k0+1 (k0 even) of row m: one 4-byte store per plane
+__device__ __forceinline__ void store_planes2(bf16_t* planes, size_t plane_stride, int k0, int m, float v0, float v1) {
+  const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+  const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+  const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+  const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+  const size_t off = ((size_t)((k0 >> 7) * 4 + ((k0 >> 5) & 3)) * 64 + ((k0 >> 3) & 3) * 16 + m) * 8 + (k0 & 7);
+  *reinterpret_cast<uint32_t*>(planes + off) = (h0 >> 16) | h1;
+  *reinterpret_cast<uint32_t*>(planes + plane_stride + off) = (m0 >> 16) | m1;
+  *reinterpret_cast<uint32_t*>(planes + 2 * plane_stride + off) = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+}
 // four consecutive columns k0..k0+3 (k0 % 4 == 0) of row m: one 8-byte store per plane
 __device__ __forceinline__ void store_planes4(bf16_t* planes, size_t plane_stride, int k0, int m, const f32x4& v) {
   uint32_t hw[2], mw[2], lw[2];

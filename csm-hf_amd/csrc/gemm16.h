@@ -125,10 +125,26 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   // position loaded here).  EPI_RESID: requested LAST, behind the weights -- the residual values were written by
   // another XCD a few launches ago and come from HBM; requested first they would hold up the x slice behind them
   // (measured at M = 16: backbone down_proj 17.7 us first vs 12.3 us last).
+  // EPI_RESID / EPI_SWIGLU run a quad epilogue: thread (tile t, C-layout lane l) owns the 4 consecutive output
+  // columns of its accumulator registers -- 16-byte residual loads / stores, packed plane stores.
+  constexpr bool QUAD = (EPI == EPI_RESID || EPI == EPI_SWIGLU);
+  static_assert(!QUAD || PT * 64 <= 64 * NW, "one quad per thread");
+  f32x4 rq = (f32x4)(0.f), lq = (f32x4)(1.f);
   constexpr int NE = (PT * 256 + 64 * NW - 1) / (64 * NW);
   float pre0[NE], pre1[NE];
   int ppos[NE];
   auto prefetch_epi = [&]() {
+    if (QUAD) {
+      if (EPI == EPI_RESID && tid < PT * 64) {
+        const int t = tid >> 6, l = tid & 63, mm = l & 15;
+        const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+        if (mm < M && n0 < a.N) {
+          rq = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
+          if (a.oplanes && a.oln) lq = *reinterpret_cast<const f32x4*>(a.oln + n0);   // the consumer's norm weight
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       pre0[e] = pre1[e] = 0.f;
@@ -139,10 +155,6 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         const int mm = l & 15, r = (l >> 4) * 4 + reg;
         const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
         if (mm < M && n < a.N) {
-          if (EPI == EPI_RESID) {
-            pre0[e] = a.out[(size_t)mm * a.ldo + n];
-            pre1[e] = (a.oplanes && a.oln) ? a.oln[n] : 1.f;   // the consumer's norm weight for the output planes
-          }
           if (EPI == EPI_QKV) {
             ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
             const int half = a.hd >> 1, spp = half / 16;
@@ -308,9 +320,40 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   }
   __syncthreads();
 
+  if (QUAD) {
+    if (tid < PT * 64) {
+      const int t = tid >> 6, l = tid & 63, mm = l & 15;
+      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      if (mm < M && n0 < a.N) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(panel + t * 256 + l * 4);
+        // XP + norm: the planes carry x * norm_weight, the RMS scale of the row multiplies the finished dot product
+        const float rs = (XP && PRO == PRO_NORM) ? stat[mm] : 1.f;
+        if (a.wscale) {
+          const f32x4 ws = *reinterpret_cast<const f32x4*>(a.wscale + n0);
+          pv[0] *= ws[0]; pv[1] *= ws[1]; pv[2] *= ws[2]; pv[3] *= ws[3];
+        }
+        pv[0] *= rs; pv[1] *= rs; pv[2] *= rs; pv[3] *= rs;
+        if (EPI == EPI_RESID) {
+          const f32x4 xn = rq + pv;
+          *reinterpret_cast<f32x4*>(a.out + (size_t)mm * a.ldo + n0) = xn;
+          if (a.oplanes) {
+            f32x4 xt;
+            xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
+            store_planes4(a.oplanes, (size_t)a.N * 16, n0, mm, xt);
+            if (a.oss) red[t * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+          }
+        } else {   // SwiGLU: (gate, up) pairs
+          const float h0 = (pv[0] / (1.f + __expf(-pv[0]))) * pv[1];
+          const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
+          if (a.oplanes) store_planes2(a.oplanes, (size_t)(a.N >> 1) * 16, n0 >> 1, mm, h0, h1);   // the consumer reads the planes only
+          else *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
+        }
+      }
+    }
+  }
   // ---- epilogue: element i = (t, l, reg): weight row = tile row (l>>4)*4+reg, batch row = l & 15 -------
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
+  for (int e = 0; e < (QUAD ? 0 : NE); ++e) {
     const int i = tid + e * 64 * NW;
     if (i >= PT * 256) continue;
     const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
@@ -373,12 +416,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       const int t = tid >> 4, mm = tid & 15;
       const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
       if (mm < M && n0 < a.N) {
-        float q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float sq = red[t * 256 + ((r >> 2) * 16 + mm) * 4 + (r & 3)];
-          q += (n0 + r < a.N) ? sq : 0.f;
-        }
+        const float q = (red[t * 64 + mm] + red[t * 64 + 16 + mm]) + (red[t * 64 + 32 + mm] + red[t * 64 + 48 + mm]);
         a.oss[(size_t)mm * a.oss_ld + (n0 >> 4)] = q;
       }
     }

@@ -28,6 +28,7 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
                            size_t slab_floats, int* tickets, int n_tickets) {
   if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
   if (a.K % 512 != 0 || a.ldx % 4 != 0) return -2;
+  if ((epi == EPI_RESID || epi == EPI_SWIGLU) && (a.N % 16 != 0 || a.ldo % 4 != 0)) return -2;   // quad epilogue: 16-byte rows
   // waves per workgroup x workgroup-level K splits: every wave owns exactly one 128-wide chunk
   const int nchunks = a.K / 128;
   int nw = nchunks >= 16 ? 16 : (nchunks >= 8 ? 8 : 4), KB = 1;
