@@ -123,7 +123,9 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  * loads: 0 none, 1 all, 2 large streams only), "nsplit_backbone" (KV splits of the backbone decode attention, 0 = by
  * length), "use_mfma" (batched rows on the matrix-core kernel), "tile_weights" (fragment-order weight copies for that
  * kernel; 0 frees them), "attn_one_wave" (bit 0 decoder / bit 1 backbone attention as one-wave workgroups),
- * "fuse_sample" (greedy arg-max folded into the head launch), "fuse_decoder_attention", "flash_prefill" */
+ * "use_planes" (bit mask: batched activations handed over as MFMA B-operand planes -- 1 residual stream, 2 SwiGLU
+ * output, 4 attention output, 8 sampler feedback row), "fuse_sample" (greedy arg-max folded into the head launch),
+ * "fuse_decoder_attention", "flash_prefill" */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
