@@ -141,6 +141,7 @@ struct csm_engine {
   bf16_t *pl_h = nullptr, *pl_act = nullptr;
   float* pl_ss = nullptr;
   int use_planes = 15;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row
+  int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
@@ -378,6 +379,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
+  else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -500,6 +502,10 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   GemvArgs g{};
   g.nt = nt_big;
   g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
+  {  // panel tiles of the gate/up launch: low byte decoder, next byte backbone (0 = auto)
+    const int pt = (&s == &e->bb) ? (e->g16_gu >> 8) & 0xff : e->g16_gu & 0xff;
+    if (pt) g.g16_pt = pt;
+  }
   const bool act_planes = planes && (e->use_planes & 2);   // A/B: bit 1 = SwiGLU output handed over as planes too
   if (planes) { g.xplanes = e->pl_h; g.xss = e->pl_ss; g.xss_n = H / 16; g.xss_ld = PL_SS_LD; g.oplanes = act_planes ? e->pl_act : nullptr; }
   LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));

@@ -48,11 +48,14 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
     if (kvdtype == 1) return launch_nw<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
     return launch_nw<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
-  // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels
+  // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels; gate/up
+  // on activation planes: 32-row panels (two workgroups per CU, one's tail under the other's stream: B=16 5.20 -> 5.04 ms)
   const int ntiles = (a.N + 15) / 16;
   const bool big = a.g16_pt ? a.g16_pt == 4 : (KB > 1 ? ntiles >= 128 : ntiles / 4 >= 128);
 #define G16(P, E)                                                                                              \
   if (pro == P && epi == E) {                                                                                  \
+    if (a.g16_pt == 2 || (!a.g16_pt && a.xplanes && E == EPI_SWIGLU))                                              \
+      return launch_nw<WT, float, P, E, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);             \
     if (big) return launch_nw<WT, float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \
     return launch_nw<WT, float, P, E, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);                \
   }
