@@ -142,8 +142,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # test hook (1-GPU box): CSM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo, which exercises the
+        # rank slicing / barrier / MAX-reduce / gather logic of this file without a second GPU; never set by the driver
+        if os.environ.get("CSM_BENCH_ONE_DEVICE") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
