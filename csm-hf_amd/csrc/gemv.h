@@ -273,23 +273,15 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   if (PRO != PRO_TOKNORM) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-#ifdef CSM_ABLATE_X
-      xa[u] = (f32x4)((float)lane); xb[u] = (f32x4)(1.f + e0);
-#else
       xa[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512);
       xb[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512 + 4);
-#endif
     }
   }
   if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-#ifdef CSM_ABLATE_LN
-      la[u] = (f32x4)(1.f); lb[u] = (f32x4)(1.f);
-#else
       la[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512);
       lb[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512 + 4);
-#endif
     }
   }
 #pragma unroll
