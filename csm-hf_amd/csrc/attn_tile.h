@@ -45,15 +45,21 @@ struct AttnTile32 {
   __device__ __forceinline__ void accumulate(const float* qh, float* pbuf, int cnt, int lane, float& m_run,
                                              float& l_run, f32x4& acc) const {
     const int t = lane & 31, half = lane >> 5;
-    float s = 0.f;
+    // pair arithmetic, two independent accumulator pairs: with one wave per SIMD (decoder attention) nothing hides
+    // the latency of a 64-deep dependent FMA chain; this one is 8 deep
+    f32x2 sa = f32x2{0.f, 0.f}, sb = f32x2{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const f32x4 qv = *reinterpret_cast<const f32x4*>(qh + (half * NK + i) * 4);
-      s = fmaf(qv[0], k[i][0], s);
-      s = fmaf(qv[1], k[i][1], s);
-      s = fmaf(qv[2], k[i][2], s);
-      s = fmaf(qv[3], k[i][3], s);
+      if (i & 1) {
+        sb = PKFMA((f32x2{qv[0], qv[1]}), (f32x2{k[i][0], k[i][1]}), sb);
+        sb = PKFMA((f32x2{qv[2], qv[3]}), (f32x2{k[i][2], k[i][3]}), sb);
+      } else {
+        sa = PKFMA((f32x2{qv[0], qv[1]}), (f32x2{k[i][0], k[i][1]}), sa);
+        sa = PKFMA((f32x2{qv[2], qv[3]}), (f32x2{k[i][2], k[i][3]}), sa);
+      }
     }
+    float s = (sa[0] + sa[1]) + (sb[0] + sb[1]);
     s = xor32_sum(s);
     const bool valid = t < cnt;
     if (!valid) s = -INFINITY;
@@ -67,14 +73,15 @@ struct AttnTile32 {
     __builtin_amdgcn_wave_barrier();
     const int tpar = lane / LPR;
     acc *= alpha;
+    f32x2 a01 = f32x2{acc[0], acc[1]}, a23 = f32x2{acc[2], acc[3]};
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       const float pv = pbuf[tpar + TP * i];
-      acc[0] = fmaf(pv, v[i][0], acc[0]);
-      acc[1] = fmaf(pv, v[i][1], acc[1]);
-      acc[2] = fmaf(pv, v[i][2], acc[2]);
-      acc[3] = fmaf(pv, v[i][3], acc[3]);
+      const f32x2 p2 = f32x2{pv, pv};
+      a01 = PKFMA(p2, (f32x2{v[i][0], v[i][1]}), a01);
+      a23 = PKFMA(p2, (f32x2{v[i][2], v[i][3]}), a23);
     }
+    acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
     __builtin_amdgcn_wave_barrier();
   }
 
