@@ -149,14 +149,33 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TI; ++j) acc[i][j] = (f32x16)(0.f);
 
+  // register prefetch: the global loads of k-step s+1 are issued right after the staging barrier of step s and fly
+  // under its LDS reads and MFMAs (at R = 512 the grid is one workgroup per CU, so nothing else hides them)
+  f32x4 pa[BM / 32];
+  u32x4 pw[BN / 64];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, c4 = idx & 7;
+      pa[i] = (f32x4)(0.f);
+      if (r0 + row < a.R) pa[i] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 64; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 2, c8 = idx & 3;
+      pw[i] = load_w8_as_bf16<WT>(W + (size_t)(n0 + row) * a.K + k0 + c8 * 8);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
     // ---- stage A: fp32 -> three bf16 planes ------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 3, c4 = idx & 7;
-      f32x4 v = (f32x4)(0.f);
-      if (r0 + row < a.R) v = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
+      const f32x4 v = pa[i];
       uint32_t h[2], m[2], l[2];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -179,9 +198,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
     for (int i = 0; i < BN / 64; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 2, c8 = idx & 3;
-      *reinterpret_cast<u32x4*>(&Ws[row * LDK + c8 * 8]) = load_w8_as_bf16<WT>(W + (size_t)(n0 + row) * a.K + k0 + c8 * 8);
+      *reinterpret_cast<u32x4*>(&Ws[row * LDK + c8 * 8]) = pw[i];
     }
-    __syncthreads();
+    lds_barrier();
+    if (k0 + BK < a.K) fetch(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       const int ko = kk + (lane >> 5) * 8;
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni], acc[mi][ni], 0, 0, 0);  // hi
         }
     }
-    __syncthreads();
+    lds_barrier();   // LDS-only: the prefetched loads stay in flight
   }
   // ---- epilogue (same C/D layout as the fp32 kernel) ------------------------------------------------
 #pragma unroll
