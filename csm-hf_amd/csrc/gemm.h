@@ -130,9 +130,12 @@ __device__ __forceinline__ u32x4 load_w8_as_bf16<fp8_t>(const fp8_t* p) {
 // BT = square block tile (128 or 64); 4 waves as 2x2, each wave (BT/2)x(BT/2) = (BT/64)^2 MFMA tiles of 32x32.
 // The 64x64 tile is used when the 128x128 grid would leave most of the chip idle (prefill of one utterance
 // through the N = 2048 projections: 4 x 16 tiles).
-template <typename WT, int EPI, int BT>
+// BKT = k-step (64 when K % 64 == 0: half the barriers per weight byte, 144-byte LDS rows; else 32)
+template <typename WT, int EPI, int BT, int BKT>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
-  constexpr int BM = BT, BN = BT, BK = 32, LDK = BK + 8;   // bf16 elements per LDS row (80 bytes)
+  constexpr int BM = BT, BN = BT, BK = BKT, LDK = BK + 8;   // bf16 elements per LDS row (80 / 144 bytes: conflict-free b128 reads)
+  constexpr int A4 = BK / 4, W8N = BK / 8;                        // f32x4 pieces per A row, 8-weight pieces per W row
+  constexpr int NA = BM * A4 / 256, NWL = BN * W8N / 256;         // pieces per thread per k-step
   constexpr int TI = BT / 64;                              // MFMA tiles per wave per dimension
   __shared__ __attribute__((aligned(16))) bf16_t Ap[3][BM * LDK];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[BN * LDK];
@@ -151,20 +154,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 
   // register prefetch: the global loads of k-step s+1 are issued right after the staging barrier of step s and fly
   // under its LDS reads and MFMAs (at R = 512 the grid is one workgroup per CU, so nothing else hides them)
-  f32x4 pa[BM / 32];
-  u32x4 pw[BN / 64];
+  f32x4 pa[NA];
+  u32x4 pw[NWL];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx >> 3, c4 = idx & 7;
+      const int row = idx / A4, c4 = idx % A4;
       pa[i] = (f32x4)(0.f);
       if (r0 + row < a.R) pa[i] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
     }
 #pragma unroll
-    for (int i = 0; i < BN / 64; ++i) {
+    for (int i = 0; i < NWL; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx >> 2, c8 = idx & 3;
+      const int row = idx / W8N, c8 = idx % W8N;
       pw[i] = load_w8_as_bf16<WT>(W + (size_t)(n0 + row) * a.K + k0 + c8 * 8);
     }
   };
@@ -172,9 +175,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   for (int k0 = 0; k0 < a.K; k0 += BK) {
     // ---- stage A: fp32 -> three bf16 planes ------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx >> 3, c4 = idx & 7;
+      const int row = idx / A4, c4 = idx % A4;
       const f32x4 v = pa[i];
       uint32_t h[2], m[2], l[2];
 #pragma unroll
@@ -195,9 +198,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
     }
     // ---- stage W (bf16 as is, fp8 widened exactly) -------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < BN / 64; ++i) {
+    for (int i = 0; i < NWL; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx >> 2, c8 = idx & 3;
+      const int row = idx / W8N, c8 = idx % W8N;
       *reinterpret_cast<u32x4*>(&Ws[row * LDK + c8 * 8]) = pw[i];
     }
     lds_barrier();

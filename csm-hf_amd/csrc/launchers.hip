@@ -39,16 +39,21 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
   return (int)hipGetLastError();
 }
 
-template <typename WT, int BT>
-static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
+template <typename WT, int BT, int BK>
+static int launch_gemm_x3_bk(hipStream_t st, int epi, const GemmArgs& a) {
   const int grid = ((a.R + BT - 1) / BT) * (a.N / BT);
   switch (epi) {
-    case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT>), dim3(grid), dim3(256), 0, st, a); break;
-    case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT>), dim3(grid), dim3(256), 0, st, a); break;
-    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
     default: return -1;
   }
   return (int)hipGetLastError();
+}
+template <typename WT, int BT>
+static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
+  if (a.K % 64 == 0) return launch_gemm_x3_bk<WT, BT, 64>(st, epi, a);
+  return launch_gemm_x3_bk<WT, BT, 32>(st, epi, a);
 }
 
 template <typename WT>
