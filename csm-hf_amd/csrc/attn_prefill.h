@@ -17,6 +17,8 @@ struct PrefillAttnArgs {
   int S, past;          // row r = b*S + s sits at position past + s
   const int* kv_start;  // nullable: first valid key of each sequence (left padding)
   float* out;           // [B*S][n_q*64]
+  bf16_t* oplanes;      // nullable: output as row-major planes [3][B*S][n_q*64] for the o_proj GEMM instead of `out`
+  size_t plane_stride;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -123,8 +125,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
     f32x4 v0, v1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v0[i] = o0[4 * r4 + i] * inv; v1[i] = o1[4 * r4 + i] * inv; }
-    *reinterpret_cast<f32x4*>(dst + d) = v0;
-    *reinterpret_cast<f32x4*>(dst + 32 + d) = v1;
+    if (a.oplanes) {
+      bf16_t* pd = a.oplanes + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
+      store_rowplanes4(pd + d, a.plane_stride, v0);
+      store_rowplanes4(pd + 32 + d, a.plane_stride, v1);
+    } else {
+      *reinterpret_cast<f32x4*>(dst + d) = v0;
+      *reinterpret_cast<f32x4*>(dst + 32 + d) = v1;
+    }
   }
 }
 #endif  // CSM_ARGS_ONLY

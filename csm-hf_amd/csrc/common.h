@@ -183,6 +183,34 @@ __device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride
   planes[2 * plane_stride + off] = (bf16_t)(__float_as_uint(l) >> 16);
 }
 
+// prefill planes are plain row-major [3][rows][K] bf16 (the prefill GEMM stages them to LDS itself): 4 consecutive
+// columns of one row, one 8-byte store per plane; `p` points at plane 0, element (row, k0)
+__device__ __forceinline__ void store_rowplanes4(bf16_t* p, size_t plane_stride, const f32x4& v) {
+  uint32_t hw[2], mw[2], lw[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float v0 = v[2 * q], v1 = v[2 * q + 1];
+    const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+    const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+    hw[q] = (h0 >> 16) | h1;
+    mw[q] = (m0 >> 16) | m1;
+    lw[q] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+  *reinterpret_cast<uint2*>(p) = make_uint2(hw[0], hw[1]);
+  *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(mw[0], mw[1]);
+  *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(lw[0], lw[1]);
+}
+__device__ __forceinline__ void store_rowplane1(bf16_t* p, size_t plane_stride, float v) {
+  const uint32_t h = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(h);
+  const uint32_t md = __float_as_uint(r) & 0xffff0000u;
+  const float l = r - __uint_as_float(md);
+  p[0] = (bf16_t)(h >> 16);
+  p[plane_stride] = (bf16_t)(md >> 16);
+  p[2 * plane_stride] = (bf16_t)(__float_as_uint(l) >> 16);
+}
 // two consecutive columns k0, k0+1 (k0 even) of row m: one 4-byte store per plane
 __device__ __forceinline__ void store_planes2(bf16_t* planes, size_t plane_stride, int k0, int m, float v0, float v1) {
   const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;

@@ -28,7 +28,8 @@
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a);
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
-                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add);
+                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes = nullptr,
+                   size_t plane_stride = 0);
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
@@ -102,6 +103,9 @@ struct csm_engine {
   // prefill scratch
   float *p_h = nullptr, *p_xn = nullptr, *p_qkv = nullptr, *p_q = nullptr, *p_att = nullptr, *p_act = nullptr;
   int *p_row_seq = nullptr, *p_row_pos = nullptr;
+  // prefill activations as row-major bf16 planes [3][rows][K] (bf16 / fp8 weights): split once by the producer
+  bf16_t *p_pl_h = nullptr, *p_pl_act = nullptr;
+  int prefill_planes = 1;
   // host mirrors
   int B = 0;
   int h_len = 0, h_frame = 0;
@@ -237,6 +241,10 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->p_att, R * nqb)) || (r = dalloc(e, &e->p_act, R * cfg->backbone.ffn)) ||
       (r = dalloc(e, &e->p_row_seq, R)) || (r = dalloc(e, &e->p_row_pos, R)))
     return r;
+  if (cfg->weight_dtype != CSM_DTYPE_F32) {
+    const size_t Km = std::max((size_t)Hb, (size_t)nqb);
+    if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * cfg->backbone.ffn))) return r;
+  }
   if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
   {
@@ -378,6 +386,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
+  else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
@@ -688,10 +697,14 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
   em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
   em.ids = ids; em.mask = mask; em.out = e->p_h;
   LCK(launch_embed(e->stream, emb_dtype(e), (int)R, em));
+  // bf16 / fp8 weights: RMSNorm, the flash attention and the SwiGLU epilogue hand their outputs to the next GEMM as
+  // exact bf16 planes (split once per element instead of once per column block of the consumer)
+  const bool pl = e->prefill_planes && e->p_pl_h && wd != CSM_DTYPE_F32 && Hb % 8 == 0 && F % 8 == 0 && (nq * hd) % 8 == 0;
   for (int l = 0; l < s.c.layers; ++l) {
     const csm_layer_weights_t& w = s.layers[l];
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, R * Hb));
     GemmArgs g{};
+    if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = R * Hb; }
     g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
     LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
@@ -702,7 +715,9 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;
     fa.S = S; fa.past = e->h_len; fa.kv_start = e->d_kv_start; fa.out = e->p_att;
+    if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = R * (size_t)(nq * hd); }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa) : -2;
+    bool att_pl = pl && fr != -2;
     if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
       AttnArgs t{};
       t.q = e->p_q; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
@@ -711,13 +726,16 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     }
     LCK(fr);
     GemmArgs o{};
+    if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = R * (size_t)(nq * hd); }
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
     LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0));
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, R * Hb));
     GemmArgs gu{};
+    if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = R * Hb; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = R * (size_t)F; }
     gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
+    if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = R * (size_t)F; }
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
     LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
   }

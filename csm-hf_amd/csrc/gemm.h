@@ -22,6 +22,12 @@ struct GemmArgs {
   float* C;  // STORE/RESID: [R][ldc]; SWIGLU: [R][ldc] with N/2 columns
   int ldc;
   int f32_mfma;  // force the fp32-MFMA kernel also for bf16 / fp8 weights (A/B measurements)
+  // bf16x3 kernel only: activations already split by the producer -- row-major planes [3][rows][K] (A is ignored) --
+  // and, for the SwiGLU epilogue, the output written as planes [3][rows][N/2] for the down_proj GEMM (C is ignored)
+  const bf16_t* Aplanes;
+  size_t a_plane_stride;
+  bf16_t* Cplanes;
+  size_t c_plane_stride;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -92,7 +98,11 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
         const float v = acc[mi][ni][reg] * (a.wscale ? a.wscale[n] : 1.f);
         if (EPI == GEPI_SWIGLU) {
           const float o = __shfl_xor(v, 1, 64);  // even lane: gate (own), up (partner)
-          if (!(lane & 1) && r < a.R) a.C[(size_t)r * a.ldc + (n >> 1)] = (v / (1.f + __expf(-v))) * o;
+          if (!(lane & 1) && r < a.R) {
+            const float hv = (v / (1.f + __expf(-v))) * o;
+            if (a.Cplanes) store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1), a.c_plane_stride, hv);
+            else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
+          }
         } else if (r < a.R) {
           if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
@@ -131,11 +141,12 @@ __device__ __forceinline__ u32x4 load_w8_as_bf16<fp8_t>(const fp8_t* p) {
 // The 64x64 tile is used when the 128x128 grid would leave most of the chip idle (prefill of one utterance
 // through the N = 2048 projections: 4 x 16 tiles).
 // BKT = k-step (64 when K % 64 == 0: half the barriers per weight byte, 144-byte LDS rows; else 32)
-template <typename WT, int EPI, int BT, int BKT>
+template <typename WT, int EPI, int BT, int BKT, bool AP>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   constexpr int BM = BT, BN = BT, BK = BKT, LDK = BK + 8;   // bf16 elements per LDS row (80 / 144 bytes: conflict-free b128 reads)
   constexpr int A4 = BK / 4, W8N = BK / 8;                        // f32x4 pieces per A row, 8-weight pieces per W row
   constexpr int NA = BM * A4 / 256, NWL = BN * W8N / 256;         // pieces per thread per k-step
+  constexpr int NP = BM * W8N / 256;                              // AP: 8-element pieces per plane per thread
   constexpr int TI = BT / 64;                              // MFMA tiles per wave per dimension
   __shared__ __attribute__((aligned(16))) bf16_t Ap[3][BM * LDK];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[BN * LDK];
@@ -154,15 +165,30 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 
   // register prefetch: the global loads of k-step s+1 are issued right after the staging barrier of step s and fly
   // under its LDS reads and MFMAs (at R = 512 the grid is one workgroup per CU, so nothing else hides them)
-  f32x4 pa[NA];
+  f32x4 pa[AP ? 1 : NA];
+  u32x4 pp[AP ? 3 * NP : 1];
   u32x4 pw[NWL];
   auto fetch = [&](int k0) {
+    if (AP) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / A4, c4 = idx % A4;
-      pa[i] = (f32x4)(0.f);
-      if (r0 + row < a.R) pa[i] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
+      for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / W8N, c8 = idx % W8N;
+        const bf16_t* src = a.Aplanes + (size_t)(r0 + row) * a.K + k0 + c8 * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          pp[3 * i + p] = (u32x4)(0u);
+          if (r0 + row < a.R) pp[3 * i + p] = *reinterpret_cast<const u32x4*>(src + p * a.a_plane_stride);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / A4, c4 = idx % A4;
+        pa[i] = (f32x4)(0.f);
+        if (r0 + row < a.R) pa[i] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(r0 + row) * a.lda + k0 + c4 * 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NWL; ++i) {
@@ -173,9 +199,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   };
   fetch(0);
   for (int k0 = 0; k0 < a.K; k0 += BK) {
-    // ---- stage A: fp32 -> three bf16 planes ------------------------------------------------------
+    // ---- stage A: ready-made planes, or fp32 -> three bf16 planes --------------------------------
+    if (AP) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
+      for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / W8N, c8 = idx % W8N;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Ap[p][row * LDK + c8 * 8]) = pp[3 * i + p];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (AP ? 0 : NA); ++i) {
       const int idx = tid + i * 256;
       const int row = idx / A4, c4 = idx % A4;
       const f32x4 v = pa[i];
@@ -241,7 +276,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
         const float v = acc[mi][ni][reg] * (a.wscale ? a.wscale[n] : 1.f);
         if (EPI == GEPI_SWIGLU) {
           const float o = __shfl_xor(v, 1, 64);
-          if (!(lane & 1) && r < a.R) a.C[(size_t)r * a.ldc + (n >> 1)] = (v / (1.f + __expf(-v))) * o;
+          if (!(lane & 1) && r < a.R) {
+            const float hv = (v / (1.f + __expf(-v))) * o;
+            if (a.Cplanes) store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1), a.c_plane_stride, hv);
+            else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
+          }
         } else if (r < a.R) {
           if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;

@@ -42,10 +42,20 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
 template <typename WT, int BT, int BK>
 static int launch_gemm_x3_bk(hipStream_t st, int epi, const GemmArgs& a) {
   const int grid = ((a.R + BT - 1) / BT) * (a.N / BT);
+  if (a.Aplanes) {
+    if (a.K % 8) return -1;
+    switch (epi) {
+      case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT, BK, true>), dim3(grid), dim3(256), 0, st, a); break;
+      case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT, BK, true>), dim3(grid), dim3(256), 0, st, a); break;
+      case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT, BK, true>), dim3(grid), dim3(256), 0, st, a); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   switch (epi) {
-    case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
-    case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
-    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT, BK>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT, BK, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT, BK, false>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT, BK, false>), dim3(grid), dim3(256), 0, st, a); break;
     default: return -1;
   }
   return (int)hipGetLastError();
@@ -92,10 +102,10 @@ int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
 }
 
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
-                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add) {
+                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes, size_t plane_stride) {
   if (H % 4 != 0) return -1;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, H, eps, out, ldo, frame_ptr,
-                     frame_stride, frame_add);
+                     frame_stride, frame_add, planes, plane_stride);
   return (int)hipGetLastError();
 }
 

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
 #ifndef CSM_ARGS_ONLY
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, const float* w, int H, float eps,
                                                       float* out, int ldo, const int* frame_ptr,
-                                                      size_t frame_stride, int frame_add) {
+                                                      size_t frame_stride, int frame_add, bf16_t* planes,
+                                                      size_t plane_stride) {
+  // planes != nullptr: the normed row goes out as three exact bf16 planes [3][rows][H] for the prefill GEMM
+  // (split once here instead of once per column block of every GEMM that reads it); `out` is then not written
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (size_t)row * ldx;
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
     v[1] = (v[1] * sc) * g[1];
     v[2] = (v[2] * sc) * g[2];
     v[3] = (v[3] * sc) * g[3];
-    *reinterpret_cast<f32x4*>(o + k) = v;
+    if (planes) store_rowplanes4(planes + (size_t)row * H + k, plane_stride, v);
+    else *reinterpret_cast<f32x4*>(o + k) = v;
   }
 }
 
