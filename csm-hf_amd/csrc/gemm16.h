@@ -3,12 +3,14 @@
 //
 // Roofline: HBM (weights N*K*2 bytes read once per launch, independent of M).  Each 16x16x32 MFMA consumes
 // a 16-row x 32-k weight fragment straight from registers (A operand) against the activations (B operand);
-// no LDS round trip for the weights.  Activations stay fp32-exact: x is split on the fly into three bf16
-// parts by truncation (x = hi + mid + lo, 3 x 8 = 24 mantissa bits, no rounding) and every weight fragment is multiplied by all three
-// (bf16 x bf16 products are exact in fp32), so the result matches the M<=4 fp32-FMA kernels to fp32
+// no LDS round trip for the weights.  Activations stay fp32-exact: x is carried as three bf16 parts
+// (x = hi + mid + lo by truncation, 3 x 8 = 24 mantissa bits, no rounding) and every weight fragment is multiplied
+// by all three (bf16 x bf16 products are exact in fp32), so the result matches the M<=4 fp32-FMA kernels to fp32
 // summation-order error; the matrix pipe has >8x headroom over the HBM stream even at 3 MFMAs per fragment.
-// The k index inside a 128-wide chunk is permuted (lane group g, step j -> k = g*32 + j*8 + 0..7) so every
-// lane reads 64 contiguous bytes of its weight row per chunk; x uses the same permutation.
+// Three variants of the operand paths (template flags TL, XP, documented at the kernel):
+//   row-major weights + fp32 x split in the kernel (k permuted so a lane reads 64 contiguous bytes of its row),
+//   fragment-order weights (one coalesced 1 KiB load per fragment) + fp32 x split in the kernel,
+//   fragment-order weights + activation planes written by the producing launch (no arithmetic ahead of the MFMAs).
 // A workgroup owns a panel of PT 16-row tiles; its NW waves take one 128-wide k chunk each and meet in LDS.
 //
 // Same prologues/epilogues as gemv.h (plain | RMSNorm ; store | residual | SwiGLU | RoPE + KV append).
