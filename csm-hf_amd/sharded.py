@@ -2,7 +2,8 @@
 
 Utterances are independent -- the only cross-row operation in the reference is the global all-zero stop
 test (`modeling_csm.py:662`) -- so the path shards by contiguous blocks of batch rows with replicated
-weights, one process per GPU, and NO collective on the per-frame path.  RCCL (`backend="nccl"`) is used
+weights, one process per GPU, and NO collective on the per-frame path (the global stop is applied after the
+gather, see `generate_sharded`).  RCCL (`backend="nccl"`) is used
 only to gather the finished `[rows, n, 32]` frames; the same code runs under `gloo` on CPU for tests.
 """
 from __future__ import annotations
@@ -38,19 +39,29 @@ def gather_frames(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
 
 def generate_sharded(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, group=None, **gen_kwargs) -> torch.Tensor:
     """Every rank passes the FULL `[B, T, 33]` batch; each generates its own rows; all ranks return the
-    full `[B, n, 32]` result.  `stop_on_all_zeros` keeps the reference's semantics per shard only when
-    False (the global stop test would need a per-frame all-reduce)."""
+    full `[B, n, 32]` result.
+
+    `stop_on_all_zeros=True` keeps the reference's GLOBAL semantics (`modeling_csm.py:662`: stop at the first
+    frame that is all-zero in every row of the batch) without a collective on the per-frame path: every shard
+    generates `max_new_frames` frames un-stopped, the gathered result is cut at the first globally all-zero
+    frame.  Rows are independent, so the frames before the cut are exactly what a per-frame global test
+    would have produced; the price is the frames generated past the cut."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if gen_kwargs.get("stop_on_all_zeros", True) and world > 1:
-        raise ValueError("generate_sharded needs stop_on_all_zeros=False: shards would stop at different frames")
+    stop = bool(gen_kwargs.get("stop_on_all_zeros", True))
+    if world == 1:
+        return model.generate(input_ids, attention_mask, **gen_kwargs)
+    kw = dict(gen_kwargs, stop_on_all_zeros=False)
     a, b = shard_rows(input_ids.shape[0], rank, world)
     if b > a:
-        local = model.generate(input_ids[a:b], attention_mask[a:b], **gen_kwargs)
+        local = model.generate(input_ids[a:b], attention_mask[a:b], **kw)
     else:  # more ranks than rows
         n = int(gen_kwargs.get("max_new_frames", 100))
         local = torch.zeros(0, n, input_ids.shape[2] - 1, dtype=torch.long, device=input_ids.device)
-    if world == 1:
-        return local
-    return gather_frames(local, input_ids.shape[0], group)
+    full = gather_frames(local, input_ids.shape[0], group)
+    if stop and full.shape[1] > 0:
+        zero = (full == 0).all(dim=2).all(dim=0)          # [n]: frame f is all-zero in every row
+        if bool(zero.any()):
+            full = full[:, : int(zero.nonzero()[0])]
+    return full

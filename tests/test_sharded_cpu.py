@@ -13,11 +13,23 @@ from csm_hf_amd.sharded import shard_rows, gather_frames, generate_sharded
 class StubModel:
     """Row-wise deterministic stand-in for CSMModel.generate (the engine needs a GPU)."""
 
-    def generate(self, ids, mask, max_new_frames=3, **_):
+    def __init__(self, zero_rows_at=None, zero_all_at=None):
+        self.zero_rows_at, self.zero_all_at = zero_rows_at, zero_all_at
+
+    def generate(self, ids, mask, max_new_frames=3, stop_on_all_zeros=False, **_):
         key = ids.sum(dim=(1, 2)) + mask.sum(dim=(1, 2)) * 7
         f = torch.arange(max_new_frames)[None, :, None]
         c = torch.arange(32)[None, None, :]
-        return (key[:, None, None] * 31 + f * 5 + c) % 2051
+        out = (key[:, None, None] * 31 + f * 5 + c) % 2051 + 1          # never 0 by itself
+        if self.zero_rows_at is not None:                               # some rows end early ...
+            out[ids[:, 0, 0] % 2 == 0, self.zero_rows_at] = 0
+        if self.zero_all_at is not None and self.zero_all_at < max_new_frames:   # ... every row ends here
+            out[:, self.zero_all_at] = 0
+        if stop_on_all_zeros:                                           # the reference's rule over THIS call's rows
+            z = (out == 0).all(dim=2).all(dim=0)
+            if bool(z.any()):
+                out = out[:, : int(z.nonzero()[0])]
+        return out
 
 
 def _free_port():
@@ -38,11 +50,13 @@ def _worker(rank, world, port, B, q):
     out = generate_sharded(StubModel(), ids, mask, max_new_frames=4, stop_on_all_zeros=False)
     ref = StubModel().generate(ids, mask, max_new_frames=4)
     ok = torch.equal(out, ref)
-    try:
-        generate_sharded(StubModel(), ids, mask, max_new_frames=4, stop_on_all_zeros=True)
-        ok = False
-    except ValueError:
-        pass
+    # global stop: rows with an even key go silent at frame 1, every row at frame 3 -> the unsharded reference rule
+    # returns 3 frames; a shard holding only even-key rows must not stop at frame 1
+    ids[:, 0, 0] = torch.arange(B) + 1          # row 0 odd (never early), row 1 even (early), ...
+    m = StubModel(zero_rows_at=1, zero_all_at=3)
+    want = m.generate(ids, mask, max_new_frames=6, stop_on_all_zeros=True)
+    got = generate_sharded(m, ids, mask, max_new_frames=6, stop_on_all_zeros=True)
+    ok = ok and want.shape[1] == 3 and torch.equal(got, want)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
