@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ int s_idx[4];
   __shared__ unsigned hist[256];
   __shared__ unsigned s_sel[2];
+  __shared__ int s_wsum[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const int V = a.V;
   const float* lg = a.logits + (size_t)row * a.ldl;
@@ -307,19 +308,46 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     for (int pass = 3; pass >= 0; --pass) {
       hist[tid] = 0;
       __syncthreads();
-      for (int i = tid; i < V; i += 256) {
-        const uint32_t k = f32_key(sx[i]);
-        if ((k & pmask) == prefix) atomicAdd(&hist[(k >> (pass * 8)) & 255u], 1u);
+      for (int i0 = 0; i0 < V; i0 += 256) {
+        const int i = i0 + tid;
+        const uint32_t k = i < V ? f32_key(sx[i]) : 0u;
+        bool live = i < V && (k & pmask) == prefix;
+        const uint32_t bin = (k >> (pass * 8)) & 255u;
+        if (pass == 3) {
+          // sign + exponent byte: a handful of distinct values per wave -- one LDS atomic per distinct value
+          // (a plain per-element atomic serialises ~2000 adds on 3-4 addresses)
+          uint64_t todo = __ballot(live);
+          while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+            const uint64_t same = __ballot(live && bin == lb);
+            if ((int)(tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__builtin_popcountll(same));
+            todo &= ~same;
+          }
+        } else if (live) {
+          atomicAdd(&hist[bin], 1u);
+        }
       }
       __syncthreads();
-      if (tid == 0) {
-        int cum = 0, d = 255;
-        for (; d > 0; --d) {
-          if (cum + (int)hist[d] >= krem) break;
-          cum += hist[d];
+      {
+        // digit d with  #(keys in higher digits) < krem <= that + hist[d] : suffix sums of the 256 bins in parallel
+        // (a single thread walking the bins cost up to 255 dependent LDS reads per pass)
+        const int lane = tid & 63, wv = tid >> 6;
+        const int h = (int)hist[tid];
+        int incl = h;   // sum over this wave's bins with index >= own
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_down(incl, o, 64);
+          if (lane + o < 64) incl += v;
         }
-        s_sel[0] = (unsigned)d;
-        s_sel[1] = (unsigned)(krem - cum);
+        if (lane == 0) s_wsum[wv] = incl;
+        __syncthreads();
+        int above = incl - h;
+        for (int w = wv + 1; w < 4; ++w) above += s_wsum[w];
+        if (above < krem && above + h >= krem) {
+          s_sel[0] = (unsigned)tid;
+          s_sel[1] = (unsigned)(krem - above);
+        }
       }
       __syncthreads();
       prefix |= s_sel[0] << (pass * 8);
@@ -353,6 +381,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < V; i += 256) {
+      // Philox mode: entries cut by the top-k filter have p == 0 and can never win, their variates are not drawn
+      // (explicit-noise mode keeps every entry, exactly like the reference's argmax over p / q)
+      if (!a.noise && sx[i] == -INFINITY) continue;
       const float p = expf(sx[i] - m2) / s2;
       float q;
       if (a.noise) {
