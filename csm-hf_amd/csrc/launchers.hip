@@ -116,7 +116,7 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
 }
 
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a) {
-  const size_t lds = (size_t)a.V * sizeof(float);
+  const size_t lds = (size_t)3 * a.V * sizeof(float);   // scaled logits | survivor values | survivor indices
   hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }

@@ -356,47 +356,71 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       __syncthreads();
     }
     const uint32_t kth_key = prefix;  // key of the k-th largest value
-    // ---- log_softmax then softmax over the survivors (two normalisations, like the reference) ----
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += 256) {
+    // ---- survivors (>= k-th value; ties included, like the reference's `x < kth` mask) compacted in index order:
+    // every thread owns a contiguous chunk, one block-wide exclusive scan of the per-thread counts, then wave 0
+    // finishes alone -- the two normalisations and the race touch ~k entries, not V, and need no more barriers.
+    float* cv = sx + V;                                   // [V] survivor values
+    int* ci = reinterpret_cast<int*>(sx + 2 * V);         // [V] survivor indices
+    const int per = (V + 255) / 256;
+    const int i0 = tid * per, i1 = min(V, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += f32_key(sx[i]) >= kth_key;
+    int incl = cnt;
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) s_wsum[wv] = incl;
+      __syncthreads();
+      for (int w = 0; w < wv; ++w) incl += s_wsum[w];
+    }
+    int pos = incl - cnt;
+    for (int i = i0; i < i1; ++i) {
       const float v = sx[i];
-      if (f32_key(v) >= kth_key) mx = fmaxf(mx, v); else sx[i] = -INFINITY;
+      if (f32_key(v) >= kth_key) { cv[pos] = v; ci[pos] = i; ++pos; }
     }
-    mx = block_max(mx, s_val);
-    float se = 0.f;
-    for (int i = tid; i < V; i += 256) se += expf(sx[i] - mx);
-    se = block_sum(se, s_val);
-    const float lse = logf(se);
-    float m2 = -INFINITY;
-    for (int i = tid; i < V; i += 256) {
-      const float lp = (sx[i] - mx) - lse;
-      sx[i] = lp;
-      m2 = fmaxf(m2, lp);
-    }
-    m2 = block_max(m2, s_val);
-    float s2 = 0.f;
-    for (int i = tid; i < V; i += 256) s2 += expf(sx[i] - m2);
-    s2 = block_sum(s2, s_val);
-    // ---- exponential race ------------------------------------------------------------------------
+    if (tid == 255) s_sel[0] = (unsigned)incl;            // number of survivors
+    __syncthreads();
+    const int ns = (int)s_sel[0];
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-      // Philox mode: entries cut by the top-k filter have p == 0 and can never win, their variates are not drawn
-      // (explicit-noise mode keeps every entry, exactly like the reference's argmax over p / q)
-      if (!a.noise && sx[i] == -INFINITY) continue;
-      const float p = expf(sx[i] - m2) / s2;
-      float q;
-      if (a.noise) {
-        q = a.noise[(size_t)row * a.noise_ld + i];
-      } else {
-        uint32_t r[4];
-        philox4x32_10((uint32_t)i, (uint32_t)row, (uint32_t)a.cb, (uint32_t)f, (uint32_t)a.seed,
-                      (uint32_t)(a.seed >> 32), r);
-        const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        q = -logf(u);
+    if (tid < 64) {
+      // log_softmax then softmax over the survivors (two normalisations, like the reference), then the race
+      float mx = -INFINITY;
+      for (int j = tid; j < ns; j += 64) mx = fmaxf(mx, cv[j]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int j = tid; j < ns; j += 64) se += expf(cv[j] - mx);
+      const float lse = logf(wave_sum(se));
+      float m2 = -INFINITY;
+      for (int j = tid; j < ns; j += 64) {
+        const float lp = (cv[j] - mx) - lse;
+        cv[j] = lp;
+        m2 = fmaxf(m2, lp);
       }
-      const float v = p / q;
-      if (v > bv) { bv = v; bi = i; }
+      m2 = wave_max(m2);
+      float s2 = 0.f;
+      for (int j = tid; j < ns; j += 64) s2 += expf(cv[j] - m2);
+      s2 = wave_sum(s2);
+      for (int j = tid; j < ns; j += 64) {
+        const int i = ci[j];
+        const float p = expf(cv[j] - m2) / s2;
+        float q;
+        if (a.noise) {
+          q = a.noise[(size_t)row * a.noise_ld + i];
+        } else {
+          uint32_t r[4];
+          philox4x32_10((uint32_t)i, (uint32_t)row, (uint32_t)a.cb, (uint32_t)f, (uint32_t)a.seed,
+                        (uint32_t)(a.seed >> 32), r);
+          const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          q = -logf(u);
+        }
+        const float v = p / q;
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+      }
     }
     choice = block_argmax(bv, bi, s_val, s_idx);
   }
