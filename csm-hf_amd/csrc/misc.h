@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     // ---- k-th largest value by 4 passes of 8-bit radix select on the monotone key ---------------
     uint32_t prefix = 0, pmask = 0;
     int krem = a.topk < V ? a.topk : V;
-    for (int pass = 3; pass >= 0; --pass) {
-      hist[tid] = 0;
-      __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {   // three barriers per pass: every thread re-zeroes its own bin after reading it
       for (int i0 = 0; i0 < V; i0 += 256) {
         const int i = i0 + tid;
         const uint32_t k = i < V ? f32_key(sx[i]) : 0u;
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         // (a single thread walking the bins cost up to 255 dependent LDS reads per pass)
         const int lane = tid & 63, wv = tid >> 6;
         const int h = (int)hist[tid];
+        hist[tid] = 0;  // for the next pass (its atomics start two barriers from here)
         int incl = h;   // sum over this wave's bins with index >= own
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -353,7 +354,6 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       prefix |= s_sel[0] << (pass * 8);
       pmask |= 255u << (pass * 8);
       krem = (int)s_sel[1];
-      __syncthreads();
     }
     const uint32_t kth_key = prefix;  // key of the k-th largest value
     // ---- survivors (>= k-th value; ties included, like the reference's `x < kth` mask) compacted in index order:
