@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ unsigned hist[256];
-  __shared__ unsigned s_sel[2];
+  __shared__ unsigned s_sel[4];
   __shared__ int s_wsum[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const int V = a.V;
@@ -302,12 +302,78 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   } else {
     for (int i = tid; i < V; i += 256) sx[i] = lg[i] / a.temperature;
     __syncthreads();
-    // ---- k-th largest value by 4 passes of 8-bit radix select on the monotone key ---------------
+    // ---- k-th largest value.  Fast path: ONE 256-bin histogram over the value range [min, max] (monotone linear
+    // bins: logits spread evenly, so no LDS-atomic pile-up like on an exponent byte), a parallel suffix scan to the bin
+    // that holds the k-th largest, then the exact value by rank counting among that bin's few entries in one wave.
+    // Fallback (degenerate range, > 256 entries in the bin): 4 passes of 8-bit radix select on the monotone key.
+    const int ktop = a.topk < V ? a.topk : V;
+    uint32_t kth_fast = 0;
+    bool fast = false;
+    {
+      float mxv = -INFINITY, mnv = INFINITY;
+      for (int i = tid; i < V; i += 256) { const float v = sx[i]; mxv = fmaxf(mxv, v); mnv = fminf(mnv, v); }
+      mxv = block_max(mxv, s_val);
+      mnv = -block_max(-mnv, s_val);
+      const float bs = 255.99f / (mxv - mnv);
+      if (mxv > mnv && bs < INFINITY) {   // block-uniform
+        float* cand = sx + V;
+        hist[tid] = 0;
+        if (tid == 0) s_sel[2] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 256) atomicAdd(&hist[min(255, (int)((sx[i] - mnv) * bs))], 1u);
+        __syncthreads();
+        {
+          const int lane = tid & 63, wv = tid >> 6;
+          const int h = (int)hist[tid];
+          int incl = h;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += v;
+          }
+          if (lane == 0) s_wsum[wv] = incl;
+          __syncthreads();
+          int above = incl - h;
+          for (int w = wv + 1; w < 4; ++w) above += s_wsum[w];
+          if (above < ktop && above + h >= ktop) {
+            s_sel[0] = (unsigned)tid;
+            s_sel[1] = (unsigned)(ktop - above);
+          }
+        }
+        __syncthreads();
+        const int bsel = (int)s_sel[0], kin = (int)s_sel[1];
+        for (int i = tid; i < V; i += 256) {
+          const float v = sx[i];
+          if (min(255, (int)((v - mnv) * bs)) == bsel) cand[atomicAdd(&s_sel[2], 1u)] = v;   // order is irrelevant: only a VALUE is derived
+        }
+        __syncthreads();
+        const int nb = (int)s_sel[2];
+        if (nb <= 256) {
+          if (tid < 64) {
+            for (int j = tid; j < nb; j += 64) {
+              const float vj = cand[j];
+              int gt = 0, ge = 0;
+              for (int i = 0; i < nb; ++i) {
+                const float vi = cand[i];
+                gt += vi > vj;
+                ge += vi >= vj;
+              }
+              if (gt < kin && kin <= ge) s_sel[3] = f32_key(vj);   // every lane that hits writes the same key
+            }
+          }
+          __syncthreads();
+          kth_fast = s_sel[3];
+          fast = true;
+        }
+      }
+    }
     uint32_t prefix = 0, pmask = 0;
-    int krem = a.topk < V ? a.topk : V;
-    hist[tid] = 0;
-    __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {   // three barriers per pass: every thread re-zeroes its own bin after reading it
+    int krem = ktop;
+    if (!fast) {
+      hist[tid] = 0;
+      __syncthreads();
+    }
+    for (int pass = fast ? -1 : 3; pass >= 0; --pass) {   // three barriers per pass: every thread re-zeroes its own bin after reading it
       for (int i0 = 0; i0 < V; i0 += 256) {
         const int i = i0 + tid;
         const uint32_t k = i < V ? f32_key(sx[i]) : 0u;
@@ -355,7 +421,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       pmask |= 255u << (pass * 8);
       krem = (int)s_sel[1];
     }
-    const uint32_t kth_key = prefix;  // key of the k-th largest value
+    const uint32_t kth_key = fast ? kth_fast : prefix;  // key of the k-th largest value
     // ---- survivors (>= k-th value; ties included, like the reference's `x < kth` mask) compacted in index order:
     // every thread owns a contiguous chunk, one block-wide exclusive scan of the per-thread counts, then wave 0
     // finishes alone -- the two normalisations and the race touch ~k entries, not V, and need no more barriers.

@@ -170,6 +170,19 @@ def test_sampler_topk_edges_and_distribution(tiny):
         if k == 1:
             want = logits.argmax(-1)
         assert torch.equal(eng.k_sample(logits, k, 0.9, noise=noise).cpu().long(), want.long()), k
+    # degenerate value distributions (the fallback paths of the k-th value search): a constant row, a row whose
+    # top 600 entries are exactly tied (more than one histogram bin can resolve), a two-valued row, huge outliers
+    deg = rnd("lgd", 5, V, scale=2.0)
+    deg[0] = 1.25
+    deg[1, torch.randperm(V, generator=torch.Generator().manual_seed(3))[:600]] = 7.0
+    deg[2] = torch.where(torch.arange(V) % 3 == 0, torch.tensor(2.0), torch.tensor(-2.0))
+    deg[3, 5] = 1e30
+    deg[3, 77] = -1e30
+    deg[4, :300] = deg[4, 300]          # 301 equal entries somewhere in the middle of the range
+    noise5 = torch.empty(5, V).exponential_(1, generator=torch.Generator().manual_seed(2))
+    for k in (2, 50, 300, 700):
+        want = O.sample_topk(deg, k, 0.9, noise5).squeeze(-1)
+        assert torch.equal(eng.k_sample(deg, k, 0.9, noise=noise5).cpu().long(), want.long()), k
     with pytest.raises(RuntimeError):
         eng.k_sample(logits, V + 1, 1.0)
     # device Philox race: empirical distribution ~ softmax over the top-k survivors
