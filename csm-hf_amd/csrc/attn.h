@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
       if (lane < Tile::LPR) {
         const f32x4 o = acc * inv;
         *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.n_q * HD + (size_t)h * HD + 4 * lane) = o;
-        if (a.oplanes) store_planes4(a.oplanes, (size_t)a.n_q * HD * 16, h * HD + 4 * lane, row, o);
+        if (a.oplanes) {   // rows 16..31: second plane group
+          const size_t ps = (size_t)a.n_q * HD * 16;
+          store_planes4(a.oplanes + (size_t)(row >> 4) * 3 * ps, ps, h * HD + 4 * lane, row & 15, o);
+        }
       }
     } else {
       float* pp = a.part + (((size_t)row * a.n_q + h) * a.nsplit + sp) * (HD + 4);
@@ -127,7 +130,11 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int
 #pragma unroll
     for (int s = 0; s < 64; ++s) num = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), s)), pv[i][s], num);
     out[(size_t)rh * HD + lane + 64 * i] = num * inv;
-    if (oplanes) store_planes(oplanes, (size_t)n_q * HD * 16, (rh % n_q) * HD + lane + 64 * i, rh / n_q, num * inv);
+    if (oplanes) {
+      const size_t ps = (size_t)n_q * HD * 16;
+      const int row = rh / n_q;
+      store_planes(oplanes + (size_t)(row >> 4) * 3 * ps, ps, (rh % n_q) * HD + lane + 64 * i, row & 15, num * inv);
+    }
   }
 }
 

@@ -23,6 +23,7 @@
 #include "attn_prefill.h"
 #include "gemm.h"
 #include "gemm16.h"
+#include "gemm32.h"
 #include "gemv.h"
 #include "misc.h"
 
@@ -152,6 +153,7 @@ struct csm_engine {
 };
 
 static void drop_tiled(csm_engine* e);
+constexpr int PL_GROUPS = 4;     // plane groups of 16 rows: batches up to 64 rows run on activation planes
 constexpr int PL_SS_LD = 512;   // partial-sum columns per row: hidden / 16 tiles, hidden <= 8192
 static inline int emb_dtype(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? CSM_DTYPE_BF16 : e->cfg.weight_dtype; }
 static inline size_t w_esz(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? 1 : (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4); }
@@ -249,10 +251,11 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
   {
     const size_t Hm = std::max(cfg->backbone.hidden, cfg->decoder.hidden), Fm = std::max(cfg->backbone.ffn, cfg->decoder.ffn);
-    if ((r = dalloc(e, &e->pl_h, 3 * 16 * Hm)) || (r = dalloc(e, &e->pl_act, 3 * 16 * Fm)) || (r = dalloc(e, &e->pl_ss, (size_t)16 * PL_SS_LD))) return r;
-    HIPCK(hipMemsetAsync(e->pl_h, 0, 3 * 16 * Hm * sizeof(bf16_t), e->stream));
-    HIPCK(hipMemsetAsync(e->pl_act, 0, 3 * 16 * Fm * sizeof(bf16_t), e->stream));
-    HIPCK(hipMemsetAsync(e->pl_ss, 0, (size_t)16 * PL_SS_LD * sizeof(float), e->stream));
+    const size_t G = PL_GROUPS;
+    if ((r = dalloc(e, &e->pl_h, G * 3 * 16 * Hm)) || (r = dalloc(e, &e->pl_act, G * 3 * 16 * Fm)) || (r = dalloc(e, &e->pl_ss, G * 16 * PL_SS_LD))) return r;
+    HIPCK(hipMemsetAsync(e->pl_h, 0, G * 3 * 16 * Hm * sizeof(bf16_t), e->stream));
+    HIPCK(hipMemsetAsync(e->pl_act, 0, G * 3 * 16 * Fm * sizeof(bf16_t), e->stream));
+    HIPCK(hipMemsetAsync(e->pl_ss, 0, G * 16 * PL_SS_LD * sizeof(float), e->stream));
   }
   e->g16_slab_floats = (size_t)1 << 20;
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
@@ -407,6 +410,11 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
   const int* rp = a.row_pos;
   int* ba = a.bump_a;
   int* bbp = a.bump_b;
+  const bf16_t* xpl = a.xplanes;
+  const float* xss = a.xss;
+  bf16_t* opl = a.oplanes;
+  float* oss = a.oss;
+  const size_t opl_group = (size_t)3 * 16 * (epi == EPI_SWIGLU ? a.N / 2 : a.N);   // plane group of 16 rows
   // rows are processed in groups: up to 16 on the matrix-core kernel (bf16 / fp8 weights, eligible shapes),
   // otherwise up to 4 on the fp32-FMA kernels; every group re-streams the weights
   int m0 = 0;
@@ -422,12 +430,27 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       const bool last = m0 + m >= M;
       a.bump_a = last ? ba : nullptr;
       a.bump_b = last ? bbp : nullptr;
+      a.xplanes = xpl ? xpl + (size_t)(m0 / 16) * 3 * 16 * a.K : nullptr;
+      a.xss = xss ? xss + (size_t)m0 * a.xss_ld : nullptr;
+      a.oplanes = opl ? opl + (size_t)(m0 / 16) * opl_group : nullptr;
+      a.oss = oss ? oss + (size_t)m0 * a.oss_ld : nullptr;
     };
+    const auto tl = e->tiled.find(a.W);
+    a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
+    if (left > 16 && e->use_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes: one launch, weights streamed once
+      const int m = left < 32 ? left : 32;
+      slice(m);
+      const int r = launch_gemm32(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
+                                  e->g16_slab_floats, e->g16_tickets, 4096);
+      if (r != -2) {
+        if (r) return r;
+        m0 += m;
+        continue;
+      }
+    }
     if (left >= 2 && e->use_mfma) {
       const int m = left < 16 ? left : 16;
       slice(m);
-      const auto tl = e->tiled.find(a.W);
-      a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
       if (!a.Wt) a.xplanes = nullptr;   // unbound weights (hooks): fp32 activations
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
@@ -450,7 +473,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
 // activation planes are used when every launch of the stack runs on the matrix-core kernel with fragment-order weights
 static bool planes_on(const csm_engine* e, const Stack& s, int M) {
   const int H = s.c.hidden, F = s.c.ffn, A = s.c.n_q * s.c.head_dim;
-  return e->use_planes && e->use_mfma && M >= 2 && M <= 16 && !e->tiled.empty() && H % 512 == 0 && F % 512 == 0 &&
+  return e->use_planes && e->use_mfma && M >= 2 && M <= 16 * PL_GROUPS && !e->tiled.empty() && H % 512 == 0 && F % 512 == 0 &&
          A % 512 == 0 && H <= 16 * PL_SS_LD && (e->cfg.weight_dtype == CSM_DTYPE_BF16 || e->cfg.weight_dtype == CSM_DTYPE_FP8);
 }
 

@@ -1,0 +1,262 @@
+// Skinny GEMM on the matrix cores for 17..32 batched decode rows: the same launch as gemm16.h with TWO 16-row
+// batch tiles per weight fragment, so the weights of a batch of 32 utterances are streamed once, not twice.
+// Only the fast operand path exists here: fragment-order weights (tile16_kernel) and activations that arrive as
+// planes written by the producing launch (GemvArgs::xplanes; rows 16..31 live in a second plane group right
+// behind the first: group stride 3 * K * 16).  Launches without planes (layer-0 inputs) keep going through
+// gemm16_kernel in two 16-row groups.  Prologues / epilogues, the split-K ticket reduction and the per-tile
+// sums of squares are those of gemm16.h, indexed by (weight tile t, batch tile mt).
+#pragma once
+#include "gemm16.h"
+
+#ifndef CSM_ARGS_ONLY
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
+__global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
+  constexpr int MT = 2, U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][U][256] | panel[U][256] | flag[16] | stat[32]
+  float* red = lds;
+  float* panel = lds + NW * U * 256;
+  int* flag = reinterpret_cast<int*>(panel + U * 256);
+  float* stat = panel + U * 256 + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int m = lane & 15, g = lane >> 4;
+  const int chunk = (int)blockIdx.y * NW + wave;
+  constexpr bool QUAD = (EPI == EPI_RESID || EPI == EPI_SWIGLU);
+  static_assert(!QUAD || U * 64 <= 64 * NW, "one quad per thread");
+  constexpr int NE = (U * 256 + 64 * NW - 1) / (64 * NW);
+
+  // ---- EPI_QKV epilogue inputs first (dependent chain: position -> cos/sin) -------------------------------
+  float pre0[NE], pre1[NE];
+  int ppos[NE];
+  if (EPI == EPI_QKV) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      pre0[e] = pre1[e] = 0.f;
+      ppos[e] = 0;
+      const int i = tid + e * 64 * NW;
+      if (i < U * 256) {
+        const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
+        const int mm = mt * 16 + (l & 15), r = (l >> 4) * 4 + reg;
+        const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+        if (mm < M && n < a.N) {
+          ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+          const int half = a.hd >> 1, spp = half / 16;
+          const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
+          if (t == 0 && head < a.n_q + a.n_kv) {
+            pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+            pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
+          }
+        }
+      }
+    }
+  }
+  // ---- B operands: ready-made planes of both batch tiles, then the weight fragments ------------------------
+  bf16x8 xh[MT][4], xm[MT][4], xl[MT][4];
+  {
+    const size_t ps = (size_t)K * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16_t* pp = a.xplanes + (size_t)mt * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[mt][j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
+        xm[mt][j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
+        xl[mt][j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+      }
+    }
+  }
+  AFrag<WT> wf[PT][4];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const size_t tile = (size_t)(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4);
+    const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
+  }
+  // residual values (and the consumer's norm weight for the output planes): requested last, consumed last
+  f32x4 rq = (f32x4)(0.f), lq = (f32x4)(1.f);
+  if (EPI == EPI_RESID && tid < U * 64) {
+    const int u = tid >> 6, t = u / MT, mt = u - t * MT, l = tid & 63, mm = mt * 16 + (l & 15);
+    const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+    if (mm < M && n0 < a.N) {
+      rq = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
+      if (a.oplanes && a.oln) lq = *reinterpret_cast<const f32x4*>(a.oln + n0);
+    }
+  }
+  // RMS scale of the rows of batch tile mt = wave (waves 0 and 1) from the producer's per-tile sums of squares
+  if (PRO == PRO_NORM && wave < MT) {
+    const float* sp = a.xss + (size_t)(wave * 16 + m) * a.xss_ld;
+    f32x4 pv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = g * 4 + 16 * i;
+      pv[i] = (f32x4)(0.f);
+      if (t < a.xss_n) pv[i] = *reinterpret_cast<const f32x4*>(sp + t);
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += (pv[i][0] + pv[i][1]) + (pv[i][2] + pv[i][3]);
+    q = xor32_sum(xor16_sum(q));
+    if (lane < 16) stat[wave * 16 + lane] = __builtin_amdgcn_rsqf(q * __builtin_amdgcn_rcpf((float)K) + a.eps);
+  }
+  f32x4 acc[PT][MT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4)(0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const bf16x8 af = wf[t][j].get();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt][j], acc[t][mt], 0, 0, 0);  // small terms first
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt][j], acc[t][mt], 0, 0, 0);
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt][j], acc[t][mt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- K reduction across the waves through LDS, fixed order ------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      *reinterpret_cast<f32x4*>(red + ((wave * U + t * MT + mt) * 64 + lane) * 4) = acc[t][mt];
+  __syncthreads();
+  for (int i = tid; i < U * 256; i += 64 * NW) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * U * 256 + i];
+    panel[i] = s;
+  }
+  if (KB > 1) {   // split-K across workgroups: slab + ticket, last arriver combines (as in gemm16.h)
+    float* slab = slabs + ((size_t)blockIdx.x * KB + blockIdx.y) * (U * 256);
+    for (int i = tid; i < U * 256; i += 64 * NW)
+      __hip_atomic_store(slab + i, panel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = tk == KB - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const float* base = slabs + (size_t)blockIdx.x * KB * (U * 256);
+    for (int i = tid; i < U * 256; i += 64 * NW) {
+      float v[16];
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) v[kb] = kb < KB ? base[(size_t)kb * (U * 256) + i] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) s += v[kb];
+      panel[i] = s;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogues ------------------------------------------------------------------------------------------
+  if (QUAD) {
+    if (tid < U * 64) {
+      const int u = tid >> 6, t = u / MT, mt = u - t * MT, l = tid & 63, mm = mt * 16 + (l & 15);
+      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      if (mm < M && n0 < a.N) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(panel + u * 256 + l * 4);
+        const float rs = (PRO == PRO_NORM) ? stat[mm] : 1.f;
+        if (a.wscale) {
+          const f32x4 ws = *reinterpret_cast<const f32x4*>(a.wscale + n0);
+          pv[0] *= ws[0]; pv[1] *= ws[1]; pv[2] *= ws[2]; pv[3] *= ws[3];
+        }
+        pv[0] *= rs; pv[1] *= rs; pv[2] *= rs; pv[3] *= rs;
+        if (EPI == EPI_RESID) {
+          const f32x4 xn = rq + pv;
+          *reinterpret_cast<f32x4*>(a.out + (size_t)mm * a.ldo + n0) = xn;
+          if (a.oplanes) {
+            f32x4 xt;
+            xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
+            const size_t ps = (size_t)a.N * 16;
+            store_planes4(a.oplanes + (size_t)mt * 3 * ps, ps, n0, l & 15, xt);
+            if (a.oss) red[u * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
+          }
+        } else {   // SwiGLU: (gate, up) pairs
+          const float h0 = (pv[0] / (1.f + __expf(-pv[0]))) * pv[1];
+          const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
+          if (a.oplanes) {
+            const size_t ps = (size_t)(a.N >> 1) * 16;
+            store_planes2(a.oplanes + (size_t)mt * 3 * ps, ps, n0 >> 1, l & 15, h0, h1);
+          } else {
+            *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
+          }
+        }
+      }
+    }
+    if (EPI == EPI_RESID && a.oplanes && a.oss) {   // per-tile sums of x_new^2 for the consumer's RMS scale
+      __syncthreads();
+      if (tid < U * 16) {
+        const int u = tid >> 4, t = u / MT, mt = u - t * MT, mm = mt * 16 + (tid & 15);
+        const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
+        if (mm < M && n0 < a.N) {
+          const int c = tid & 15;
+          a.oss[(size_t)mm * a.oss_ld + (n0 >> 4)] = (red[u * 64 + c] + red[u * 64 + 16 + c]) + (red[u * 64 + 32 + c] + red[u * 64 + 48 + c]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * 64 * NW;
+      if (i >= U * 256) continue;
+      const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
+      const int mm = mt * 16 + (l & 15), r = (l >> 4) * 4 + reg;
+      if (mm >= M) continue;
+      const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+      if (n >= a.N) continue;
+      const float rs = (PRO == PRO_NORM) ? stat[mm] : 1.f;
+      const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f) * rs;
+      if (EPI == EPI_STORE) {
+        a.out[(size_t)mm * a.ldo + n] = v;
+      } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
+        const int half = a.hd >> 1, spp = half / 16;
+        const int head = blockIdx.x / spp, s = blockIdx.x - head * spp;
+        const int hi = s * 16 + r;
+        const int b = a.row_seq ? a.row_seq[mm] : a.seq_base + mm;
+        const int pos = ppos[e];
+        KT* kc = reinterpret_cast<KT*>(a.kcache);
+        KT* vc = reinterpret_cast<KT*>(a.vcache);
+        if (head < a.n_q + a.n_kv) {
+          if (t == 0) {
+            const float v0 = v, v1 = panel[(MT + mt) * 256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f) * rs;
+            const float c = pre0[e], sn = pre1[e];
+            const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
+            if (head < a.n_q) {
+              float* q = a.qbuf + (size_t)mm * a.n_q * a.hd + head * a.hd;
+              q[hi] = o0 * a.qscale;
+              q[hi + half] = o1 * a.qscale;
+            } else {
+              const int j = head - a.n_q;
+              store_kv(kc + k_index<KT>(b, j, hi, pos, a.n_kv, a.hd, a.lmax), o0);
+              store_kv(kc + k_index<KT>(b, j, hi + half, pos, a.n_kv, a.hd, a.lmax), o1);
+            }
+          }
+        } else {
+          const int j = head - a.n_q - a.n_kv;
+          store_kv(vc + v_index(b, j, pos, t * half + hi, a.n_kv, a.hd, a.lmax), v);
+        }
+      }
+    }
+  }
+  if (a.bump_a && blockIdx.x == 0 && tid == 0) {
+    *a.bump_a += 1;
+    if (a.bump_b) *a.bump_b += 1;
+  }
+}
+#endif  // CSM_ARGS_ONLY
+
+// 17..32 rows; needs a.xplanes and a.Wt; returns -2 when the shape is not covered
+int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                  size_t slab_floats, int* tickets, int n_tickets);

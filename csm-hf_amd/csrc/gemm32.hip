@@ -1,0 +1,62 @@
+// Instantiations + launcher of the 32-row MFMA skinny GEMM (gemm32.h).
+#include "gemm32.h"
+
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
+static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
+                      int n_tickets) {
+  constexpr int U = PT * 2;
+  int gx;
+  if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
+  else gx = ((a.N + 15) / 16 + PT - 1) / PT;
+  if (KB > 1 && ((size_t)gx * KB * U * 256 > slab_floats || gx > n_tickets)) return -2;
+  const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 32) * sizeof(float);
+  auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT>;
+  hipLaunchKernelGGL(fn, dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  return (int)hipGetLastError();
+}
+
+template <typename WT, typename KT, int PRO, int EPI, int PT>
+static int launch_nw32(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
+  if (nw == 16) return launch_g32<WT, KT, PRO, EPI, 16, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  if (nw == 8) return launch_g32<WT, KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
+  return -2;
+}
+
+template <typename WT>
+static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                           size_t slab_floats, int* tickets, int n_tickets) {
+  if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
+  if (a.K % 1024 != 0) return -2;                          // 8 or 16 waves, one 128-wide chunk each
+  if ((epi == EPI_RESID || epi == EPI_SWIGLU) && (a.N % 16 != 0 || a.ldo % 4 != 0)) return -2;
+  const int nchunks = a.K / 128;
+  int nw = nchunks >= 16 ? 16 : 8, KB = 1;
+  if (nchunks > 16) {   // K = 8192: 8 waves x 8 workgroup-level splits, as in gemm16
+    if (pro == PRO_NORM) return -2;
+    nw = 8;
+    KB = nchunks / 8;
+    if (KB > 16 || nchunks % 8) return -2;
+  }
+  if (nchunks % nw) return -2;
+  if (epi == EPI_QKV) {
+    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || KB != 1) return -2;
+    if (kvdtype == 1) return launch_nw32<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    return launch_nw32<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  }
+  // panels: gate/up 32 rows (as on planes at M <= 16), the residual launches 16 rows (64 when that leaves >= 128
+  // workgroups per K split), the heads 16 rows
+  const int ntiles = (a.N + 15) / 16;
+  if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_nw32<WT, float, PRO_NORM, EPI_SWIGLU, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  if (pro == PRO_PLAIN && epi == EPI_RESID) {
+    if (KB > 1 && ntiles >= 128) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  }
+  if (pro == PRO_NORM && epi == EPI_STORE) return launch_nw32<WT, float, PRO_NORM, EPI_STORE, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  return -2;
+}
+
+int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
+                  size_t slab_floats, int* tickets, int n_tickets) {
+  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 32 || !a.xplanes || !a.Wt || a.configure_only) return -2;
+  if (wdtype == 2) return launch_gemm32_t<fp8_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
+  return launch_gemm32_t<bf16_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
+}

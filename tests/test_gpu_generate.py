@@ -337,10 +337,11 @@ def test_csm1b_batch16_rows_equal_solo_and_graph_equals_eager(csm1b_bf16):
     assert min(agree) >= 32 * 2 and sum(a == 32 * 6 for a in agree) >= 2, agree
 
 
-@pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
+@pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (32, {}), (40, {}), (70, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
 def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
-    """ragged batches (M < 16 on the matrix-core kernel; 16 + 2 rows = two groups, the second on the fp32-FMA
-    kernels, activation planes off) and the A/B paths (no activation planes; row-major weights) against solo runs"""
+    """ragged batches (M < 16 on the matrix-core kernel; 18 and 32 rows = one launch of the 32-row kernel on planes,
+    two 16-row groups where the input is fp32; 40 rows = 32 + 8; 70 rows = 16-row groups without planes) and the A/B paths (no
+    activation planes; row-major weights) against solo runs"""
     m = csm1b_bf16
     cfg = m.config
     ids, mask = synth_context(cfg, B, 12, 20, seed=43)
@@ -355,7 +356,7 @@ def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
             for k in opts:
                 m._engine.set_option(k, {"use_planes": 15, "tile_weights": 1}[k])
     agree = []
-    for b in (0, B - 1):
+    for b in sorted({0, min(17, B - 1), B - 1}):
         solo = m.generate(ids[b:b + 1].to(DEV), mask[b:b + 1].to(DEV), max_new_frames=4, topk=1, stop_on_all_zeros=False).cpu()
         same = (solo[0] == full[b]).reshape(-1)
         agree.append(int((~same).nonzero()[0]) if not bool(same.all()) else same.numel())
