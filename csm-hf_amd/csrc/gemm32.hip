@@ -17,7 +17,6 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
 
 template <typename WT, typename KT, int PRO, int EPI, int PT>
 static int launch_nw32(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
-  if (nw == 16) return launch_g32<WT, KT, PRO, EPI, 16, PT>(st, M, KB, a, slabs, sf, tk, nt);
   if (nw == 8) return launch_g32<WT, KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
   return -2;
 }
@@ -28,17 +27,14 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
   if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
   if (a.K % 1024 != 0) return -2;                          // 8 or 16 waves, one 128-wide chunk each
   if ((epi == EPI_RESID || epi == EPI_SWIGLU) && (a.N % 16 != 0 || a.ldo % 4 != 0)) return -2;
+  // 8 waves per workgroup always (two batch tiles need ~170 VGPRs: a 16-wave workgroup would spill), one 128-wide
+  // chunk per wave, the rest of K split across workgroups -- allowed for the normed launches too, because on planes the
+  // RMS scale is applied by the (last-arriver) epilogue
   const int nchunks = a.K / 128;
-  int nw = nchunks >= 16 ? 16 : 8, KB = 1;
-  if (nchunks > 16) {   // K = 8192: 8 waves x 8 workgroup-level splits, as in gemm16
-    if (pro == PRO_NORM) return -2;
-    nw = 8;
-    KB = nchunks / 8;
-    if (KB > 16 || nchunks % 8) return -2;
-  }
-  if (nchunks % nw) return -2;
+  const int nw = 8, KB = nchunks / 8;
+  if (nchunks % 8 || KB > 16) return -2;
   if (epi == EPI_QKV) {
-    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || KB != 1) return -2;
+    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128)) return -2;
     if (kvdtype == 1) return launch_nw32<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
     return launch_nw32<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
