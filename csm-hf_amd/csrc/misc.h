@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_sel[4];
   __shared__ int s_wsum[4];
+  __shared__ float s_mn[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const int V = a.V;
   const float* lg = a.logits + (size_t)row * a.ldl;
@@ -312,8 +313,15 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     {
       float mxv = -INFINITY, mnv = INFINITY;
       for (int i = tid; i < V; i += 256) { const float v = sx[i]; mxv = fmaxf(mxv, v); mnv = fminf(mnv, v); }
-      mxv = block_max(mxv, s_val);
-      mnv = -block_max(-mnv, s_val);
+      {   // max and min in one exchange (two barriers instead of four)
+        mxv = wave_max(mxv);
+        mnv = -wave_max(-mnv);
+        __syncthreads();
+        if ((tid & 63) == 0) { s_val[tid >> 6] = mxv; s_mn[tid >> 6] = mnv; }
+        __syncthreads();
+        mxv = fmaxf(fmaxf(s_val[0], s_val[1]), fmaxf(s_val[2], s_val[3]));
+        mnv = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+      }
       const float bs = 255.99f / (mxv - mnv);
       if (mxv > mnv && bs < INFINITY) {   // block-uniform
         float* cand = sx + V;
