@@ -125,7 +125,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  * kernel; 0 frees them), "attn_one_wave" (bit 0 decoder / bit 1 backbone attention as one-wave workgroups),
  * "use_planes" (bit mask: batched activations handed over as MFMA B-operand planes -- 1 residual stream, 2 SwiGLU
  * output, 4 attention output, 8 sampler feedback row), "fuse_sample" (greedy arg-max folded into the head launch),
- * "fuse_decoder_attention", "flash_prefill" */
+ * "fuse_decoder_attention", "flash_prefill", "prefill_planes" (prefill activations handed to the GEMMs as bf16 planes),
+ * "g16_gu" / "g16_down" (panel-shape overrides of the batched gate/up and down_proj launches) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
