@@ -105,14 +105,110 @@ def cpu_baseline(cfg, model, ids, mask, frames: int, gpu_tokens, budget_s: float
             toks.append(out.samples)
             done += 1
         dt_s = time.perf_counter() - t0
-    rec = dict(value=round(done * ids.shape[0] / dt_s, 3), unit="frames/s", cores=best_nt, kind="port", arith="f32",
+    rec = dict(value=round(done * ids.shape[0] / dt_s, 3), unit="frames/s", cores=best_nt, threads_used=best_nt,
+               host_cores=ncpu, host_cpu_model=_cpu_model(), kind="port", arith="f32",
                sample=f"csm-1b, same {ids.shape[1]}-frame context, {done} decode frames after prefill "
                       f"(prefill {t_prefill:.2f}s excluded), B={ids.shape[0]}, greedy; thread-count probe "
                       + ", ".join(f"{k}t:{1 / v:.2f}fps" for k, v in probe.items()))
     if gpu_tokens is not None:
         n = min(len(toks), gpu_tokens.shape[1])
         rec["first_frames_equal_gpu"] = bool(torch.equal(torch.stack(toks[:n], 1), gpu_tokens[:, :n].cpu()))
+    # the reference's own dtype for this configuration is bf16 (README.md:73): the same oracle in bf16 arithmetic,
+    # same thread count, bounded to a third of the budget (its greedy stream is not comparable token for token:
+    # bf16 logits tie and the reference breaks ties with the RNG)
+    try:
+        sdb = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+        with torch.inference_mode():
+            out = O.generate_frame(sdb, cfg, ids, mask, 1.0, 1, None, True)
+            cache, prev = out.cache, out.samples
+            t0 = time.perf_counter()
+            done_b = 0
+            while done_b < frames and time.perf_counter() - t0 < budget_s / 3:
+                row = torch.cat([prev, torch.zeros(ids.shape[0], 1, dtype=torch.long)], 1).unsqueeze(1)
+                m1 = torch.zeros(ids.shape[0], 1, C + 1, dtype=mask.dtype)
+                m1[:, :, :C] = 1
+                out = O.generate_frame(sdb, cfg, row, m1, 1.0, 1, cache, True)
+                cache, prev = out.cache, out.samples
+                done_b += 1
+            rec["bf16"] = dict(value=round(done_b * ids.shape[0] / (time.perf_counter() - t0), 3), unit="frames/s",
+                               threads_used=best_nt, frames=done_b)
+    except Exception as ex:   # the bf16 leg is informative; never let it break the bench line
+        rec["bf16"] = {"error": str(ex)[:200]}
     return rec
+
+
+def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
+    """BASELINE configs[3]: a [rows, ctx, 33] batch of utterances sharded over the ranks through `generate_sharded`
+    (the real engine on every rank, RCCL only gathers the finished frames), greedy, stop disabled.  Two legs:
+    weak = 16 rows per GPU (16 x world rows in total), strong = 128 rows in total.  Times the whole call (prefill +
+    decode + gather, max over ranks) and, separately, the decode frame-steps from the engine's HIP events."""
+    from csm_hf_amd.sharded import generate_sharded, shard_rows
+    out = {}
+    for leg, rows in (("weak", 16 * world), ("strong", 128)):
+        ids, mask = synth_context(cfg, rows, ctx // 4, ctx - ctx // 4, seed=4)
+        ids, mask = ids.to(dev), mask.to(dev)
+        a0, a1 = shard_rows(rows, rank, world)
+        walls = []
+        for it in range(2):          # first pass sizes the engine and captures the graph (untimed)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks = generate_sharded(model, ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
+                                    stop_on_all_zeros=False)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            walls.append(time.perf_counter() - t0)
+        dec_ms = model._engine.last_generate_ms()
+        tm = torch.tensor([walls[-1], dec_ms / 1e3], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        assert toks.shape == (rows, frames, cfg.audio_num_codebooks), toks.shape
+        passes = max(1, -(-(a1 - a0) // 64))
+        out[leg] = {"rows_total": rows, "rows_per_gpu": a1 - a0, "frames": frames,
+                    "frames_per_s_end_to_end": round(rows * frames / float(tm[0]), 1),
+                    "frames_per_s_decode_only": round(rows * frames / (float(tm[1]) * passes), 1),
+                    "wall_s": round(float(tm[0]), 4), "decode_ms_last_pass": round(float(tm[1]) * 1e3, 2),
+                    "engine_passes_per_gpu": passes,
+                    "tokens_checksum": int(toks.to(torch.int64).sum().item())}
+    return out
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run with one rank per
+    GPU.  Fails loudly (non-zero) when the box has fewer than N devices -- never reports a 1-GPU run as N."""
+    import subprocess
+    one_dev = os.environ.get("CSM_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not (one_dev and have >= 1):
+        print(f"[bench] --gpus {n} requested but only {have} GPU(s) visible", file=sys.stderr, flush=True)
+        return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -131,12 +227,20 @@ def main():
     ap.add_argument("--lean", action="store_true", help="profiling runs: no cpu_baseline leg and no dominant-kernel chain "
                     "(its launches would be counted with the step's own kernels)")
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--config4", type=int, default=-1, help="1/0: also run the BASELINE configs[3] sub-record (batch of "
+                    "utterances through generate_sharded, 16 rows/GPU weak + 128 rows strong); default: on when --gpus > 1")
+    ap.add_argument("--config4-frames", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"[bench] --gpus {a.gpus} does not match WORLD_SIZE {world}", file=sys.stderr, flush=True)
+        sys.exit(3)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -208,15 +312,21 @@ def main():
     wall_max, hip_max = float(tm[0]), float(tm[1])
 
     toks = eng.read_frames(0, W + K)
+    all_toks = toks
     if dist is not None:      # the only RCCL traffic: gather finished frames, off the timed path
         gathered = [torch.empty_like(toks) for _ in range(world)]
         dist.all_gather(gathered, toks)
         all_toks = torch.cat(gathered, 0)
         assert all_toks.shape == (world * B, W + K, cfg.audio_num_codebooks)
+    # position-weighted checksum of every rank's frames (tests compare it with solo runs of the same rows)
+    wgt = torch.arange(1, B * (W + K) * cfg.audio_num_codebooks + 1, device=dev, dtype=torch.int64).reshape(B, W + K, -1)
+    checks = [int((all_toks[r * B:(r + 1) * B] * wgt).sum()) for r in range(world)]
 
     if rank == 0:
         L_mean = a.ctx + W + (K - 1) / 2.0 + 1          # positions read by the backbone step of timed frame i
-        by = bytes_step(cfg, B, L_mean, wbytes=1 if a.weights == "fp8" else 2)
+        kvb = 4 if a.kv_dtype == "f32" else 2
+        by = bytes_step(cfg, B, L_mean, wbytes=1 if a.weights == "fp8" else 2, kvbytes=kvb)   # KV priced at its stored width
+        by_survey = bytes_step(cfg, B, L_mean, wbytes=1 if a.weights == "fp8" else 2, kvbytes=2)
         step_s = hip_max / K
         achieved = by / step_s / 1e9
         out = {
@@ -232,13 +342,15 @@ def main():
                                    f"{K} timed frame-steps after {W} warm-up, topk={a.topk} T={a.temperature}, "
                                    f"hipGraph={'on' if use_graph else 'off'}",
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
+            "tokens_checksum_per_rank": checks,
             "prefill_ms": round(prefill_ms, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
             "setup_s": round(t_setup, 1),
             "roofline": {"bound": "hbm", "kernel": "frame-step hipGraph (decoder loop + backbone step)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
-                         "algorithmic_bytes_per_step": int(by), "traffic": None},
+                         "algorithmic_bytes_per_step": int(by), "algorithmic_bytes_per_step_bf16_kv": int(by_survey),
+                         "traffic": None},
         }
         # the dominant kernel of the step by time: the decoder gate/up GEMV (128 launches per step, 33.55 MB each).
         # Its launch time is measured here with HIP events on the engine stream as a dependent chain of 200
@@ -254,14 +366,15 @@ def main():
                     "share_of_step_time": round(128 * us / (step_s * 1e6), 3)}
             except Exception as ex:      # never let the side measurement break the bench line
                 out["roofline"]["dominant_kernel"] = {"error": str(ex)[:200]}
-        # static PMC measurement of the same command, if one was committed for this configuration
+        # `traffic` stays null: PMC counters cannot be read inside this process.  The separately collected rocprofv3
+        # --pmc measurement of this same command (tools/collect_pmc.sh) is quoted as `traffic_static`, labelled as such.
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("batch") == B and rec.get("ctx") == a.ctx and a.weights == "bf16":
-                    out["roofline"]["traffic"] = rec["hbm_bytes_per_step"]
-                    out["roofline"]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, see DESIGN.md)"
+                    out["roofline"]["traffic_static"] = {"hbm_bytes_per_step": rec["hbm_bytes_per_step"],
+                                                         "source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc run of this command)"}
             except Exception:
                 pass
         # parity of the benchmarked run against the reference's golden vectors (same context at rank 0, B=1)
@@ -280,6 +393,15 @@ def main():
                              "equal_all": bool((mine == ref).all())}
         if world == 1 and not a.no_cpu_baseline and not a.lean:
             out["cpu_baseline"] = cpu_baseline(cfg, model, ids, mask, a.cpu_frames, toks)
+    # BASELINE configs[3] (batch of utterances sharded over the GPUs): every rank takes part
+    want4 = a.config4 == 1 or (a.config4 < 0 and world > 1)
+    c4 = None
+    if want4 and not a.lean and a.weights == "bf16":
+        del eng
+        c4 = run_config4(model, cfg, rank, world, dist, dev, a.ctx, a.config4_frames)
+    if rank == 0:
+        if c4 is not None:
+            out["config4"] = c4
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -35,6 +35,8 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
 int launch_set_int(hipStream_t st, int* p, int v);
+int launch_set_rng(hipStream_t st, uint64_t* p, uint64_t seed, uint64_t row_offset);
+int configure_sample();
 int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz);
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
@@ -71,13 +73,19 @@ struct Stack {
   int nqkv() const { return (c.n_q + 2 * c.n_kv) * c.head_dim; }
 };
 
+// What a captured frame-step depends on.  The sampling seed and the shard's row offset are NOT here: they live in
+// device memory (d_rng) and are rewritten before every launch, like the frame index and the backbone length.
 struct GraphKey {
   int B, topk, nsplit;
   float temperature;
-  uint64_t seed;
   const void *noise, *forced, *ltrace, *htrace;
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
+struct GraphEntry {
+  hipGraphExec_t exec;
+  uint64_t last_use;
+};
+constexpr size_t MAX_GRAPHS = 8;   // LRU bound on cached frame-step graphs
 
 struct csm_engine {
   csm_config_t cfg{};
@@ -92,6 +100,7 @@ struct csm_engine {
   int* d_len = nullptr;
   int* d_frame = nullptr;
   int* d_kv_start = nullptr;
+  uint64_t* d_rng = nullptr;   // {seed, global index of row 0}: read by the sampler, written before every launch
   int64_t* ring = nullptr;
   // decode scratch
   float *q_bb = nullptr, *att_bb = nullptr, *part_bb = nullptr, *act_bb = nullptr, *h_bb = nullptr;
@@ -134,7 +143,9 @@ struct csm_engine {
     while (p < ns && p < 64) p *= 2;
     return p;
   }
-  std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, GraphEntry> graphs;
+  uint64_t graph_tick = 0;
+  int graphs_captured = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::vector<void*> allocs;
@@ -189,6 +200,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   if (cfg->n_codebooks < 2) return fail(CSM_ERR_ARG, "n_codebooks must be >= 2");
   HIPCK(hipSetDevice(device));
   LCK(gemv_configure_all());
+  LCK(configure_sample());
   csm_engine* e = new csm_engine();
   e->cfg = *cfg;
   e->device = device;
@@ -221,8 +233,10 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       s->vc.push_back(v);
     }
   }
-  if ((r = dalloc(e, &e->d_len, 1)) || (r = dalloc(e, &e->d_frame, 1)) || (r = dalloc(e, &e->d_kv_start, (size_t)B)))
+  if ((r = dalloc(e, &e->d_len, 1)) || (r = dalloc(e, &e->d_frame, 1)) || (r = dalloc(e, &e->d_kv_start, (size_t)B)) ||
+      (r = dalloc(e, &e->d_rng, 2)))
     return r;
+  HIPCK(hipMemsetAsync(e->d_rng, 0, 2 * sizeof(uint64_t), e->stream));
   if ((r = dalloc(e, &e->ring, (size_t)B * cfg->max_frames * C))) return r;
   HIPCK(hipMemsetAsync(e->ring, 0, (size_t)B * cfg->max_frames * C * sizeof(int64_t), e->stream));
   HIPCK(hipMemsetAsync(e->d_kv_start, 0, B * sizeof(int), e->stream));
@@ -268,7 +282,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
 }
 
 static void drop_graphs(csm_engine* e) {
-  for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second.exec);
   e->graphs.clear();
 }
 
@@ -600,7 +614,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
   const int B = e->B, C = e->cfg.n_codebooks, V = e->cfg.audio_vocab, Hd = e->cfg.decoder.hidden;
   auto sample = [&](int cb, const float* logits, int ldl) -> int {
     SampleArgs a{};
-    a.logits = logits; a.ldl = ldl; a.V = V; a.temperature = s->temperature; a.topk = s->topk; a.seed = s->seed;
+    a.logits = logits; a.ldl = ldl; a.V = V; a.temperature = s->temperature; a.topk = s->topk; a.rng = e->d_rng;
     if (s->noise) {
       a.noise = s->noise + (size_t)cb * V;
       a.noise_ld = (size_t)C * V;
@@ -671,6 +685,7 @@ static int check_ready(csm_engine* e, const csm_sampling_t* s) {
 extern "C" int csm_decode_frame(csm_engine_t* e, const csm_sampling_t* s) {
   if (int r = check_ready(e, s)) return r;
   if (e->h_frame >= e->cfg.max_frames) return fail(CSM_ERR_CAPACITY, "frame ring full (%d)", e->cfg.max_frames);
+  LCK(launch_set_rng(e->stream, e->d_rng, s->seed, (uint64_t)(uint32_t)s->row_offset));
   LCK(decode_frame_impl(e, s));
   e->ready = false;
   return 0;
@@ -794,13 +809,24 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
   if (e->h_frame + n_frames > e->cfg.max_frames) return fail(CSM_ERR_CAPACITY, "frame ring too small: %d + %d > %d", e->h_frame, n_frames, e->cfg.max_frames);
   if (e->h_len + n_frames > e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "KV cache too small: %d + %d > %d", e->h_len, n_frames, e->cfg.max_len);
   const bool want_h = s->last_h_trace != nullptr;
+  LCK(launch_set_rng(e->stream, e->d_rng, s->seed, (uint64_t)(uint32_t)s->row_offset));
   HIPCK(hipEventRecord(e->ev0, e->stream));
   if (use_graph && n_frames > 0) {
     GraphKey k{};
-    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature; k.seed = s->seed;
+    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature;
     k.noise = s->noise; k.forced = s->forced; k.ltrace = s->logits_trace; k.htrace = s->last_h_trace;
+    const bool greedy = s->topk <= 1 || s->temperature == 0.f;
+    if (greedy) { k.topk = 1; k.temperature = 0.f; }   // every greedy setting runs the same launches
     auto it = e->graphs.find(k);
     if (it == e->graphs.end()) {
+      if (e->graphs.size() >= MAX_GRAPHS) {   // evict the least recently used graph
+        auto lru = e->graphs.begin();
+        for (auto jt = e->graphs.begin(); jt != e->graphs.end(); ++jt)
+          if (jt->second.last_use < lru->second.last_use) lru = jt;
+        HIPCK(hipStreamSynchronize(e->stream));
+        hipGraphExecDestroy(lru->second.exec);
+        e->graphs.erase(lru);
+      }
       hipGraph_t g = nullptr;
       HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
       int r = decode_frame_impl(e, s);
@@ -814,9 +840,11 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       hipGraphExec_t ge = nullptr;
       HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       HIPCK(hipGraphDestroy(g));
-      it = e->graphs.emplace(k, ge).first;
+      it = e->graphs.emplace(k, GraphEntry{ge, 0}).first;
+      e->graphs_captured++;
     }
-    for (int i = 0; i < n_frames; ++i) HIPCK(hipGraphLaunch(it->second, e->stream));
+    it->second.last_use = ++e->graph_tick;
+    for (int i = 0; i < n_frames; ++i) HIPCK(hipGraphLaunch(it->second.exec, e->stream));
   } else {
     for (int i = 0; i < n_frames; ++i) {
       LCK(decode_frame_impl(e, s));
@@ -843,6 +871,59 @@ extern "C" int csm_read_frames(csm_engine_t* e, int64_t* frames_out, int first, 
   HIPCK(hipMemcpy2DAsync(frames_out, (size_t)n * C * sizeof(int64_t), e->ring + (size_t)first * C,
                          (size_t)e->cfg.max_frames * C * sizeof(int64_t), (size_t)n * C * sizeof(int64_t), e->B,
                          hipMemcpyDeviceToDevice, e->stream));
+  return 0;
+}
+
+extern "C" int csm_rewind_frames(csm_engine_t* e) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  LCK(launch_set_int(e->stream, e->d_frame, 0));
+  e->h_frame = 0;
+  return 0;
+}
+
+extern "C" int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  if (captured_total_host) *captured_total_host = e->graphs_captured;
+  if (cached_host) *cached_host = (int)e->graphs.size();
+  return 0;
+}
+
+// Re-home a live context into a larger engine (same model, same device).  K rows are [lmax][4] strips per
+// (sequence, kv-head, 4-dim group), V rows are [lmax][hd] per (sequence, kv-head): 2-D copies with the two pitches.
+extern "C" int csm_kv_copy(csm_engine_t* dst, csm_engine_t* src) {
+  if (!dst || !src || dst == src) return fail(CSM_ERR_ARG, "bad engines");
+  if (dst->device != src->device || dst->esz_kv != src->esz_kv || dst->cfg.n_codebooks != src->cfg.n_codebooks ||
+      memcmp(&dst->cfg.backbone, &src->cfg.backbone, sizeof(csm_llama_cfg_t)) || memcmp(&dst->cfg.decoder, &src->cfg.decoder, sizeof(csm_llama_cfg_t)))
+    return fail(CSM_ERR_ARG, "engines differ in model shape / KV dtype / device");
+  const int B = src->B, len = src->h_len, nf = src->h_frame, C = src->cfg.n_codebooks;
+  if (B > dst->cfg.max_batch || len > dst->cfg.max_len || nf > dst->cfg.max_frames)
+    return fail(CSM_ERR_CAPACITY, "destination engine too small (batch %d, length %d, frames %d)", B, len, nf);
+  HIPCK(hipStreamSynchronize(src->stream));
+  hipStream_t st = dst->stream;
+  const size_t es = src->esz_kv;
+  if (B > 0 && len > 0) {
+    Stack& a = src->bb; Stack& b = dst->bb;
+    const int nkv = a.c.n_kv, hd = a.c.head_dim;
+    for (int l = 0; l < a.c.layers; ++l) {
+      HIPCK(hipMemcpy2DAsync(b.kc[l], (size_t)b.lmax * 4 * es, a.kc[l], (size_t)a.lmax * 4 * es, (size_t)len * 4 * es,
+                             (size_t)B * nkv * (hd / 4), hipMemcpyDeviceToDevice, st));
+      HIPCK(hipMemcpy2DAsync(b.vc[l], (size_t)b.lmax * hd * es, a.vc[l], (size_t)a.lmax * hd * es, (size_t)len * hd * es,
+                             (size_t)B * nkv, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (B > 0) {
+    if (nf > 0)
+      HIPCK(hipMemcpy2DAsync(dst->ring, (size_t)dst->cfg.max_frames * C * sizeof(int64_t), src->ring,
+                             (size_t)src->cfg.max_frames * C * sizeof(int64_t), (size_t)nf * C * sizeof(int64_t), B,
+                             hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(dst->d_kv_start, src->d_kv_start, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(dst->head_out, src->head_out, (size_t)B * src->ld_head * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(dst->last_h, src->last_h, (size_t)B * src->cfg.backbone.hidden * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  LCK(launch_set_int(st, dst->d_len, len));
+  LCK(launch_set_int(st, dst->d_frame, nf));
+  dst->B = B; dst->h_len = len; dst->h_frame = nf; dst->ready = src->ready;
+  HIPCK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -939,6 +1020,9 @@ extern "C" int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, i
                                uint64_t seed, const float* noise, int32_t* out_idx) {
   if (!logits || !out_idx) return fail(CSM_ERR_ARG, "null argument");
   if (topk < 1 || topk > V) return fail(CSM_ERR_ARG, "selected index k out of range");
+  if (topk > 1 && temperature != 0.f && (size_t)3 * V * sizeof(float) > 160 * 1024 - 4096)
+    return fail(CSM_ERR_CAPACITY, "top-k sampling keeps 3 x V floats in LDS: V = %d exceeds the 13 300-entry limit of this kernel", V);
+  if (!e) LCK(configure_sample());
   hipStream_t st = e ? e->stream : nullptr;  // engine-less call (module-level sample_topk): null stream
   SampleArgs a{};
   a.logits = logits; a.ldl = V; a.V = V; a.temperature = temperature; a.topk = topk; a.seed = seed; a.noise = noise;

@@ -115,9 +115,21 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
   return (int)hipGetLastError();
 }
 
+int configure_sample() {   // once per process, outside any capture: the top-k path may need more than 64 KiB of LDS
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(160 * 1024 - 4096));
+}
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a) {
-  const size_t lds = (size_t)3 * a.V * sizeof(float);   // scaled logits | survivor values | survivor indices
+  const bool greedy = a.topk <= 1 || a.temperature == 0.f;
+  // top-k: scaled logits | survivor values | survivor indices in LDS; greedy streams the row from memory
+  const size_t lds = greedy ? 0 : (size_t)3 * a.V * sizeof(float);
+  if (lds > 160 * 1024 - 4096) return -3;   // V > 13 300: the reference's sampler has no such limit (documented)
   hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+__global__ void set_rng_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset) { p[0] = seed; p[1] = row_offset; }
+int launch_set_rng(hipStream_t st, uint64_t* p, uint64_t seed, uint64_t row_offset) {
+  hipLaunchKernelGGL(set_rng_kernel, dim3(1), dim3(1), 0, st, p, seed, row_offset);
   return (int)hipGetLastError();
 }
 

@@ -198,6 +198,8 @@ struct SampleArgs {
   float temperature;
   int topk;
   uint64_t seed;
+  const uint64_t* rng;  // nullable: device-resident {seed, global index of row 0} -- overrides `seed`, so that a captured
+                        // graph replays with a new seed / shard offset without re-capture
   const float* noise;  // nullable, [rows][noise_ld] (already offset to this codebook)
   size_t noise_ld;
   int cb, C, B;
@@ -487,8 +489,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
           q = a.noise[(size_t)row * a.noise_ld + i];
         } else {
           uint32_t r[4];
-          philox4x32_10((uint32_t)i, (uint32_t)row, (uint32_t)a.cb, (uint32_t)f, (uint32_t)a.seed,
-                        (uint32_t)(a.seed >> 32), r);
+          const uint64_t seed = a.rng ? a.rng[0] : a.seed;
+          const uint32_t grow = (uint32_t)row + (a.rng ? (uint32_t)a.rng[1] : 0u);   // global row: shards draw distinct streams
+          philox4x32_10((uint32_t)i, grow, (uint32_t)a.cb, (uint32_t)f, (uint32_t)seed, (uint32_t)(seed >> 32), r);
           const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
           q = -logf(u);
         }

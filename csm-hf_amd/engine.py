@@ -17,7 +17,7 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
@@ -26,6 +26,7 @@ EXPORTS = [
     "csm_get_state", "csm_generate", "csm_read_frames", "csm_frames_done", "csm_cur_len", "csm_set_kv_start",
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
+    "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy",
 ]
 
 
@@ -60,7 +61,8 @@ class Weights(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("topk", C.c_int32), ("seed", C.c_uint64), ("noise", C.c_void_p),
-                ("forced", C.c_void_p), ("logits_trace", C.c_void_p), ("last_h_trace", C.c_void_p)]
+                ("forced", C.c_void_p), ("logits_trace", C.c_void_p), ("last_h_trace", C.c_void_p),
+                ("row_offset", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -112,6 +114,9 @@ def load_library(path: Optional[str] = None):
     lib.csm_bench_gemv.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, vp, i32, vp, f32, vp, i32, i32, i32, i32,
                                    C.POINTER(f32), i32, i32, i32]
     lib.csm_sync.argtypes = [vp]
+    lib.csm_rewind_frames.argtypes = [vp]
+    lib.csm_graph_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.csm_kv_copy.argtypes = [vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -382,9 +387,10 @@ class Engine:
         return lh, lg
 
     def sampling(self, temperature=1.0, topk=50, seed=0, noise=None, forced=None, logits_trace=None,
-                 last_h_trace=None) -> Sampling:
+                 last_h_trace=None, row_offset=0) -> Sampling:
         s = Sampling()
         s.temperature, s.topk, s.seed = float(temperature), int(topk), int(seed) & (2 ** 64 - 1)
+        s.row_offset = int(row_offset)
         s.noise = None if noise is None else noise.data_ptr()
         s.forced = None if forced is None else forced.data_ptr()
         s.logits_trace = None if logits_trace is None else logits_trace.data_ptr()
@@ -425,6 +431,21 @@ class Engine:
         _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
         self.sync()
         return lh, lg
+
+    def rewind_frames(self):
+        """generate_frame streaming: frames already handed to the caller free their ring slots."""
+        _ck(self.lib, self.lib.csm_rewind_frames(self._h))
+        self.frames = 0
+
+    def graph_stats(self):
+        a, b = C.c_int(), C.c_int()
+        _ck(self.lib, self.lib.csm_graph_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def adopt_state(self, other: "Engine"):
+        """Move the live context (KV caches, counters, frame ring, pending logits) of `other` into this engine."""
+        _ck(self.lib, self.lib.csm_kv_copy(self._h, other._h))
+        self.batch, self.length, self.frames = other.batch, other.length, other.frames
 
     def device_counters(self):
         a, b = C.c_int(), C.c_int()

@@ -75,14 +75,16 @@ def sample_topk(logits: torch.Tensor, topk: int, temperature: float, seed: Optio
     V = logits.shape[-1]
     if topk > V or topk < 1:
         raise RuntimeError("selected index k out of range")
+    # (top-k keeps 3 x V floats in LDS: V <= 13 300; greedy has no limit -- the C entry reports it otherwise)
     lg = logits.reshape(-1, V).to(torch.float32).contiguous()
     nz = None if noise is None else noise.reshape(-1, V).to(logits.device, torch.float32).contiguous()
     out = torch.empty(lg.shape[0], dtype=torch.int32, device=logits.device)
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     torch.cuda.current_stream(logits.device).synchronize()
-    rc = lib.csm_sample_topk(None, C.c_void_p(lg.data_ptr()), lg.shape[0], V, float(temperature), int(topk), int(seed),
-                             None if nz is None else C.c_void_p(nz.data_ptr()), C.c_void_p(out.data_ptr()))
+    with torch.cuda.device(logits.device):   # the engine-less entry launches on the current device's null stream
+        rc = lib.csm_sample_topk(None, C.c_void_p(lg.data_ptr()), lg.shape[0], V, float(temperature), int(topk), int(seed),
+                                 None if nz is None else C.c_void_p(nz.data_ptr()), C.c_void_p(out.data_ptr()))
     if rc != 0:
         raise RuntimeError(lib.csm_last_error().decode())
     return out.reshape(*logits.shape[:-1], 1)
@@ -147,6 +149,7 @@ class CSMModel(nn.Module):
         self.weight_format = "native"   # "fp8": linear weights as e4m3fn + per-row scales (BASELINE config 5)
         self.use_graph = True
         self.seed = 0
+        self.row_offset = 0             # global index of row 0 of this model's batch (batch-sharded generation)
 
     # ---- HF-style plumbing -------------------------------------------------------------------------------
     @property
@@ -216,29 +219,42 @@ class CSMModel(nn.Module):
         self._epoch += 1
         self._frame_pending = False
 
-    def _ensure_engine(self, batch: int, need_len: int, need_frames: int, prefill_rows: int) -> Engine:
+    def _ensure_engine(self, batch: int, need_len: int, need_frames: int, prefill_rows: int, cont: bool = False) -> Engine:
+        """Create or re-size the engine.  `cont`: the call continues a live context (past_key_values): the engine may
+        still grow (the reference's DynamicCache grows without bound), but then the resident KV cache, counters, frame
+        ring and pending logits are MOVED into the larger engine (csm_kv_copy) -- a continuation never restarts from an
+        empty cache.  The prefill scratch is not a growth reason: Engine.prefill chunks by max_prefill_rows."""
         p = next(self.parameters())
         if p.device.type != "cuda":
             raise RuntimeError("CSMModel must be on an AMD GPU (model.to('cuda')): csm_hf_amd has no CPU path")
         c = self._caps
         if self._engine is not None and self._engine.fp8 != (self.weight_format == "fp8"):
+            if cont:
+                raise ValueError("weight_format changed while a KV cache is live")
             self._drop_engine()
         grow = (self._engine is None or batch > self._engine.max_batch or need_len > self._engine.max_len or
-                need_frames > self._engine.max_frames or prefill_rows > self._engine.max_prefill_rows)
+                need_frames > self._engine.max_frames)
         if grow:
             c["max_batch"] = max(c["max_batch"], batch)
-            c["max_len"] = max(c["max_len"], need_len, self.config.max_seq_len)
+            # a live context that outgrows its cache doubles it (amortised like the reference's cat-grown cache)
+            c["max_len"] = max(c["max_len"], need_len if not cont else max(need_len, 2 * self._engine.max_len),
+                               self.config.max_seq_len)
             c["max_frames"] = max(c["max_frames"], need_frames, 256)
-            c["max_prefill_rows"] = max(c["max_prefill_rows"], prefill_rows)
-            packed = None
-            if self._engine is not None:
-                packed = self._engine.packed
-                self._engine.close()
+            c["max_prefill_rows"] = max(c["max_prefill_rows"], min(prefill_rows, 8192))
+            old = self._engine
+            packed = old.packed if old is not None else None
+            if old is not None and not cont:
+                old.close()
+                old = None
                 self._epoch += 1
-            self._engine = Engine(self.config, self.state_dict(), p.device, p.dtype, max_batch=c["max_batch"],
-                                  max_len=c["max_len"], max_frames=c["max_frames"],
-                                  max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed,
-                                  weight_format=self.weight_format)
+            eng = Engine(self.config, self.state_dict(), p.device, p.dtype, max_batch=c["max_batch"],
+                         max_len=c["max_len"], max_frames=c["max_frames"],
+                         max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed,
+                         weight_format=self.weight_format)
+            if old is not None:      # continuation: re-home the live state, then release the old engine
+                eng.adopt_state(old)
+                old.close()
+            self._engine = eng
         return self._engine
 
     # ---- helpers -----------------------------------------------------------------------------------------------
@@ -281,7 +297,7 @@ class CSMModel(nn.Module):
                 raise ValueError("stale or foreign past_key_values: the KV cache lives in the engine and only the "
                                  "handle returned by the most recent call can be continued")
         base = self._engine.length if cont else 0
-        eng = self._ensure_engine(B, base + S + 1, 1, min(B * S, max(B * S, 128)))
+        eng = self._ensure_engine(B, base + S + 1, 1, B * S, cont=cont)
         if not cont:
             eng.reset()
             self._epoch += 1
@@ -312,9 +328,10 @@ class CSMModel(nn.Module):
                            past_key_values=past_key_values, use_cache=True, return_dict=True)
         eng = self._engine
         if eng.frames + 1 > eng.max_frames:
-            # ring full: restartable because frames already returned are owned by the caller
-            raise ValueError("frame ring full: call setup_caches(max_frames=...) with a larger value")
-        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed())
+            # every frame of this path has already been handed to the caller (the reference keeps none either,
+            # :578-589): restart the on-device ring instead of limiting a stream to max_frames frames
+            eng.rewind_frames()
+        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed(), row_offset=self.row_offset)
         eng.decode_frame(s)
         tokens = eng.read_frames(eng.frames, 1)[:, 0, :]
         self._frame_pending = True
@@ -331,8 +348,10 @@ class CSMModel(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: int = 100,
-                 temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True):
-        """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.
+                 temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True,
+                 *, seed: Optional[int] = None):
+        """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.  `seed` (extension, default: drawn
+        from torch's seed and a call counter) keys the device Philox stream of the sampler.
 
         One prefill, then per frame one replay of the captured hipGraph (31-step decoder loop + next
         backbone step).  With `stop_on_all_zeros` the host checks each frame (one sync per frame, like the
@@ -347,7 +366,8 @@ class CSMModel(nn.Module):
         self._frame_pending = False
         eng.set_kv_start(self._kv_starts(attention_mask, B, T))
         eng.prefill(input_ids, attention_mask, want_outputs=False)
-        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed())
+        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed() if seed is None else int(seed),
+                         row_offset=self.row_offset)
         n = 0
         if stop_on_all_zeros:
             while n < max_new_frames:

@@ -37,6 +37,27 @@ def gather_frames(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
     return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0)
 
 
+MAX_ROWS_PER_PASS = 64   # rows one engine pass keeps on the matrix-core activation-plane path (csrc/engine.hip: PL_GROUPS)
+
+
+def _generate_rows(model, ids, mask, row0: int, kw) -> torch.Tensor:
+    """One shard's rows in engine-sized passes; the sampler sees GLOBAL row indices (row0 + local row)."""
+    outs = []
+    prev = getattr(model, "row_offset", 0)
+    if "seed" not in kw and hasattr(model, "_next_seed"):
+        kw = dict(kw, seed=model._next_seed())    # ONE seed per sharded call (same on every rank: same torch seed, same
+        # call count), so with global row indices the sampled result does not depend on the world size or pass split
+    try:
+        for a in range(0, ids.shape[0], MAX_ROWS_PER_PASS):
+            # the sampler's Philox counter uses the GLOBAL row (shard start + local row): every rank derives the same
+            # seed from torch's seed, so without the offset local row i of every GPU would draw the same noise
+            model.row_offset = row0 + a
+            outs.append(model.generate(ids[a:a + MAX_ROWS_PER_PASS], mask[a:a + MAX_ROWS_PER_PASS], **kw))
+    finally:
+        model.row_offset = prev
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
 def generate_sharded(model, input_ids: torch.Tensor, attention_mask: torch.Tensor, group=None, **gen_kwargs) -> torch.Tensor:
     """Every rank passes the FULL `[B, T, 33]` batch; each generates its own rows; all ranks return the
     full `[B, n, 32]` result.
@@ -50,16 +71,16 @@ def generate_sharded(model, input_ids: torch.Tensor, attention_mask: torch.Tenso
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     stop = bool(gen_kwargs.get("stop_on_all_zeros", True))
-    if world == 1:
+    if world == 1 and input_ids.shape[0] <= MAX_ROWS_PER_PASS:
         return model.generate(input_ids, attention_mask, **gen_kwargs)
     kw = dict(gen_kwargs, stop_on_all_zeros=False)
     a, b = shard_rows(input_ids.shape[0], rank, world)
     if b > a:
-        local = model.generate(input_ids[a:b], attention_mask[a:b], **kw)
+        local = _generate_rows(model, input_ids[a:b], attention_mask[a:b], a, kw)
     else:  # more ranks than rows
         n = int(gen_kwargs.get("max_new_frames", 100))
         local = torch.zeros(0, n, input_ids.shape[2] - 1, dtype=torch.long, device=input_ids.device)
-    full = gather_frames(local, input_ids.shape[0], group)
+    full = gather_frames(local, input_ids.shape[0], group) if world > 1 else local
     if stop and full.shape[1] > 0:
         zero = (full == 0).all(dim=2).all(dim=0)          # [n]: frame f is all-zero in every row
         if bool(zero.any()):

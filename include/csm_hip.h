@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 2
+#define CSM_ABI_VERSION 3
 
 enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
@@ -100,13 +100,18 @@ typedef struct csm_engine csm_engine_t;
 typedef struct {
   float temperature;     /* 0 => argmax (the reference would produce NaNs) */
   int32_t topk;          /* 1 => greedy */
-  uint64_t seed;         /* Philox key for the Exp(1) race; ignored when noise != NULL or greedy */
+  uint64_t seed;         /* Philox key for the Exp(1) race; ignored when noise != NULL or greedy.  Kept in device
+                            memory by the engine (written before every launch), so it is NOT part of a captured graph */
   const float* noise;    /* optional explicit Exp(1) draws [max_frames?1][B][n_codebooks][audio_vocab] for
                             parity tests; indexed [b][cb][v] for the CURRENT frame */
   const int64_t* forced; /* optional teacher-forced tokens [B][max_frames][n_codebooks]: fed back instead
                             of the model's samples (samples are still recorded) */
   float* logits_trace;   /* optional [max_frames][B][n_codebooks][audio_vocab] fp32 dump of every logits row */
   float* last_h_trace;   /* optional [max_frames][B][Hb] fp32 dump of last_hidden_state per frame */
+  int32_t row_offset;    /* global index of this engine's row 0 (batch-sharded generation): the
+                            Philox counter uses row_offset + local row, so shards draw distinct, world-size-independent
+                            streams.  No reference counterpart (torch's global generator, modeling_csm.py:175) */
+  int32_t reserved;
 } csm_sampling_t;
 
 /* ---- lifecycle: CSMModel.__init__ / setup_caches / reset_caches (modeling_csm.py:214-245, 284-290) */
@@ -153,6 +158,15 @@ int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logits_out);
  * csm_read_frames.  No host sync inside. */
 int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_frames, int use_graph);
 int csm_read_frames(csm_engine_t* e, int64_t* frames_out /* device [B,n,C] */, int first, int n);
+/* generate_frame-driven streaming (modeling_csm.py:484-589 hands every frame to the caller): restart the on-device
+ * frame ring at slot 0 once the caller has read what it holds, so a stream is not limited to max_frames frames */
+int csm_rewind_frames(csm_engine_t* e);
+/* captured-graph bookkeeping (tests): graphs captured since creation, graphs currently cached (LRU, <= 8) */
+int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host);
+/* Move the live state of `src` (KV caches of the resident batch, lengths, frame ring, pending codebook-0 logits) into
+ * `dst`, an engine of the same model with larger capacities -- the reference's DynamicCache simply grows
+ * (transformers cache_utils.py:144-145); here a continuation that outgrows max_len / max_frames re-homes its cache */
+int csm_kv_copy(csm_engine_t* dst, csm_engine_t* src);
 int csm_frames_done(csm_engine_t* e, int* n_host);            /* syncs the stream */
 int csm_cur_len(csm_engine_t* e, int* len_host);              /* syncs the stream */
 /* per-row first valid KV position (left padding): pads are masked at every step */

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in csm_hip.h but not exported"
     assert declared == set(EXPORTS)
-    assert lib.csm_abi_version() == 2
+    assert lib.csm_abi_version() == 3
 
 
 def test_no_gpu_fails_loudly():
@@ -93,7 +93,10 @@ def test_rope_table_matches_oracle_formula():
 def test_api_surface_matches_reference_signatures():
     import inspect
     g = inspect.signature(CSMModel.generate).parameters
-    assert list(g)[1:] == ["input_ids", "attention_mask", "max_new_frames", "temperature", "topk", "use_cache", "stop_on_all_zeros"]
+    # the reference's parameters, in order; extensions (seed) are keyword-only so positional callers are unaffected
+    pos = [k for k, v in g.items() if v.kind == v.POSITIONAL_OR_KEYWORD]
+    assert pos[1:] == ["input_ids", "attention_mask", "max_new_frames", "temperature", "topk", "use_cache", "stop_on_all_zeros"]
+    assert all(v.kind == v.KEYWORD_ONLY and v.default is None for k, v in g.items() if k not in pos)
     assert (g["max_new_frames"].default, g["temperature"].default, g["topk"].default) == (100, 1.0, 50)
     f = inspect.signature(CSMModel.generate_frame).parameters
     assert list(f)[1:] == ["input_ids", "attention_mask", "position_ids", "temperature", "topk", "past_key_values",

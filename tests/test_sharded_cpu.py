@@ -15,9 +15,12 @@ class StubModel:
 
     def __init__(self, zero_rows_at=None, zero_all_at=None):
         self.zero_rows_at, self.zero_all_at = zero_rows_at, zero_all_at
+        self.row_offset = 0
 
     def generate(self, ids, mask, max_new_frames=3, stop_on_all_zeros=False, **_):
-        key = ids.sum(dim=(1, 2)) + mask.sum(dim=(1, 2)) * 7
+        # like the engine's Philox counter, the output depends on the GLOBAL row index (row_offset + local row): the
+        # sharded result equals the unsharded one only if generate_sharded hands every shard its row offset
+        key = ids.sum(dim=(1, 2)) + mask.sum(dim=(1, 2)) * 7 + (self.row_offset + torch.arange(ids.shape[0])) * 13
         f = torch.arange(max_new_frames)[None, :, None]
         c = torch.arange(32)[None, None, :]
         out = (key[:, None, None] * 31 + f * 5 + c) % 2051 + 1          # never 0 by itself
