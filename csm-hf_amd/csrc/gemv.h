@@ -17,6 +17,7 @@
 // the o_proj launch (PRO_ATTN).
 #pragma once
 #include "common.h"
+#include "prefetch.h"
 #ifndef CSM_ARGS_ONLY
 #include "attn_tile.h"
 #endif
@@ -83,6 +84,10 @@ struct GemvArgs {
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
+  // weight streamer (prefetch.h): launches-started counter bumped by workgroup 0 (nullable), and a host-side slot
+  // the launcher fills with this launch's workgroup -> rows geometry
+  unsigned* prog;
+  PfGeom* geom_out;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ float part[4][2 * T];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
@@ -407,6 +413,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int U = 4;
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   float* red = xs + (size_t)M * K;

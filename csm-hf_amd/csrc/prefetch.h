@@ -1,0 +1,172 @@
+// Weight streamer: a persistent kernel on a second HIP stream that walks the weight matrices of a captured frame-step
+// in consumption order and pulls them into the XCD-local L2 ahead of the launches that read them.
+//
+// Why: a frame-step at small batch is a chain of ~770 dependent launches; each launch boundary (~1.5 us) and each
+// latency-bound small launch leaves HBM idle, so the chain streams 9 GB in ~3.4 ms (2.6 TB/s) although the memory
+// system sustains 6.3 TB/s.  L2 contents survive kernel boundaries (tools/ubench/prefetch.hip, E2: a 32 MiB matrix
+// re-read by the next launch runs at 9.2 TB/s, a fresh one at 4.1-4.8), and a kernel on another stream runs concurrently
+// with a replaying hipGraph (E5/E6; a parallel BRANCH of the graph does not: ROCm 7.2 serialises it).  The streamer
+// therefore fetches, with fire-and-forget LDS-DMA loads (`global_load_lds_dwordx4`: 1 KiB per wave instruction, no
+// VGPR destination, never waited for), exactly the rows each consumer workgroup will read, FROM THE XCD that workgroup
+// will run on (workgroup b of every dispatch lands on XCD (b + rot) % 8; `rot` is measured at engine creation), paced
+// by a launch counter the consumers bump: a segment may be fetched once the bytes fetched-but-not-yet-consumed fit a
+// window (default 24 MiB of the 32 MiB aggregate L2), and is skipped when its consumer has already started.
+//
+// The streamer never writes model state, so results are bit-identical with it on or off; a late or absent streamer
+// only costs speed.  Every spin is bounded (it gives up after `budget_ticks` without progress).
+// No reference counterpart: the reference (modeling_csm.py) issues torch ops one by one.
+#pragma once
+#include "common.h"
+
+// How one weight-streaming launch maps its workgroups to matrix rows; filled by the launcher (gemv_inst.inc).
+struct PfGeom {
+  const void* W;   // row-major [N][K]
+  int N, K, esz;
+  int kind;        // 0: task t -> rows 2t, 2t+1;  1: QKV epilogue (RoPE pairs, gemv.h gemv_map_task);  -1: not streamed
+  int grid, tpb;   // workgroup b, iteration it covers tasks [b*tpb + it*stride, +tpb)
+  int iters, stride;
+  int ntask;
+  int hd, n_rope_heads;   // kind 1: head_dim, n_q + n_kv
+};
+
+// A range of consumer workgroups of one launch (device-side schedule entry).
+struct PfSeg {
+  const char* W;
+  uint32_t row_bytes;
+  int32_t N, kind, tpb, iters, stride, ntask, hd, n_rope_heads;
+  int32_t b0, b1;    // consumer workgroups [b0, b1)
+  int32_t owner;     // index of the consuming launch within the frame-step
+  int32_t need;      // may be fetched once (launches started) >= rep * n_launch + need
+};
+
+struct PfArgs {
+  const PfSeg* segs;
+  int n, n_launch, reps;
+  int rot;                 // workgroup b of a dispatch runs on XCD (b + rot) % 8
+  const unsigned* prog;    // launches started so far (bumped by workgroup 0 of every streamed launch)
+  unsigned* ticket;        // [8] per-XCD arrival counters, zeroed before the launch
+  unsigned* status;        // [0] workgroups that gave up, [1] finished, [2] segments skipped as late (workgroup 0 of XCD 0)
+  long long budget_ticks;  // s_memrealtime ticks (100 MHz) without progress before giving up
+};
+
+#ifndef CSM_ARGS_ONLY
+__device__ __forceinline__ unsigned pf_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
+
+__global__ void pf_where_kernel(unsigned* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = pf_xcc_id();
+}
+
+// one poller wave + three loader waves per workgroup
+__global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
+  __shared__ __attribute__((aligned(16))) char dump[4 * 1024];
+  __shared__ unsigned s_bl;
+  __shared__ int s_cur, s_state, s_done;
+  const unsigned x = pf_xcc_id();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) {
+    s_bl = atomicAdd(a.ticket + x, 1u);
+    s_cur = 0; s_state = 0; s_done = 0;
+  }
+  __syncthreads();
+  const unsigned bl = s_bl, nl = gridDim.x >> 3;
+  if (bl >= nl) return;   // uneven placement: surplus workgroups idle (their share is dealt by the modulo below)
+  volatile int* v_cur = &s_cur;
+  volatile int* v_state = &s_state;
+  volatile int* v_done = &s_done;
+  if (wave == 0) {
+    // poller: keeps the launch counter fresh in LDS, so the loaders never put a vector load (whose in-order vmcnt
+    // wait would cover every prefetch load in flight) between their prefetches
+    long long t_last = __builtin_amdgcn_s_memrealtime();
+    int last = -1;
+    while (*v_done < 3) {
+      const int c = (int)__hip_atomic_load(a.prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) *v_cur = c;
+      const long long now = __builtin_amdgcn_s_memrealtime();
+      if (c != last) { last = c; t_last = now; }
+      if (now - t_last > a.budget_ticks) {
+        if (lane == 0) { *v_state = 2; atomicAdd(a.status, 1u); }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) atomicAdd(a.status + 1, 1u);
+    return;
+  }
+  const unsigned slot = bl * 3u + (unsigned)(wave - 1), nslot = nl * 3u;
+  auto* ldst = (__attribute__((address_space(3))) void*)(dump + wave * 1024);
+  unsigned skipped = 0;
+  for (int rep = 0; rep < a.reps; ++rep) {
+    const int base = rep * a.n_launch;
+    for (int e = 0; e < a.n; ++e) {
+      const PfSeg* sp = a.segs + e;
+      const int want = base + sp->need;
+      int cur = *v_cur;
+      while (cur < want) {
+        if (*v_state == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        __builtin_amdgcn_s_sleep(1);
+        cur = *v_cur;
+      }
+      if (cur > base + sp->owner) { ++skipped; continue; }   // its consumer is already running: leave it alone
+      const int b0 = sp->b0, b1 = sp->b1, tpb = sp->tpb, iters = sp->iters, ntask = sp->ntask, N = sp->N;
+      const unsigned rb = sp->row_bytes;
+      const char* W = sp->W;
+      // consumer workgroups of this XCD inside [b0, b1): b = bf + 8 i
+      const int bf = b0 + (int)((x + 16u - (unsigned)((b0 + a.rot) & 7)) & 7u);
+      if (bf >= b1) continue;
+      const unsigned nbx = (unsigned)(b1 - bf + 7) >> 3;
+      const unsigned FB = 2u * (unsigned)tpb * rb;                 // footprint of one (workgroup, iteration)
+      const unsigned ppb = (FB + 4095u) >> 12;
+      const unsigned n_units = nbx * (unsigned)iters * ppb;
+      const int half = sp->hd >> 1;
+      for (unsigned u = slot; u < n_units; u += nslot) {
+        const unsigned piece = u % ppb, r = u / ppb;
+        const int it = (int)(r % (unsigned)iters), i = (int)(r / (unsigned)iters);
+        const int b = bf + 8 * i;
+        const int t0 = b * tpb + it * sp->stride;
+        if (t0 >= ntask) continue;
+        const int nt = min(tpb, ntask - t0);
+        // virtual footprint [0, fb) -> addresses
+        unsigned fb;
+        size_t base0, base1 = 0;
+        unsigned split = 0xffffffffu;   // virtual offset where chunk 1 starts (RoPE pairs)
+        if (sp->kind == 1) {
+          const int head = t0 / half, hi = t0 - head * half;
+          if (head < sp->n_rope_heads) {
+            base0 = (size_t)(head * sp->hd + hi) * rb;
+            base1 = base0 + (size_t)half * rb;
+            split = (unsigned)nt * rb;
+            fb = 2u * split;
+          } else {
+            base0 = (size_t)(head * sp->hd + 2 * hi) * rb;
+            fb = 2u * (unsigned)nt * rb;
+          }
+        } else {
+          base0 = (size_t)(2 * t0) * rb;
+          const int rows = min(2 * nt, N - 2 * t0);
+          fb = (unsigned)rows * rb;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned vo = piece * 4096u + (unsigned)j * 1024u + (unsigned)lane * 16u;
+          if (piece * 4096u + (unsigned)j * 1024u >= fb) break;    // wave-uniform
+          if (vo >= fb) vo = 0;
+          const char* src = W + (vo >= split ? base1 + (vo - split) : base0 + vo);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, ldst, 16, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    atomicAdd((int*)&s_done, 1);
+    if (skipped && x == 0 && bl == 0 && wave == 1) atomicAdd(a.status + 2, skipped);
+  }
+}
+#endif  // CSM_ARGS_ONLY
+
+int launch_pf_where(hipStream_t st, unsigned* out8);
+int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a);

@@ -3,7 +3,7 @@
 Runs only in the build container (needs /root/reference and `transformers`); the reference never
 travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
 
-    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2] [--frames2 200]
+    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise] [--frames2 200]
 
 What it does
   * imports /root/reference/modeling_csm.py unmodified;
@@ -130,13 +130,16 @@ def topn(logits, n):
 
 @torch.inference_mode()
 def run_case(name, cfg, sd, dtype, ids, mask, frames, *, full_logits=False, topn_keep=4, extra=None,
-             check_nocache=False):
+             check_nocache=False, topk=1, temperature=1.0, noise=None):
+    """`noise` [frames, B, C, V]: explicit Exp(1) draws substituted for the reference's `exponential_` call
+    (modeling_csm.py:175) in sampling order (frame-major, codebook-minor), so a top-k run is reproducible bit for bit."""
     t0 = time.time()
     model = build_ref(cfg, sd, dtype)
     C, V = cfg.audio_num_codebooks, cfg.audio_vocab_size
     torch.manual_seed(1234)   # bf16 top-1 ties are broken by the global RNG (modeling_csm.py:175)
-    with Recorder(model) as rec:
-        toks = model.generate(ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
+    flat = None if noise is None else [noise[f][:, c, :] for f in range(frames) for c in range(C)]
+    with Recorder(model, noise=flat) as rec:
+        toks = model.generate(ids, mask, max_new_frames=frames, temperature=temperature, topk=topk,
                               use_cache=True, stop_on_all_zeros=False)
     n = toks.shape[1]
     B = ids.shape[0]
@@ -161,8 +164,8 @@ def run_case(name, cfg, sd, dtype, ids, mask, frames, *, full_logits=False, topn
     sdd = {k: v.to(dtype) for k, v in sd.items()}
     tr = {}
     torch.manual_seed(1234)
-    otoks = O.generate(sdd, cfg, ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
-                       stop_on_all_zeros=False, trace=tr)
+    otoks = O.generate(sdd, cfg, ids, mask, max_new_frames=frames, temperature=temperature, topk=topk,
+                       stop_on_all_zeros=False, trace=tr, noise=noise)
     t_or = time.time() - t0
     eq = bool(torch.equal(otoks, toks))
     dl = float((tr["logits"] - logits).abs().max())
@@ -262,6 +265,19 @@ def gen_1b(which, frames2):
     if "cfg2" in which:
         ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
         run_case("csm1b_cfg2_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, frames2, topn_keep=2)
+    if "b4" in which:
+        # BASELINE configs[2] layout ("voice cloning"): 48 text + 400 audio + the all-zero EOS audio frame + 63 text
+        # frames = 512, four DISTINCT rows, so the batched (matrix-core) decode kernels are pinned against the
+        # reference itself rather than against the engine's own single-row kernels
+        ids, mask = synth_context(cfg, 4, 48, 400, seed=3, tail_text=63, eos_frame=True)
+        run_case("csm1b_b4_ctx512_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, 4, topn_keep=2)
+    if "b4noise" in which:
+        # the sampler in situ: top-k = 50, T = 1.0 on all 32 codebooks with explicit Exp(1) noise [n,B,C,V]
+        ids, mask = synth_context(cfg, 4, 48, 400, seed=3, tail_text=63, eos_frame=True)
+        n = 2
+        noise = torch.empty(n, 4, cfg.audio_num_codebooks, cfg.audio_vocab_size).exponential_(1, generator=torch.Generator().manual_seed(11))
+        run_case("csm1b_b4_topk50_noise_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, n, topn_keep=2, topk=50,
+                 temperature=1.0, noise=noise, extra=dict(noise_seed=np.int32(11)))
 
 
 def processor_cases():
@@ -298,7 +314,7 @@ def gen_processor():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2")
+    ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise")
     ap.add_argument("--frames2", type=int, default=200)
     a = ap.parse_args()
     which = set(a.only.split(","))
@@ -309,7 +325,7 @@ def main():
         gen_sampler()
     if "processor" in which:
         gen_processor()
-    if which & {"cfg1", "prefill512", "cfg2"}:
+    if which & {"cfg1", "prefill512", "cfg2", "b4", "b4noise"}:
         gen_1b(which, a.frames2)
 
 

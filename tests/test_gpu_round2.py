@@ -83,7 +83,7 @@ def test_continuation_survives_engine_growth():
     m2 = tiny_model()[2]
     pkv, cur, cm, got = None, ids[:, :120], mask[:, :120], []
     for _ in range(150):
-        out = m2.generate_frame(cur, cm, temperature=1.0, topk=1, past_key_values=pkv, return_dict=True)
+        out = m2.generate_frame(cur, cm, temperature=1.0, topk=1, past_key_values=pkv, use_cache=True, return_dict=True)
         got.append(out.samples)
         pkv = out.past_key_values
         cur = torch.cat([out.samples, torch.zeros(2, 1, dtype=torch.long, device=DEV)], 1).unsqueeze(1)
@@ -103,7 +103,7 @@ def test_generate_frame_stream_longer_than_the_frame_ring():
     m2 = tiny_model()[2]
     pkv, cur, cm, got = None, ids, mask, []
     for _ in range(n):
-        out = m2.generate_frame(cur, cm, temperature=1.0, topk=1, past_key_values=pkv, return_dict=True)
+        out = m2.generate_frame(cur, cm, temperature=1.0, topk=1, past_key_values=pkv, use_cache=True, return_dict=True)
         got.append(out.samples)
         pkv = out.past_key_values
         cur = torch.cat([out.samples, torch.zeros(1, 1, dtype=torch.long, device=DEV)], 1).unsqueeze(1)
