@@ -84,6 +84,10 @@ struct GraphKey {
 struct GraphEntry {
   hipGraphExec_t exec;
   uint64_t last_use;
+  // weight-streamer schedule of this frame-step (prefetch.h): device array of segments in consumption order
+  PfSeg* d_segs = nullptr;
+  int n_segs = 0, n_launch = 0;
+  size_t sched_bytes = 0, step_bytes = 0;
 };
 constexpr size_t MAX_GRAPHS = 8;   // LRU bound on cached frame-step graphs
 
@@ -146,6 +150,15 @@ struct csm_engine {
   std::map<GraphKey, GraphEntry> graphs;
   uint64_t graph_tick = 0;
   int graphs_captured = 0;
+  // weight streamer (prefetch.h): a persistent kernel on `stream2` pulls the weights of the replaying graph into L2
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
+  unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
+  int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
+  int pf_enable = 1, pf_window_mb = 24, pf_sub_kb = 4096, pf_grid = 256;
+  std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
+  long long pf_last[4] = {0, 0, 0, 0};   // schedule of the last replayed graph: segments, launches, scheduled bytes, streamed-launch bytes
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::vector<void*> allocs;
@@ -276,13 +289,32 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
+  // weight streamer: second stream, fork/join events, launch counter, and the dispatcher's workgroup -> XCD rotation
+  HIPCK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+  HIPCK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  if ((r = dalloc(e, &e->d_prog, 16)) || (r = dalloc(e, &e->d_pf_misc, 64))) return r;
+  HIPCK(hipMemsetAsync(e->d_prog, 0, 16 * sizeof(unsigned), e->stream));
+  HIPCK(hipMemsetAsync(e->d_pf_misc, 0, 64 * sizeof(unsigned), e->stream));
+  {
+    unsigned where[8];
+    LCK(launch_pf_where(e->stream, e->d_pf_misc + 16));
+    HIPCK(hipMemcpyAsync(where, e->d_pf_misc + 16, sizeof(where), hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    bool rr = true;
+    for (int b = 0; b < 8; ++b) rr = rr && where[b] == ((where[0] + b) & 7u);
+    e->pf_rot = rr ? (int)where[0] : -1;
+  }
   HIPCK(hipStreamSynchronize(e->stream));
   *out = e;
   return 0;
 }
 
 static void drop_graphs(csm_engine* e) {
-  for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second.exec);
+  for (auto& kv : e->graphs) {
+    hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.d_segs) hipFree(kv.second.d_segs);
+  }
   e->graphs.clear();
 }
 
@@ -290,7 +322,11 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   if (!e) return 0;
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
+  if (e->stream2) hipStreamSynchronize(e->stream2);
   drop_graphs(e);
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->stream2) hipStreamDestroy(e->stream2);
   for (void* p : e->allocs) hipFree(p);
   drop_tiled(e);
   if (e->ev0) hipEventDestroy(e->ev0);
@@ -406,6 +442,10 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
+  else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
+  else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
+  else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
+  else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -477,8 +517,13 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     if (a.xplanes || a.oplanes) return fail(CSM_ERR_STATE, "activation planes requested but the matrix-core kernel does not cover N=%d K=%d M=%d", a.N, a.K, M);
     const int m = left < 4 ? left : 4;
     slice(m);
+    PfGeom geom{};
+    geom.kind = -1;
+    if (e->pf_rec) { a.prog = e->d_prog; a.geom_out = &geom; }   // capture: this launch is paced / streamed (prefetch.h)
     const int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
+    a.prog = nullptr; a.geom_out = nullptr;
     if (r) return r;
+    if (e->pf_rec) e->pf_rec->push_back(geom);
     m0 += m;
   }
   return 0;
@@ -803,6 +848,67 @@ extern "C" int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logit
   return 0;
 }
 
+// Weight-streamer schedule of a captured frame-step: every streamed launch is cut into runs of consumer workgroups of
+// about `pf_sub_kb`; run e may be fetched once the bytes of runs whose consumer has not started yet, up to and including
+// e, fit the window (cyclically over consecutive frames).  Runs that could only be fetched after their own consumer has
+// started are left to the consumer.
+static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, GraphEntry& ent) {
+  ent.n_launch = (int)geoms.size();
+  if (geoms.empty()) return 0;
+  std::vector<PfSeg> segs;
+  std::vector<size_t> bytes;
+  const size_t sub = (size_t)e->pf_sub_kb << 10;
+  for (int li = 0; li < (int)geoms.size(); ++li) {
+    const PfGeom& g = geoms[li];
+    if (g.kind < 0 || !g.W || g.grid < 1 || g.tpb < 1) continue;
+    const size_t rb = (size_t)g.K * g.esz;
+    const size_t per_block = (size_t)g.iters * 2 * g.tpb * rb;
+    int bps = (int)((sub + per_block - 1) / per_block);
+    bps = (bps + 7) & ~7;
+    if (bps < 8) bps = 8;
+    for (int b0 = 0; b0 < g.grid; b0 += bps) {
+      PfSeg sg{};
+      sg.W = (const char*)g.W; sg.row_bytes = (uint32_t)rb; sg.N = g.N; sg.kind = g.kind; sg.tpb = g.tpb; sg.iters = g.iters;
+      sg.stride = g.stride; sg.ntask = g.ntask; sg.hd = g.hd > 1 ? g.hd : 2; sg.n_rope_heads = g.n_rope_heads;
+      sg.b0 = b0; sg.b1 = std::min(g.grid, b0 + bps); sg.owner = li;
+      segs.push_back(sg);
+      bytes.push_back((size_t)(sg.b1 - sg.b0) * per_block);
+      ent.step_bytes += bytes.back();
+    }
+  }
+  const int n = (int)segs.size();
+  if (n == 0) return 0;
+  const size_t window = (size_t)e->pf_window_mb << 20;
+  std::vector<PfSeg> keep;
+  for (int i = 0; i < n; ++i) {
+    size_t acc = bytes[i];
+    int j = i - 1, wrap = 0;   // walk back, cyclically into the previous frame
+    int need = 0;
+    bool all = false;
+    for (int steps = 0; steps < n - 1; ++steps) {
+      int jj = j;
+      if (jj < 0) { jj += n; wrap = 1; } else wrap = 0;
+      if (acc + bytes[jj] > window) { need = segs[jj].owner + 1 - (wrap || j < 0 ? ent.n_launch : 0); break; }
+      acc += bytes[jj];
+      --j;
+      if (steps == n - 2) all = true;
+    }
+    if (all || n == 1) need = -(1 << 29);    // a whole frame-step fits the window
+    if (need > segs[i].owner) continue;   // could only be fetched after its own consumer started
+    segs[i].need = need;
+    keep.push_back(segs[i]);
+    ent.sched_bytes += bytes[i];
+  }
+  if (keep.empty()) return 0;
+  void* d = nullptr;
+  hipError_t r = hipMalloc(&d, keep.size() * sizeof(PfSeg));
+  if (r != hipSuccess) return fail(CSM_ERR_NOMEM, "hipMalloc for the weight-streamer schedule failed: %s", hipGetErrorString(r));
+  HIPCK(hipMemcpy(d, keep.data(), keep.size() * sizeof(PfSeg), hipMemcpyHostToDevice));
+  ent.d_segs = (PfSeg*)d;
+  ent.n_segs = (int)keep.size();
+  return 0;
+}
+
 extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_frames, int use_graph) {
   if (int r = check_ready(e, s)) return r;
   if (n_frames < 0) return fail(CSM_ERR_ARG, "n_frames < 0");
@@ -825,12 +931,16 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
           if (jt->second.last_use < lru->second.last_use) lru = jt;
         HIPCK(hipStreamSynchronize(e->stream));
         hipGraphExecDestroy(lru->second.exec);
+        if (lru->second.d_segs) hipFree(lru->second.d_segs);
         e->graphs.erase(lru);
       }
       hipGraph_t g = nullptr;
+      std::vector<PfGeom> geoms;
       HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      e->pf_rec = &geoms;
       int r = decode_frame_impl(e, s);
       if (!r) r = backbone_step_impl(e, s, false, true, want_h);
+      e->pf_rec = nullptr;
       hipError_t ce = hipStreamEndCapture(e->stream, &g);
       if (r) {
         if (g) hipGraphDestroy(g);
@@ -840,11 +950,36 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       hipGraphExec_t ge = nullptr;
       HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       HIPCK(hipGraphDestroy(g));
-      it = e->graphs.emplace(k, GraphEntry{ge, 0}).first;
+      GraphEntry ent{};
+      ent.exec = ge;
+      if (int br = build_pf_schedule(e, geoms, ent)) return br;
+      it = e->graphs.emplace(k, ent).first;
       e->graphs_captured++;
     }
     it->second.last_use = ++e->graph_tick;
+    const bool stream_weights = e->pf_enable && e->pf_rot >= 0 && it->second.n_segs > 0;
+    e->pf_last[0] = it->second.n_segs; e->pf_last[1] = it->second.n_launch;
+    e->pf_last[2] = (long long)it->second.sched_bytes; e->pf_last[3] = (long long)it->second.step_bytes;
+    if (stream_weights) {   // the streamer runs beside the replays on stream2, paced by the launch counter
+      HIPCK(hipMemsetAsync(e->d_prog, 0, sizeof(unsigned), e->stream));
+      HIPCK(hipMemsetAsync(e->d_pf_misc, 0, 16 * sizeof(unsigned), e->stream));
+      HIPCK(hipEventRecord(e->ev_fork, e->stream));
+      HIPCK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+      PfArgs pa{};
+      pa.segs = it->second.d_segs; pa.n = it->second.n_segs; pa.n_launch = it->second.n_launch; pa.reps = n_frames;
+      pa.rot = e->pf_rot; pa.prog = e->d_prog; pa.ticket = e->d_pf_misc; pa.status = e->d_pf_misc + 8;
+      pa.budget_ticks = 2000000;   // 20 ms without a launch starting: give up (s_memrealtime runs at 100 MHz)
+      LCK(launch_weight_prefetch(e->stream2, e->pf_grid, pa));
+      HIPCK(hipEventRecord(e->ev_join, e->stream2));
+    }
     for (int i = 0; i < n_frames; ++i) HIPCK(hipGraphLaunch(it->second.exec, e->stream));
+    if (stream_weights) {
+      HIPCK(hipEventRecord(e->ev1, e->stream));
+      HIPCK(hipStreamWaitEvent(e->stream, e->ev_join, 0));   // later work on the engine stream sees the streamer finished
+      e->h_len += n_frames;
+      e->h_frame += n_frames;
+      return 0;
+    }
   } else {
     for (int i = 0; i < n_frames; ++i) {
       LCK(decode_frame_impl(e, s));
@@ -878,6 +1013,17 @@ extern "C" int csm_rewind_frames(csm_engine_t* e) {
   if (!e) return fail(CSM_ERR_ARG, "null engine");
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   e->h_frame = 0;
+  return 0;
+}
+
+extern "C" int csm_prefetch_stats(csm_engine_t* e, long long* out8_host) {
+  if (!e || !out8_host) return fail(CSM_ERR_ARG, "null argument");
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipStreamSynchronize(e->stream2));
+  unsigned st[4];
+  HIPCK(hipMemcpy(st, e->d_pf_misc + 8, sizeof(st), hipMemcpyDeviceToHost));
+  out8_host[0] = st[0]; out8_host[1] = st[1]; out8_host[2] = st[2]; out8_host[3] = e->pf_rot;
+  for (int i = 0; i < 4; ++i) out8_host[4 + i] = e->pf_last[i];
   return 0;
 }
 

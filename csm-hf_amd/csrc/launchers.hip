@@ -1,8 +1,10 @@
 // Host launchers for attention / GEMM / misc kernels.
+#define CSM_PREFETCH_KERNELS 1
 #include "attn.h"
 #include "attn_prefill.h"
 #include "gemm.h"
 #include "misc.h"
+#include "prefetch.h"
 
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
@@ -200,5 +202,15 @@ int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t
   const int grid = (int)((n / 8 + 255) / 256);
   if (wdtype == 1) hipLaunchKernelGGL((widen_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, dst, n);
   else hipLaunchKernelGGL((widen_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, dst, n);
+  return (int)hipGetLastError();
+}
+
+// ---- weight streamer (prefetch.h) ------------------------------------------------------------------------
+int launch_pf_where(hipStream_t st, unsigned* out8) {
+  hipLaunchKernelGGL(pf_where_kernel, dim3(8), dim3(256), 0, st, out8);
+  return (int)hipGetLastError();
+}
+int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a) {
+  hipLaunchKernelGGL(weight_prefetch_kernel, dim3(grid), dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }

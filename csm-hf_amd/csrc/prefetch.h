@@ -49,7 +49,7 @@ struct PfArgs {
   long long budget_ticks;  // s_memrealtime ticks (100 MHz) without progress before giving up
 };
 
-#ifndef CSM_ARGS_ONLY
+#ifdef CSM_PREFETCH_KERNELS   // defined by launchers.hip only: the kernels live in one translation unit
 __device__ __forceinline__ unsigned pf_xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
     if (skipped && x == 0 && bl == 0 && wave == 1) atomicAdd(a.status + 2, skipped);
   }
 }
-#endif  // CSM_ARGS_ONLY
+#endif  // CSM_PREFETCH_KERNELS
 
 int launch_pf_where(hipStream_t st, unsigned* out8);
 int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a);

@@ -26,7 +26,7 @@ EXPORTS = [
     "csm_get_state", "csm_generate", "csm_read_frames", "csm_frames_done", "csm_cur_len", "csm_set_kv_start",
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
-    "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy",
+    "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_rewind_frames.argtypes = [vp]
     lib.csm_graph_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.csm_kv_copy.argtypes = [vp, vp]
+    lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     if path is None:
         _lib = lib
     return lib
@@ -441,6 +442,14 @@ class Engine:
         a, b = C.c_int(), C.c_int()
         _ck(self.lib, self.lib.csm_graph_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def prefetch_stats(self) -> dict:
+        """Weight-streamer bookkeeping of the last generate() (csm_prefetch_stats)."""
+        a = (C.c_longlong * 8)()
+        _ck(self.lib, self.lib.csm_prefetch_stats(self._h, a))
+        keys = ("gave_up", "finished", "skipped_late_sample", "xcd_rotation", "segments", "streamed_launches",
+                "scheduled_bytes", "streamed_launch_bytes")
+        return dict(zip(keys, [int(v) for v in a]))
 
     def adopt_state(self, other: "Engine"):
         """Move the live context (KV caches, counters, frame ring, pending logits) of `other` into this engine."""

@@ -131,7 +131,9 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  * "use_planes" (bit mask: batched activations handed over as MFMA B-operand planes -- 1 residual stream, 2 SwiGLU
  * output, 4 attention output, 8 sampler feedback row), "fuse_sample" (greedy arg-max folded into the head launch),
  * "fuse_decoder_attention", "flash_prefill", "prefill_planes" (prefill activations handed to the GEMMs as bf16 planes),
- * "g16_gu" / "g16_down" (panel-shape overrides of the batched gate/up and down_proj launches) */
+ * "g16_gu" / "g16_down" (panel-shape overrides of the batched gate/up and down_proj launches), "weight_prefetch" (weight
+ * streamer on/off), "prefetch_window_mb" (bytes it may run ahead of the consumers, default 24), "prefetch_sub_kb"
+ * (pacing granularity), "prefetch_grid" (its workgroups, default 256) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
@@ -163,6 +165,12 @@ int csm_read_frames(csm_engine_t* e, int64_t* frames_out /* device [B,n,C] */, i
 int csm_rewind_frames(csm_engine_t* e);
 /* captured-graph bookkeeping (tests): graphs captured since creation, graphs currently cached (LRU, <= 8) */
 int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host);
+/* weight streamer (csrc/prefetch.h: a persistent kernel on a second stream that pulls the replaying graph's weights into
+ * the XCD-local L2 ahead of the launches that read them; engine options "weight_prefetch", "prefetch_window_mb",
+ * "prefetch_sub_kb", "prefetch_grid").  out8 = {workgroups that gave up, workgroups finished, segments skipped as late
+ * (one sampled wave), workgroup->XCD rotation (-1: streamer disabled), segments in the schedule, streamed launches per
+ * frame-step, scheduled bytes, bytes of all streamed launches} for the last csm_generate; syncs both streams */
+int csm_prefetch_stats(csm_engine_t* e, long long* out8_host);
 /* Move the live state of `src` (KV caches of the resident batch, lengths, frame ring, pending codebook-0 logits) into
  * `dst`, an engine of the same model with larger capacities -- the reference's DynamicCache simply grows
  * (transformers cache_utils.py:144-145); here a continuation that outgrows max_len / max_frames re-homes its cache */

@@ -155,6 +155,30 @@ def test_standalone_sampler_wide_vocabulary_and_device():
         sample_topk(big.to(DEV), 50, 1.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_streamer_is_transparent(dtype):
+    """The weight streamer (csrc/prefetch.h) only READS weights: tokens are bit-identical with it on or off, it never
+    gives up or hangs, and its schedule covers the streamed launches of the captured frame-step."""
+    cfg, sd, m = tiny_model(dtype)
+    ids, mask = synth_context(cfg, 1, 4, 6, seed=12)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    on = m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
+    st = m._engine.prefetch_stats()
+    assert 0 <= st["xcd_rotation"] < 8, "dispatch is not round-robin over the XCDs on this box: streamer disabled"
+    assert st["gave_up"] == 0 and st["finished"] > 0 and st["segments"] > 0 and st["streamed_launches"] > 100
+    assert 0 < st["scheduled_bytes"] <= st["streamed_launch_bytes"]
+    m._engine.set_option("weight_prefetch", 0)
+    off = m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
+    assert torch.equal(on, off)
+    # sampled decoding and a tiny window as well
+    m._engine.set_option("weight_prefetch", 1)
+    m._engine.set_option("prefetch_window_mb", 1)
+    a = m.generate(ids, mask, max_new_frames=5, topk=20, temperature=0.9, stop_on_all_zeros=False, seed=3).cpu()
+    m._engine.set_option("weight_prefetch", 0)
+    b = m.generate(ids, mask, max_new_frames=5, topk=20, temperature=0.9, stop_on_all_zeros=False, seed=3).cpu()
+    assert torch.equal(a, b)
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
