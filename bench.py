@@ -311,6 +311,7 @@ def main():
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     wall_max, hip_max = float(tm[0]), float(tm[1])
 
+    pf_stats = eng.prefetch_stats()
     toks = eng.read_frames(0, W + K)
     all_toks = toks
     if dist is not None:      # the only RCCL traffic: gather finished frames, off the timed path
@@ -343,6 +344,7 @@ def main():
                                    f"hipGraph={'on' if use_graph else 'off'}",
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
             "tokens_checksum_per_rank": checks,
+            "weight_streamer": pf_stats,
             "prefill_ms": round(prefill_ms, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
             "setup_s": round(t_setup, 1),

@@ -31,14 +31,19 @@ def _sources_mtime() -> float:
     return m
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _sources_mtime():
+def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+    """`defines` / `out`: A/B variants of the same ABI (e.g. ("CSM_NO_PROBE",) -> libcsm_hip_noprobe.so), selected at
+    run time with the CSM_HIP_LIB environment variable."""
+    global OBJ
+    lib_out = out or LIB
+    if not force and not defines and os.path.exists(LIB) and os.path.getmtime(LIB) >= _sources_mtime():
         return LIB
     hipcc = _hipcc()
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir = OBJ if not defines else OBJ + "_" + "_".join(defines)
+    os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(u):
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(OBJ, u + ".o")]
+        cmd = [hipcc, *FLAGS, *[f"-D{d}=1" for d in defines], "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(obj_dir, u + ".o")]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {u}.hip:\n{r.stderr[-4000:]}")
@@ -47,12 +52,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(min(len(UNITS), os.cpu_count() or 4)) as ex:
         list(ex.map(compile_one, UNITS))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(OBJ, u + ".o") for u in UNITS], "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(obj_dir, u + ".o") for u in UNITS], "-o", lib_out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    defs = tuple(a[2:] for a in sys.argv[1:] if a.startswith("-D"))
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build_library(force="--force" in sys.argv or bool(defs), verbose=True, defines=defs, out=outs[0] if outs else None))

@@ -133,7 +133,8 @@ struct csm_engine {
   float* g16_slabs = nullptr;
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
-  int nt_backbone = 1, nt_decoder = 0;
+  int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
+                                           // consumed lines are then the first victims in L2 (3.32 -> 3.30 ms per step)
   // KV splits of the backbone decode attention: the kernel is latency-bound per 32-key tile, so aim for
   // <= 2 tiles per workgroup at the current length (+ headroom for the frames of this generate call) while
   // keeping at least ~256 workgroups; frozen into the graph at capture time.
@@ -157,7 +158,14 @@ struct csm_engine {
   unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
   int pf_enable = 1, pf_window_mb = 24, pf_sub_kb = 4096, pf_grid = 256;
+  int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
+  int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
+  int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
+  int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB
   std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
+  std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
+  uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
+  int dbg_launches = 0;
   long long pf_last[4] = {0, 0, 0, 0};   // schedule of the last replayed graph: segments, launches, scheduled bytes, streamed-launch bytes
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
@@ -446,6 +454,15 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
+  else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_skip_late")) e->pf_skip_late = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 1 ? 1 : value;
+  else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
+  else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value;
+  else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value;
+  else if (!strcmp(name, "prefetch_stride")) e->pf_stride = (value == 32 || value == 64 || value == 128 || value == 256) ? value : 0;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -520,8 +537,9 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     PfGeom geom{};
     geom.kind = -1;
     if (e->pf_rec) { a.prog = e->d_prog; a.geom_out = &geom; }   // capture: this launch is paced / streamed (prefetch.h)
+    if (e->pf_rec && e->dbg_buf && (int)e->pf_rec->size() < e->dbg_launches) a.dbg = e->dbg_buf + e->pf_rec->size() * 4096;
     const int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
-    a.prog = nullptr; a.geom_out = nullptr;
+    a.prog = nullptr; a.geom_out = nullptr; a.dbg = nullptr;
     if (r) return r;
     if (e->pf_rec) e->pf_rec->push_back(geom);
     m0 += m;
@@ -866,7 +884,13 @@ static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, Gr
     int bps = (int)((sub + per_block - 1) / per_block);
     bps = (bps + 7) & ~7;
     if (bps < 8) bps = 8;
+    const size_t total = (size_t)g.N * rb;
+    size_t limit = total;
+    if (e->pf_max_kb > 0 && total > ((size_t)e->pf_max_kb << 10)) limit = (size_t)e->pf_part_kb << 10;
+    size_t done = 0;
     for (int b0 = 0; b0 < g.grid; b0 += bps) {
+      if (done >= limit) break;
+      done += (size_t)(std::min(g.grid, b0 + bps) - b0) * per_block;
       PfSeg sg{};
       sg.W = (const char*)g.W; sg.row_bytes = (uint32_t)rb; sg.N = g.N; sg.kind = g.kind; sg.tpb = g.tpb; sg.iters = g.iters;
       sg.stride = g.stride; sg.ntask = g.ntask; sg.hd = g.hd > 1 ? g.hd : 2; sg.n_rope_heads = g.n_rope_heads;
@@ -888,13 +912,15 @@ static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, Gr
     for (int steps = 0; steps < n - 1; ++steps) {
       int jj = j;
       if (jj < 0) { jj += n; wrap = 1; } else wrap = 0;
-      if (acc + bytes[jj] > window) { need = segs[jj].owner + 1 - (wrap || j < 0 ? ent.n_launch : 0); break; }
+      if (acc + bytes[jj] > window) { need = segs[jj].owner + 1 - e->pf_lead - (wrap || j < 0 ? ent.n_launch : 0); break; }
       acc += bytes[jj];
       --j;
       if (steps == n - 2) all = true;
     }
     if (all || n == 1) need = -(1 << 29);    // a whole frame-step fits the window
-    if (need > segs[i].owner) continue;   // could only be fetched after its own consumer started
+    // a run that could only be fetched once its own consumer has started is left to the consumer; co-fetch keeps the
+    // runs that become fetchable exactly when their consumer starts (the streamer then reads beside the consumer)
+    if (need > segs[i].owner || (need == segs[i].owner && !e->pf_cofetch)) continue;
     segs[i].need = need;
     keep.push_back(segs[i]);
     ent.sched_bytes += bytes[i];
@@ -952,6 +978,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       HIPCK(hipGraphDestroy(g));
       GraphEntry ent{};
       ent.exec = ge;
+      e->last_geoms = geoms;
       if (int br = build_pf_schedule(e, geoms, ent)) return br;
       it = e->graphs.emplace(k, ent).first;
       e->graphs_captured++;
@@ -969,6 +996,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       pa.segs = it->second.d_segs; pa.n = it->second.n_segs; pa.n_launch = it->second.n_launch; pa.reps = n_frames;
       pa.rot = e->pf_rot; pa.prog = e->d_prog; pa.ticket = e->d_pf_misc; pa.status = e->d_pf_misc + 8;
       pa.budget_ticks = 2000000;   // 20 ms without a launch starting: give up (s_memrealtime runs at 100 MHz)
+      pa.skip_late = e->pf_skip_late; pa.poll_sleep = e->pf_poll_sleep; pa.depth = e->pf_depth; pa.seg_sleep = e->pf_seg_sleep; pa.stride = e->pf_stride;
       LCK(launch_weight_prefetch(e->stream2, e->pf_grid, pa));
       HIPCK(hipEventRecord(e->ev_join, e->stream2));
     }
@@ -1013,6 +1041,29 @@ extern "C" int csm_rewind_frames(csm_engine_t* e) {
   if (!e) return fail(CSM_ERR_ARG, "null engine");
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   e->h_frame = 0;
+  return 0;
+}
+
+// debug probe: streamed launch i of the next captured frame-step writes {XCD id, clocks until its weights were consumed}
+// per workgroup into buf[i][2048][2] (uint32); pass NULL to stop.  Drops the cached graphs.
+extern "C" int csm_set_debug_buffer(csm_engine_t* e, uint32_t* buf, int n_launches) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  e->dbg_buf = buf;
+  e->dbg_launches = buf ? n_launches : 0;
+  drop_graphs(e);
+  return 0;
+}
+
+// geometry of the streamed launches of the last captured frame-step: out[i] = {N, K, grid, tasks per workgroup, kind}
+extern "C" int csm_last_geoms(csm_engine_t* e, int32_t* out_host, int max_launches, int* n_host) {
+  if (!e || !out_host || !n_host) return fail(CSM_ERR_ARG, "null argument");
+  const int n = std::min((int)e->last_geoms.size(), max_launches);
+  for (int i = 0; i < n; ++i) {
+    const PfGeom& g = e->last_geoms[i];
+    int32_t* o = out_host + 5 * i;
+    o[0] = g.N; o[1] = g.K; o[2] = g.grid; o[3] = g.tpb; o[4] = g.kind;
+  }
+  *n_host = n;
   return 0;
 }
 

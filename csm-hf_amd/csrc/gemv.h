@@ -88,6 +88,10 @@ struct GemvArgs {
   // the launcher fills with this launch's workgroup -> rows geometry
   unsigned* prog;
   PfGeom* geom_out;
+
+  // debug (tools/streamer_probe.py): per workgroup {XCD id, shader clocks from kernel entry until the weights were
+  // consumed} of this launch, [grid][2] uint32; nullable
+  uint32_t* dbg;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -251,12 +255,19 @@ struct GemvEpi {
 // own registers (K floats -- cheaper than a workgroup barrier).  Grid = all tasks (one per wave), so a
 // matrix of <= 64 KiB per CU is entirely in flight at once.  K must equal 512*U*KS.
 // ---------------------------------------------------------------------------------------------------
+// amdgpu_waves_per_eu(1, 4): without it the compiler aims at 8 waves per SIMD (64 VGPRs) and, to get there, SINKS
+// loads below the RMS prologue (the last norm-weight loads were issued one by one behind the statistic: three extra
+// dependent L2 round trips per normed launch).  These launches run at <= 4 waves per SIMD anyway (192 .. 1024
+// workgroups on 256 CUs), so registers are free: every load of a wave is issued before anything is consumed.
 template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T>
-__global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GemvArgs a) {
   __shared__ float part[4][2 * T];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
+#ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
+  const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+#endif
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
@@ -367,6 +378,12 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       xp[u][3] = (xp[u][3] * sc2) * f32x2{lb[u][2], lb[u][3]};
     }
   }
+#ifdef CSM_PROBE
+  // T1: the activations (and, for normed launches, the RMS statistic) are in registers
+  const float probe_x = xp[0][0][0] + xp[U - 1][3][1];
+  asm volatile("" :: "v"(probe_x));
+  const unsigned long long dbg_t1 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+#endif
   float s0[T], s1[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -383,6 +400,14 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     s1[t] = c1[0] + c1[1];
     wave_sum2(s0[t], s1[t]);
   }
+#ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
+  if (a.dbg && tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.dbg[2 * blockIdx.x] = (xcc & 15u) | ((uint32_t)(dbg_t1 - dbg_t0) << 8);   // bits 8..: clocks until the activations arrived
+    a.dbg[2 * blockIdx.x + 1] = (uint32_t)(__builtin_readcyclecounter() - dbg_t0);
+  }
+#endif
   if (KS > 1) {
     if (lane == 0) {
 #pragma unroll

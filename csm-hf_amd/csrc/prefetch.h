@@ -47,6 +47,14 @@ struct PfArgs {
   unsigned* ticket;        // [8] per-XCD arrival counters, zeroed before the launch
   unsigned* status;        // [0] workgroups that gave up, [1] finished, [2] segments skipped as late (workgroup 0 of XCD 0)
   long long budget_ticks;  // s_memrealtime ticks (100 MHz) without progress before giving up
+  int skip_late;           // 1: a segment whose consumer has already started is skipped
+  int poll_sleep;          // s_sleep units between two polls of the launch counter
+  int seg_sleep;           // s_sleep units every loader wave idles before each segment (rate limiter)
+  int stride;              // 0: contiguous 16-byte loads (every byte crosses the CU);  64 | 128: ONE dword per `stride`
+                           // bytes -- the L2 fills whole lines, the CU receives 1/16 or 1/32 of the bytes
+  int depth;               // prefetch loads (1 KiB each) a loader wave keeps in flight: 4 | 8 | 16 | 32, else unlimited.
+                           // An unthrottled streamer floods the memory queues and the chain's latency-critical loads
+                           // (activations, a few KB per launch) wait behind it
 };
 
 #ifdef CSM_PREFETCH_KERNELS   // defined by launchers.hip only: the kernels live in one translation unit
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
         if (lane == 0) { *v_state = 2; atomicAdd(a.status, 1u); }
         return;
       }
-      __builtin_amdgcn_s_sleep(2);
+      for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
     }
     if (lane == 0) atomicAdd(a.status + 1, 1u);
     return;
@@ -99,10 +107,15 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
   const unsigned slot = bl * 3u + (unsigned)(wave - 1), nslot = nl * 3u;
   auto* ldst = (__attribute__((address_space(3))) void*)(dump + wave * 1024);
   unsigned skipped = 0;
+  PfSeg nxt = a.segs[0];
   for (int rep = 0; rep < a.reps; ++rep) {
     const int base = rep * a.n_launch;
     for (int e = 0; e < a.n; ++e) {
-      const PfSeg* sp = a.segs + e;
+      // the descriptor of the NEXT segment is requested (scalar loads) before this one is processed: a dependent
+      // ~1 us descriptor fetch per segment would cap the streamer at a few MB per microsecond
+      const PfSeg seg = nxt;
+      nxt = a.segs[e + 1 < a.n ? e + 1 : 0];
+      const PfSeg* sp = &seg;
       const int want = base + sp->need;
       int cur = *v_cur;
       while (cur < want) {
@@ -110,7 +123,8 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
         __builtin_amdgcn_s_sleep(1);
         cur = *v_cur;
       }
-      if (cur > base + sp->owner) { ++skipped; continue; }   // its consumer is already running: leave it alone
+      if (a.skip_late && cur > base + sp->owner) { ++skipped; continue; }   // its consumer is already running: leave it alone
+      for (int z = 0; z < a.seg_sleep; z += 8) __builtin_amdgcn_s_sleep(8);
       const int b0 = sp->b0, b1 = sp->b1, tpb = sp->tpb, iters = sp->iters, ntask = sp->ntask, N = sp->N;
       const unsigned rb = sp->row_bytes;
       const char* W = sp->W;
@@ -119,7 +133,8 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
       if (bf >= b1) continue;
       const unsigned nbx = (unsigned)(b1 - bf + 7) >> 3;
       const unsigned FB = 2u * (unsigned)tpb * rb;                 // footprint of one (workgroup, iteration)
-      const unsigned ppb = (FB + 4095u) >> 12;
+      const unsigned PB = a.stride ? 64u * (unsigned)a.stride : 4096u;   // bytes one unit covers
+      const unsigned ppb = (FB + PB - 1u) / PB;
       const unsigned n_units = nbx * (unsigned)iters * ppb;
       const int half = sp->hd >> 1;
       for (unsigned u = slot; u < n_units; u += nslot) {
@@ -149,14 +164,29 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
           const int rows = min(2 * nt, N - 2 * t0);
           fb = (unsigned)rows * rb;
         }
+        if (a.stride) {
+          unsigned vo = piece * PB + (unsigned)lane * (unsigned)a.stride;
+          if (piece * PB < fb) {
+            if (vo >= fb) vo = 0;
+            const char* src = W + (vo >= split ? base1 + (vo - split) : base0 + vo);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, ldst, 4, 0, 0);
+          }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned vo = piece * 4096u + (unsigned)j * 1024u + (unsigned)lane * 16u;
-          if (piece * 4096u + (unsigned)j * 1024u >= fb) break;    // wave-uniform
-          if (vo >= fb) vo = 0;
-          const char* src = W + (vo >= split ? base1 + (vo - split) : base0 + vo);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, ldst, 16, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            unsigned vo = piece * 4096u + (unsigned)j * 1024u + (unsigned)lane * 16u;
+            if (piece * 4096u + (unsigned)j * 1024u >= fb) break;    // wave-uniform
+            if (vo >= fb) vo = 0;
+            const char* src = W + (vo >= split ? base1 + (vo - split) : base0 + vo);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, ldst, 16, 0, 0);
+          }
         }
+        // throttle: at most `depth` loads of this wave outstanding before the next unit is issued
+        if (a.depth == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (a.depth == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (a.depth == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (a.depth == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (a.depth == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
   }

@@ -27,6 +27,7 @@ EXPORTS = [
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
+    "csm_set_debug_buffer", "csm_last_geoms",
 ]
 
 
@@ -118,6 +119,8 @@ def load_library(path: Optional[str] = None):
     lib.csm_graph_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.csm_kv_copy.argtypes = [vp, vp]
     lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.csm_set_debug_buffer.argtypes = [vp, vp, i32]
+    lib.csm_last_geoms.argtypes = [vp, C.POINTER(C.c_int32), i32, C.POINTER(i32)]
     if path is None:
         _lib = lib
     return lib
@@ -450,6 +453,16 @@ class Engine:
         keys = ("gave_up", "finished", "skipped_late_sample", "xcd_rotation", "segments", "streamed_launches",
                 "scheduled_bytes", "streamed_launch_bytes")
         return dict(zip(keys, [int(v) for v in a]))
+
+    def set_debug_buffer(self, buf: Optional[torch.Tensor], n_launches: int = 0):
+        self._dbg_keep = buf
+        _ck(self.lib, self.lib.csm_set_debug_buffer(self._h, _ptr(buf), int(n_launches)))
+
+    def last_geoms(self, max_launches: int = 1024):
+        a = (C.c_int32 * (5 * max_launches))()
+        n = C.c_int()
+        _ck(self.lib, self.lib.csm_last_geoms(self._h, a, max_launches, C.byref(n)))
+        return [tuple(a[5 * i:5 * i + 5]) for i in range(n.value)]
 
     def adopt_state(self, other: "Engine"):
         """Move the live context (KV caches, counters, frame ring, pending logits) of `other` into this engine."""

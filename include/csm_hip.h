@@ -171,6 +171,11 @@ int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host)
  * (one sampled wave), workgroup->XCD rotation (-1: streamer disabled), segments in the schedule, streamed launches per
  * frame-step, scheduled bytes, bytes of all streamed launches} for the last csm_generate; syncs both streams */
 int csm_prefetch_stats(csm_engine_t* e, long long* out8_host);
+/* debug probes of the weight streamer (tools/streamer_probe.py): per-workgroup {XCD id, clocks until the weights were
+ * consumed} of the first n streamed launches of the next captured frame-step -> buf[n][2048][2] uint32 (device);
+ * geometry {N, K, grid, tasks per workgroup, kind} of the streamed launches of the last captured frame-step */
+int csm_set_debug_buffer(csm_engine_t* e, uint32_t* buf, int n_launches);
+int csm_last_geoms(csm_engine_t* e, int32_t* out_host, int max_launches, int* n_host);
 /* Move the live state of `src` (KV caches of the resident batch, lengths, frame ring, pending codebook-0 logits) into
  * `dst`, an engine of the same model with larger capacities -- the reference's DynamicCache simply grows
  * (transformers cache_utils.py:144-145); here a continuation that outgrows max_len / max_frames re-homes its cache */
