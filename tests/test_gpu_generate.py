@@ -302,10 +302,15 @@ def test_csm1b_config2_200_frames(gold, csm1b_bf16):
     n = g["tokens"].shape[1]
     toks, _, _ = traced_generate(m, ids, mask, n)
     compared = margin_check(toks, g, 1e-4)
-    # every sample of the fixture clears the margin (min top-1 margin of the stream is recorded in the file), so the
-    # whole 6 400-token stream must match, not a prefix
-    assert float(g["min_margin"]) > 1e-4 and compared == 32 * n == 6400
-    assert np.array_equal(toks.numpy(), g["tokens"])
+    # the whole 6 400-token stream must match, not a prefix: the only licence to differ is AT a sample whose reference
+    # top-1 margin is below 1e-4 (the stream has one at 1.5e-6; the engine agrees with the reference there too)
+    margin = (g["top_vals"][..., 0] - g["top_vals"][..., 1])[:, 0].reshape(-1)
+    low = np.nonzero(margin < 1e-4)[0]
+    assert compared == (int(low[0]) if len(low) else 32 * n) and 32 * n == 6400
+    mine, ref = toks.numpy().reshape(-1), g["tokens"].reshape(-1)
+    diff = np.nonzero(mine != ref)[0]
+    assert len(diff) == 0 or margin[diff[0]] < 1e-4, f"first mismatch at sample {diff[0]} with margin {margin[diff[0]]}"
+    assert len(diff) == 0, "free-running stream left the reference at a near-tie (allowed by the margin rule, but new)"
     # teacher-forced over all 200 frames: argmax equals the reference wherever its margin > 1e-3
     toks_f, lt_f, _ = traced_generate(m, ids, mask, n, forced=torch.from_numpy(g["tokens"]))
     margin = g["top_vals"][..., 0] - g["top_vals"][..., 1]
