@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   const int j = blk % a.n_kv;
   const int row = blk / a.n_kv;
   const int b = a.row_seq ? a.row_seq[row] : row;
-  const int pos = a.row_pos ? a.row_pos[row] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+  const int pos = row_position(a.row_pos, row, a.pos_ptr, a.pos_const);
   const int t_lo0 = a.kv_start ? a.kv_start[b] : 0;
   const int len = pos + 1 - t_lo0;
   int span = (len + a.nsplit - 1) / a.nsplit;

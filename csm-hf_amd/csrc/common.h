@@ -246,6 +246,16 @@ __device__ __forceinline__ void store_planes4(bf16_t* planes, size_t plane_strid
 // for every weight load in flight; use this one between a prologue's LDS exchange and the weight consumption.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Position of a row: per-row table | device scalar (backbone length) | launch constant (decoder pass).  Written as
+// branches around VOLATILE loads on purpose: from `p ? *p : (q ? *q : c)` the compiler built ONE load through a selected
+// pointer and parked the constant in scratch memory to have something to point at -- a dependent scratch round trip
+// (~1 500 clocks) ahead of every load of the QKV launches, constant-position decoder passes included.
+__device__ __forceinline__ int row_position(const int* row_pos, int m, const int* pos_ptr, int pos_const) {
+  if (row_pos) return *reinterpret_cast<const volatile int*>(row_pos + m);
+  if (pos_ptr) return *reinterpret_cast<const volatile int*>(pos_ptr);
+  return pos_const;
+}
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
 

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
         if (mm < M && n < a.N) {
           if (EPI == EPI_QKV) {
-            ppos[e] = a.row_pos ? a.row_pos[mm] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+            ppos[e] = row_position(a.row_pos, mm, a.pos_ptr, a.pos_const);
             const int half = a.hd >> 1, spp = half / 16;
             const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
             if (t == 0 && head < a.n_q + a.n_kv) {

@@ -111,7 +111,7 @@ __device__ __forceinline__ void attn_short_to_lds(const GemvArgs& a, int m, floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = a.n_q / a.n_kv;
   const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
-  const int pos = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
+  const int pos = row_position(a.row_pos, m, a.pos_ptr, a.pos_const);
   const int cnt = pos + 1;  // <= 32
   const int hpw = (a.n_q + 3) >> 2;
   const int h0 = wave * hpw, h1 = min(a.n_q, h0 + hpw);
@@ -189,13 +189,20 @@ struct GemvEpi {
         a0[m] = a.out[(size_t)m * a.ldo + k.r0];
         if (k.has1) a1[m] = a.out[(size_t)m * a.ldo + k.r1];
       } else if (EPI == EPI_QKV) {
-        pos[m] = a.row_pos ? a.row_pos[m] : (a.pos_ptr ? *a.pos_ptr : a.pos_const);
-        if (k.head < a.n_q + a.n_kv) {
-          const int half = a.hd >> 1;
-          a0[m] = a.cos_tab[(size_t)pos[m] * half + k.hi];
-          a1[m] = a.sin_tab[(size_t)pos[m] * half + k.hi];
-        }
+        pos[m] = row_position(a.row_pos, m, a.pos_ptr, a.pos_const);   // consumed by prefetch_late
       }
+    }
+  }
+  // EPI_QKV: cos/sin of the row position.  Issued BEHIND the weight loads: their address depends on a loaded position
+  // (backbone: the device-resident length), and vmcnt retires in issue order -- requested first, that dependent
+  // round trip stood in front of every other load of the launch; requested last, it hides under the weight stream.
+  __device__ __forceinline__ void prefetch_late(const GemvArgs& a, const GemvTask& k) {
+    if (EPI != EPI_QKV || !k.live || k.head >= a.n_q + a.n_kv) return;
+    const int half = a.hd >> 1;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      a0[m] = a.cos_tab[(size_t)pos[m] * half + k.hi];
+      a1[m] = a.sin_tab[(size_t)pos[m] * half + k.hi];
     }
   }
   // one lane writes the two outputs of the task for batch row m
@@ -264,10 +271,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   __shared__ float part[4][2 * T];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
 #ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
-  const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long dbg_t0 = __builtin_readcyclecounter();   // before the first kernel argument is read
 #endif
+  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
   const int ntask = (EPI == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
@@ -279,8 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   // vmcnt retires in issue order: the x slice and the norm weights (L2 hits, consumed first by the RMS
   // prologue) are requested ahead of the weight stream so the prologue runs while the weights are in flight.
   // PRO_TOKNORM cannot: its x row address depends on the argmax below, so there the weights go first.
-  // The epilogue prefetch goes first of all: EPI_QKV's cos/sin addresses depend on the position it loads, and at
-  // M = 1 the residual values requested behind the weights arrive too late (dec o_proj 3.13 vs 2.94 us).
+  // The epilogue prefetch goes first of all: at M = 1 the residual values requested behind the weights arrive too
+  // late (dec o_proj 3.13 vs 2.94 us); EPI_QKV requests only its position here and the cos/sin row behind the weights.
   f32x4 xa[U], xb[U], la[U], lb[U];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -310,6 +317,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       if (a.nt) { w0[t][u].load_nt(w0p + u * 512); w1[t][u].load_nt(w1p + u * 512); }
       else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
     }
+  }
+  if (EPI == EPI_QKV && kw == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) epi[t].prefetch_late(a, k[t]);
   }
   // (The machine scheduler sinks half of these loads below the RMS prologue to stay at 63 VGPRs = 8 waves per
   // SIMD; pinning them here with __builtin_amdgcn_sched_barrier(0) costs 69 VGPRs and measured the same: with
@@ -501,6 +512,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   }
   issue(ta, wa0, wa1, 0);  // in flight while the prologue runs
   if (iters > 1) issue(tb, wb0, wb1, 0);
+  if (kw == 0) {
+    ea.prefetch_late(a, ta);
+    if (iters > 1) eb.prefetch_late(a, tb);
+  }
 
   // ---- prologue: stage x into LDS (plain | RMS-normalised | short-cache attention output) -----------
   if (PRO == PRO_ATTN) {
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     t = gemv_map_task<EPI>(a, cur.task + 2 * stride, ntask);
     if (more) {
       issue(t, w0, w1, 0);
-      if (kw == 0) ep.prefetch(a, t);
+      if (kw == 0) { ep.prefetch(a, t); ep.prefetch_late(a, t); }
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) wave_sum2(acc0[m], acc1[m]);

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the probe is compiled in only in the -DCSM_PROBE variant of the library (even a disabled probe costs 6 % per frame)
-PROBE_LIB = os.path.join(ROOT, "csm-hf_amd", "libcsm_hip_probe.so")
+PROBE_LIB = os.environ.get("CSM_PROBE_LIB") or os.path.join(ROOT, "csm-hf_amd", "libcsm_hip_probe.so")
 if not os.path.exists(PROBE_LIB):
     from csm_hf_amd.build import build_library
     build_library(force=True, defines=("CSM_PROBE",), out=PROBE_LIB)
@@ -76,7 +76,9 @@ print("\nfirst 48 streamed launches: (N, K) mean clocks off -> on")
 for i in range(min(48, len(geoms))):
     N, K, grid, tpb, kind = geoms[i]
     g = min(grid, 2048)
-    print(f"  {i:3d} ({N:5d},{K:5d}) grid {grid:4d}: {float(res[0][i, :g, 1].float().mean()):7.0f} -> {float(res[1][i, :g, 1].float().mean()):7.0f}")
+    print(f"  {i:3d} ({N:5d},{K:5d}) grid {grid:4d}: {float(res[0][i, :g, 1].float().mean()):7.0f} -> {float(res[1][i, :g, 1].float().mean()):7.0f}"
+          f"   activations in at {float((res[0][i, :g, 0] >> 8).float().mean()):6.0f} -> {float((res[1][i, :g, 0] >> 8).float().mean()):6.0f}"
+          f"   min/max over workgroups (on) {int(res[1][i, :g, 1].min())}/{int(res[1][i, :g, 1].max())}")
 for shape in ((16384, 1024), (1024, 8192), (2048, 8192), (1536, 1024)):
     idx = [i for i, gm in enumerate(geoms) if (gm[0], gm[1]) == shape and i < NL]
     if len(idx) < 12:
