@@ -159,6 +159,7 @@ struct csm_engine {
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
   int pf_enable = 1, pf_window_mb = 24, pf_sub_kb = 4096, pf_grid = 256;
   int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
+  int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
   int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
   int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB
@@ -166,7 +167,8 @@ struct csm_engine {
   std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
   uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
   int dbg_launches = 0;
-  long long pf_last[4] = {0, 0, 0, 0};   // schedule of the last replayed graph: segments, launches, scheduled bytes, streamed-launch bytes
+  long long pf_last[4] = {0, 0, 0, 0};
+  int pf_last_frames = 0;   // schedule of the last replayed graph: segments, launches, scheduled bytes, streamed-launch bytes
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   std::vector<void*> allocs;
@@ -225,10 +227,13 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   csm_engine* e = new csm_engine();
   e->cfg = *cfg;
   e->device = device;
+  int prio_least = 0, prio_greatest = 0;
+  HIPCK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   if (stream) {
     e->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
-    HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // highest priority: streams of different priority classes never share a hardware queue with the weight streamer
+    HIPCK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_greatest));
     e->own_stream = true;
   }
   HIPCK(hipEventCreate(&e->ev0));
@@ -298,7 +303,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   // weight streamer: second stream, fork/join events, launch counter, and the dispatcher's workgroup -> XCD rotation
-  HIPCK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+  HIPCK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_least));
   HIPCK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   if ((r = dalloc(e, &e->d_prog, 16)) || (r = dalloc(e, &e->d_pf_misc, 64))) return r;
@@ -312,6 +317,16 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     bool rr = true;
     for (int b = 0; b < 8; ++b) rr = rr && where[b] == ((where[0] + b) & 7u);
     e->pf_rot = rr ? (int)where[0] : -1;
+    // the streamer must run BESIDE the engine stream: a waiter on stream2 has to see a flag raised by a kernel
+    // submitted later on the engine stream.  If the two streams share a hardware queue it times out (3 ms): streamer off.
+    unsigned seen = 0;
+    HIPCK(hipMemsetAsync(e->d_pf_misc + 32, 0, 2 * sizeof(unsigned), e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    LCK(launch_pf_concurrency_probe(e->stream2, e->stream, e->d_pf_misc + 32, e->d_pf_misc + 33));
+    HIPCK(hipStreamSynchronize(e->stream2));
+    HIPCK(hipStreamSynchronize(e->stream));
+    HIPCK(hipMemcpy(&seen, e->d_pf_misc + 33, sizeof(seen), hipMemcpyDeviceToHost));
+    if (!seen) e->pf_rot = -1;
   }
   HIPCK(hipStreamSynchronize(e->stream));
   *out = e;
@@ -455,6 +470,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
   else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_skip_late")) e->pf_skip_late = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 1 ? 1 : value;
@@ -523,10 +539,18 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       const int m = left < 16 ? left : 16;
       slice(m);
       if (!a.Wt) a.xplanes = nullptr;   // unbound weights (hooks): fp32 activations
+      PfGeom geom{};
+      geom.kind = -1;
+      // capture of a single-group batch (M <= 16): the launch is paced / streamed (prefetch.h); larger batches re-stream
+      // every matrix once per group and are left alone
+      const bool rec = e->pf_rec && M <= 16 && e->pf_batched;
+      if (rec) { a.prog = e->d_prog; a.geom_out = &geom; }
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
+      a.prog = nullptr; a.geom_out = nullptr;
       if (r != -2) {
         if (r) return r;
+        if (rec) e->pf_rec->push_back(geom);
         m0 += m;
         continue;
       }
@@ -873,18 +897,24 @@ extern "C" int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logit
 static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, GraphEntry& ent) {
   ent.n_launch = (int)geoms.size();
   if (geoms.empty()) return 0;
+  for (const PfGeom& g : geoms)
+    if (g.exclusive) return 0;   // a launch that needs whole CUs to itself: the streamer would hold the chain up (gemm16.h)
   std::vector<PfSeg> segs;
   std::vector<size_t> bytes;
   const size_t sub = (size_t)e->pf_sub_kb << 10;
   for (int li = 0; li < (int)geoms.size(); ++li) {
     const PfGeom& g = geoms[li];
     if (g.kind < 0 || !g.W || g.grid < 1 || g.tpb < 1) continue;
-    const size_t rb = (size_t)g.K * g.esz;
-    const size_t per_block = (size_t)g.iters * 2 * g.tpb * rb;
+    size_t rb = (size_t)g.K * g.esz;
+    size_t per_block = (size_t)g.iters * 2 * g.tpb * rb;
+    if (g.kind == 2) {   // fragment-order copy: bytes of one (tile, chunk) block; a workgroup reads tpb x iters of them
+      rb = (size_t)2048 * g.esz;
+      per_block = (size_t)g.tpb * g.iters * rb;
+    }
     int bps = (int)((sub + per_block - 1) / per_block);
     bps = (bps + 7) & ~7;
     if (bps < 8) bps = 8;
-    const size_t total = (size_t)g.N * rb;
+    const size_t total = g.kind == 2 ? (size_t)g.grid * per_block : (size_t)g.N * rb;
     size_t limit = total;
     if (e->pf_max_kb > 0 && total > ((size_t)e->pf_max_kb << 10)) limit = (size_t)e->pf_part_kb << 10;
     size_t done = 0;
@@ -985,6 +1015,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
     }
     it->second.last_use = ++e->graph_tick;
     const bool stream_weights = e->pf_enable && e->pf_rot >= 0 && it->second.n_segs > 0;
+    e->pf_last_frames = n_frames;
     e->pf_last[0] = it->second.n_segs; e->pf_last[1] = it->second.n_launch;
     e->pf_last[2] = (long long)it->second.sched_bytes; e->pf_last[3] = (long long)it->second.step_bytes;
     if (stream_weights) {   // the streamer runs beside the replays on stream2, paced by the launch counter
@@ -1067,14 +1098,20 @@ extern "C" int csm_last_geoms(csm_engine_t* e, int32_t* out_host, int max_launch
   return 0;
 }
 
-extern "C" int csm_prefetch_stats(csm_engine_t* e, long long* out8_host) {
-  if (!e || !out8_host) return fail(CSM_ERR_ARG, "null argument");
+extern "C" int csm_prefetch_stats(csm_engine_t* e, long long* out10_host) {
+  if (!e || !out10_host) return fail(CSM_ERR_ARG, "null argument");
   HIPCK(hipStreamSynchronize(e->stream));
   HIPCK(hipStreamSynchronize(e->stream2));
-  unsigned st[4];
+  unsigned st[4], prog = 0;
   HIPCK(hipMemcpy(st, e->d_pf_misc + 8, sizeof(st), hipMemcpyDeviceToHost));
-  out8_host[0] = st[0]; out8_host[1] = st[1]; out8_host[2] = st[2]; out8_host[3] = e->pf_rot;
-  for (int i = 0; i < 4; ++i) out8_host[4 + i] = e->pf_last[i];
+  HIPCK(hipMemcpy(&prog, e->d_prog, sizeof(prog), hipMemcpyDeviceToHost));
+  out10_host[0] = st[0]; out10_host[1] = st[1]; out10_host[2] = st[2]; out10_host[3] = e->pf_rot;
+  for (int i = 0; i < 4; ++i) out10_host[4 + i] = e->pf_last[i];
+  out10_host[8] = prog;            // launches counted since the last csm_generate began
+  out10_host[9] = e->pf_last_frames;
+  unsigned dbg[4];
+  HIPCK(hipMemcpy(dbg, e->d_pf_misc + 12, sizeof(dbg), hipMemcpyDeviceToHost));
+  snprintf(g_err, sizeof(g_err), "streamer stop record: segment %u want %u seen %u rep %u", dbg[0], dbg[1], dbg[2], dbg[3]);
   return 0;
 }
 

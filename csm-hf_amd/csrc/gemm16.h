@@ -104,6 +104,10 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // split arithmetic ahead of the MFMAs; the RMS scale of row m is applied in the epilogue from the producer's per-tile
 // sums of squares.  An ablation without the x / norm-weight loads and their arithmetic ran the B = 16 step in 4.57 ms
 // instead of 5.75 ms -- that chain, not the weight stream, was the critical path of the small launches.  XP needs TL.
+// NOTE on the 16-wave (1024-thread) variants: at 113-128 registers their four waves per SIMD take the whole 512-entry
+// register file of every SIMD of a CU, so such a workgroup only starts on a CU with nothing else resident.  The weight
+// streamer (prefetch.h) keeps a wave on every SIMD of every CU, so a frame-step that contains one of these launches is
+// not streamed (launch_g16 reports `exclusive`); capping them at 96 registers (5 waves per SIMD) spills 24-58 registers.
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL, bool XP>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag[16] | stat[NW][16]
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   int* flag = reinterpret_cast<int*>(panel + PT * 256);
   float* stat = panel + PT * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing
   const int K = a.K;
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const int m = lane & 15, g = lane >> 4;

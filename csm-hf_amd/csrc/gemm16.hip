@@ -10,6 +10,22 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16 + NW * 16) * sizeof(float);
   if (a.xplanes && !a.Wt) return -2;   // planes are laid out for the fragment-order k order
+  if (a.geom_out && a.Wt) {            // weight streamer (prefetch.h, kind 2): workgroup (bx, by) -> fragment blocks
+    PfGeom& g = *a.geom_out;
+    g.W = a.Wt; g.N = a.N; g.K = a.K; g.esz = (int)sizeof(WT); g.kind = 2;
+    g.grid = gx * KB; g.tpb = PT; g.iters = NW; g.stride = gx; g.ntask = a.K / 128;
+    g.hd = a.hd; g.n_rope_heads = (EPI == EPI_QKV) ? a.n_q + a.n_kv : 0;
+    // does a workgroup of this launch leave room for one streamer wave per SIMD?  (registers are allocated in blocks of 8)
+    hipFuncAttributes fa{};
+    const void* fn = a.xplanes ? (const void*)gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>
+                               : (const void*)gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
+      const int alloc = (fa.numRegs + 7) & ~7, per_simd = (NW + 3) / 4;
+      g.exclusive = per_simd * alloc + ((PF_STREAMER_VGPRS + 7) & ~7) > 512;
+    } else {
+      g.exclusive = NW >= 16;
+    }
+  }
   if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);

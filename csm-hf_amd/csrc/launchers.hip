@@ -210,6 +210,11 @@ int launch_pf_where(hipStream_t st, unsigned* out8) {
   hipLaunchKernelGGL(pf_where_kernel, dim3(8), dim3(256), 0, st, out8);
   return (int)hipGetLastError();
 }
+int launch_pf_concurrency_probe(hipStream_t waiter_stream, hipStream_t setter_stream, unsigned* flag, unsigned* out) {
+  hipLaunchKernelGGL(pf_wait_kernel, dim3(1), dim3(1), 0, waiter_stream, flag, out, (long long)300000);   // 3 ms
+  hipLaunchKernelGGL(pf_set_kernel, dim3(1), dim3(1), 0, setter_stream, flag);
+  return (int)hipGetLastError();
+}
 int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a) {
   hipLaunchKernelGGL(weight_prefetch_kernel, dim3(grid), dim3(256), 0, st, a);
   return (int)hipGetLastError();

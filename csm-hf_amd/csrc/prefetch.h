@@ -23,11 +23,17 @@ struct PfGeom {
   const void* W;   // row-major [N][K]
   int N, K, esz;
   int kind;        // 0: task t -> rows 2t, 2t+1;  1: QKV epilogue (RoPE pairs, gemv.h gemv_map_task);  -1: not streamed
+                   // 2: matrix-core skinny GEMM on the fragment-order copy (gemm16.h): W = the copy, grid = gx * KB
+                   //    linear workgroups (x fastest), tpb = PT tiles per panel, iters = NW chunks per workgroup,
+                   //    stride = gx, ntask = K / 128 chunks per tile row, K * esz / (K / 128) = bytes per chunk;
+                   //    n_rope_heads > 0 marks the QKV panel -> tile map (g16_row)
   int grid, tpb;   // workgroup b, iteration it covers tasks [b*tpb + it*stride, +tpb)
   int iters, stride;
   int ntask;
   int hd, n_rope_heads;   // kind 1: head_dim, n_q + n_kv
+  int exclusive;          // this launch's workgroups fill a CU's register file: nothing (no streamer) can stay resident beside it
 };
+constexpr int PF_STREAMER_VGPRS = 72;   // registers of weight_prefetch_kernel (checked by the build log); one wave per SIMD
 
 // A range of consumer workgroups of one launch (device-side schedule entry).
 struct PfSeg {
@@ -67,6 +73,20 @@ __device__ __forceinline__ unsigned pf_xcc_id() {
 __global__ void pf_where_kernel(unsigned* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = pf_xcc_id();
 }
+
+// concurrency self-test: the waiter (second stream) spins until the setter (engine stream, submitted AFTER it) has
+// raised the flag, or until `budget_ticks` of the 100 MHz clock pass; out = 1 if it saw the flag.  Two HIP streams can
+// share one hardware queue, and then the streamer would hold up the very chain it is meant to feed.
+__global__ void pf_wait_kernel(const unsigned* flag, unsigned* out, long long budget_ticks) {
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned seen = 0;
+  while (!seen && __builtin_amdgcn_s_memrealtime() - t0 < budget_ticks) {
+    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *out = seen;
+}
+__global__ void pf_set_kernel(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // one poller wave + three loader waves per workgroup
 __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
@@ -119,7 +139,13 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
       const int want = base + sp->need;
       int cur = *v_cur;
       while (cur < want) {
-        if (*v_state == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        if (*v_state == 2) {
+          if (lane == 0 && wave == 1) {   // debug record of where a workgroup stopped: {segment, want, seen, rep}
+            a.status[4] = (unsigned)e; a.status[5] = (unsigned)want; a.status[6] = (unsigned)cur; a.status[7] = (unsigned)rep;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          return;
+        }
         __builtin_amdgcn_s_sleep(1);
         cur = *v_cur;
       }
@@ -132,6 +158,36 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
       const int bf = b0 + (int)((x + 16u - (unsigned)((b0 + a.rot) & 7)) & 7u);
       if (bf >= b1) continue;
       const unsigned nbx = (unsigned)(b1 - bf + 7) >> 3;
+      if (sp->kind == 2) {
+        // fragment-order weights: workgroup (bx, by) reads, for each of its `tpb` tiles, `iters` consecutive chunks
+        const unsigned cb = rb;                          // bytes of one (tile, chunk) fragment block
+        const unsigned RB = (unsigned)iters * cb;        // contiguous bytes per tile
+        const unsigned FB2 = (unsigned)tpb * RB;
+        const unsigned ppb2 = (FB2 + 4095u) >> 12;
+        const unsigned n_units2 = nbx * ppb2;
+        const int gx = sp->stride, half2 = sp->hd >> 1, spp = half2 >> 4;
+        for (unsigned u = slot; u < n_units2; u += nslot) {
+          const unsigned piece = u % ppb2;
+          const int b = bf + 8 * (int)(u / ppb2);
+          const int bx = b % gx, by = b / gx;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned po = piece * 4096u + (unsigned)j * 1024u;
+            if (po >= FB2) break;
+            unsigned vo = po + (unsigned)lane * 16u;
+            if (vo >= FB2) vo = po;
+            const int t = (int)(vo / RB);
+            const unsigned off = vo - (unsigned)t * RB;
+            int tile;
+            if (sp->n_rope_heads > 0) { const int head = bx / spp, s_ = bx - head * spp; tile = (head * sp->hd + t * half2 + s_ * 16) >> 4; }
+            else tile = bx * tpb + t;
+            tile = min(tile, ((N + 15) >> 4) - 1);     // partial last panel: stay inside the copy
+            const char* src = W + ((size_t)tile * (size_t)ntask + (size_t)by * (size_t)iters) * cb + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, ldst, 16, 0, 0);
+          }
+        }
+        continue;
+      }
       const unsigned FB = 2u * (unsigned)tpb * rb;                 // footprint of one (workgroup, iteration)
       const unsigned PB = a.stride ? 64u * (unsigned)a.stride : 4096u;   // bytes one unit covers
       const unsigned ppb = (FB + PB - 1u) / PB;
@@ -199,4 +255,5 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
 #endif  // CSM_PREFETCH_KERNELS
 
 int launch_pf_where(hipStream_t st, unsigned* out8);
+int launch_pf_concurrency_probe(hipStream_t waiter_stream, hipStream_t setter_stream, unsigned* flag, unsigned* out);
 int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a);

@@ -448,11 +448,13 @@ class Engine:
 
     def prefetch_stats(self) -> dict:
         """Weight-streamer bookkeeping of the last generate() (csm_prefetch_stats)."""
-        a = (C.c_longlong * 8)()
+        a = (C.c_longlong * 10)()
         _ck(self.lib, self.lib.csm_prefetch_stats(self._h, a))
         keys = ("gave_up", "finished", "skipped_late_sample", "xcd_rotation", "segments", "streamed_launches",
-                "scheduled_bytes", "streamed_launch_bytes")
-        return dict(zip(keys, [int(v) for v in a]))
+                "scheduled_bytes", "streamed_launch_bytes", "launches_counted", "frames")
+        d = dict(zip(keys, [int(v) for v in a]))
+        d["note"] = self.lib.csm_last_error().decode(errors="replace")
+        return d
 
     def set_debug_buffer(self, buf: Optional[torch.Tensor], n_launches: int = 0):
         self._dbg_keep = buf

@@ -169,8 +169,9 @@ int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host)
  * the XCD-local L2 ahead of the launches that read them; engine options "weight_prefetch", "prefetch_window_mb",
  * "prefetch_sub_kb", "prefetch_grid").  out8 = {workgroups that gave up, workgroups finished, segments skipped as late
  * (one sampled wave), workgroup->XCD rotation (-1: streamer disabled), segments in the schedule, streamed launches per
- * frame-step, scheduled bytes, bytes of all streamed launches} for the last csm_generate; syncs both streams */
-int csm_prefetch_stats(csm_engine_t* e, long long* out8_host);
+ * frame-step, scheduled bytes, bytes of all streamed launches, launches counted, frames} for the last csm_generate;
+ * syncs both streams */
+int csm_prefetch_stats(csm_engine_t* e, long long* out10_host);
 /* debug probes of the weight streamer (tools/streamer_probe.py): per-workgroup {XCD id, clocks until the weights were
  * consumed} of the first n streamed launches of the next captured frame-step -> buf[n][2048][2] uint32 (device);
  * geometry {N, K, grid, tasks per workgroup, kind} of the streamed launches of the last captured frame-step */
