@@ -281,6 +281,20 @@ def main():
     eng.reset()
     eng.set_kv_start([0] * B)
     eng.prefill(ids[:, :min(a.ctx, 128)], mask[:, :min(a.ctx, 128)], want_outputs=False)   # cold start: code objects load here
+    # context prefill, timed in both precisions (bf16 weights): "bf16" = activations rounded to bf16 at the GEMM inputs
+    # (one MFMA pass), "exact" = fp32 activations as three bf16 planes.  The benchmarked run continues from the EXACT one.
+    prefill_ms_bf16 = None
+    if a.weights != "fp32":
+        eng.set_option("prefill_bf16", 1)
+        for _ in range(2):
+            eng.reset()
+            eng.set_kv_start([0] * B)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.prefill(ids, mask, want_outputs=False)
+            eng.sync()
+            prefill_ms_bf16 = (time.perf_counter() - t0) * 1e3
+        eng.set_option("prefill_bf16", 0)
     eng.reset()
     eng.set_kv_start([0] * B)
     torch.cuda.synchronize()
@@ -346,6 +360,7 @@ def main():
             "tokens_checksum_per_rank": checks,
             "weight_streamer": pf_stats,
             "prefill_ms": round(prefill_ms, 2),
+            "prefill_ms_bf16_activations": None if prefill_ms_bf16 is None else round(prefill_ms_bf16, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
             "setup_s": round(t_setup, 1),
             "roofline": {"bound": "hbm", "kernel": "frame-step hipGraph (decoder loop + backbone step)",

@@ -185,7 +185,14 @@ __device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride
 
 // prefill planes are plain row-major [3][rows][K] bf16 (the prefill GEMM stages them to LDS itself): 4 consecutive
 // columns of one row, one 8-byte store per plane; `p` points at plane 0, element (row, k0)
+// plane_stride == 0 selects the ONE-plane form (prefill_precision = bf16): the value rounded to nearest-even bf16,
+// like the reference's own bf16 execution rounds every activation -- one MFMA per weight fragment instead of three.
 __device__ __forceinline__ void store_rowplanes4(bf16_t* p, size_t plane_stride, const f32x4& v) {
+  if (plane_stride == 0) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                              (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+    return;
+  }
   uint32_t hw[2], mw[2], lw[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -203,6 +210,7 @@ __device__ __forceinline__ void store_rowplanes4(bf16_t* p, size_t plane_stride,
   *reinterpret_cast<uint2*>(p + 2 * plane_stride) = make_uint2(lw[0], lw[1]);
 }
 __device__ __forceinline__ void store_rowplane1(bf16_t* p, size_t plane_stride, float v) {
+  if (plane_stride == 0) { p[0] = f32_to_bf16(v); return; }
   const uint32_t h = __float_as_uint(v) & 0xffff0000u;
   const float r = v - __uint_as_float(h);
   const uint32_t md = __float_as_uint(r) & 0xffff0000u;

@@ -30,7 +30,7 @@
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a);
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
                    int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes = nullptr,
-                   size_t plane_stride = 0);
+                   size_t plane_stride = 0, const float* part = nullptr, int nsplit = 0, size_t part_stride = 0, int ldp = 0);
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
@@ -119,7 +119,10 @@ struct csm_engine {
   int *p_row_seq = nullptr, *p_row_pos = nullptr;
   // prefill activations as row-major bf16 planes [3][rows][K] (bf16 / fp8 weights): split once by the producer
   bf16_t *p_pl_h = nullptr, *p_pl_act = nullptr;
+  float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
+  int prefill_splitk = 1;
   int prefill_planes = 1;
+  int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   // host mirrors
   int B = 0;
   int h_len = 0, h_frame = 0;
@@ -286,6 +289,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   if (cfg->weight_dtype != CSM_DTYPE_F32) {
     const size_t Km = std::max((size_t)Hb, (size_t)nqb);
     if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * cfg->backbone.ffn))) return r;
+    if (R <= 4096 && (r = dalloc(e, &e->p_part, 4 * R * Hb))) return r;   // only small prefills are short of workgroups
   }
   if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
@@ -463,6 +467,8 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
+  else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
+  else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
@@ -825,11 +831,23 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
   // bf16 / fp8 weights: RMSNorm, the flash attention and the SwiGLU epilogue hand their outputs to the next GEMM as
   // exact bf16 planes (split once per element instead of once per column block of the consumer)
   const bool pl = e->prefill_planes && e->p_pl_h && wd != CSM_DTYPE_F32 && Hb % 8 == 0 && F % 8 == 0 && (nq * hd) % 8 == 0;
+  // prefill_precision = bf16: ONE plane (activations rounded to nearest bf16 by the producer), flagged by a plane
+  // stride of 0; = exact: three planes, one stride apart
+  const bool one = pl && e->prefill_bf16;
+  const size_t ps_h = one ? 0 : R * (size_t)Hb, ps_att = one ? 0 : R * (size_t)(nq * hd), ps_act = one ? 0 : R * (size_t)F;
+  // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
+  // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
+  const bool can_split = pl && e->prefill_splitk && e->p_part && R <= 4096;
+  const int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
+  const size_t part_stride = R * (size_t)Hb;
+  int pending = 0;   // splits waiting in p_part for the next RMSNorm
   for (int l = 0; l < s.c.layers; ++l) {
     const csm_layer_weights_t& w = s.layers[l];
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, R * Hb));
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, Hb));
+    pending = 0;
     GemmArgs g{};
-    if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = R * Hb; }
+    if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
     LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
@@ -840,7 +858,7 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;
     fa.S = S; fa.past = e->h_len; fa.kv_start = e->d_kv_start; fa.out = e->p_att;
-    if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = R * (size_t)(nq * hd); }
+    if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa) : -2;
     bool att_pl = pl && fr != -2;
     if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
@@ -851,23 +869,39 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     }
     LCK(fr);
     GemmArgs o{};
-    if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = R * (size_t)(nq * hd); }
+    if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
-    LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, R * Hb));
+    if (att_pl && ks_o > 1) {
+      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, o));
+      pending = ks_o;
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
+    }
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, Hb));
+    pending = 0;
     GemmArgs gu{};
-    if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = R * Hb; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = R * (size_t)F; }
+    if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
     gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
-    if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = R * (size_t)F; }
+    if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
-    LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
+    if (pl && ks_d > 1) {
+      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, d));
+      pending = ks_d;
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
+    }
   }
   // last position of every sequence: rows b*S + S-1
   const float* hl = e->p_h + (size_t)(S - 1) * Hb;
   const int ldl = S * Hb;
-  LCK(launch_rmsnorm(e->stream, hl, ldl, s.final_norm, B, Hb, s.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
+  // (the last layer's split-K partials are folded into the last rows here, in place, before the head reads them)
+  LCK(launch_rmsnorm(e->stream, hl, ldl, s.final_norm, B, Hb, s.c.rms_eps, e->last_h, Hb, nullptr, 0, 0, nullptr, 0,
+                     pending > 1 ? e->p_part + (size_t)(S - 1) * Hb : nullptr, pending, part_stride, ldl));
   LCK(launch_set_int(e->stream, e->d_len, e->h_len + S));
   LCK(backbone_head(e, hl, ldl, B, false, false));
   e->h_len += S;

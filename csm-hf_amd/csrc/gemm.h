@@ -11,7 +11,7 @@
 #pragma once
 #include "common.h"
 
-enum { GEPI_STORE = 0, GEPI_RESID = 1, GEPI_SWIGLU = 2 };
+enum { GEPI_STORE = 0, GEPI_RESID = 1, GEPI_SWIGLU = 2, GEPI_PARTIAL = 3 };
 
 struct GemmArgs {
   const float* A;  // [R][lda]
@@ -23,12 +23,30 @@ struct GemmArgs {
   int ldc;
   int f32_mfma;  // force the fp32-MFMA kernel also for bf16 / fp8 weights (A/B measurements)
   // bf16x3 kernel only: activations already split by the producer -- row-major planes [3][rows][K] (A is ignored) --
-  // and, for the SwiGLU epilogue, the output written as planes [3][rows][N/2] for the down_proj GEMM (C is ignored)
+  // and, for the SwiGLU epilogue, the output written as planes [3][rows][N/2] for the down_proj GEMM (C is ignored).
+  // A plane stride of 0 means ONE plane (activations rounded to bf16 by the producer: prefill_precision = bf16).
   const bf16_t* Aplanes;
   size_t a_plane_stride;
   bf16_t* Cplanes;
   size_t c_plane_stride;
+  // split-K (GEPI_PARTIAL, grid.y = ksplit): split s accumulates k in [s K/ksplit, (s+1) K/ksplit) and stores its
+  // partial product to Cpart + s * part_stride, row-major [R][N]; the consumer (rmsnorm_kernel) adds the partials to the
+  // residual stream in fixed order.  A one-utterance prefill has only R x N / 64^2 = 256 output tiles for the N = 2048
+  // projections -- one 4-wave workgroup per CU, nothing to hide a k-step's load latency behind.
+  int ksplit;
+  float* Cpart;
+  size_t part_stride;
 };
+
+// K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64
+static inline int prefill_ksplit(int R, int N, int K) {
+  const long tiles64 = (long)((R + 63) / 64) * (N / 64);
+  if (((long)((R + 127) / 128) * (N / 128)) >= 256 || tiles64 >= 768) return 1;
+  int s = (int)((1024 + tiles64 - 1) / tiles64);
+  if (s > 4) s = 4;
+  while (s > 1 && (K % (64 * s))) --s;
+  return s;
+}
 
 #ifndef CSM_ARGS_ONLY
 template <typename WT, int EPI>
@@ -141,14 +159,16 @@ __device__ __forceinline__ u32x4 load_w8_as_bf16<fp8_t>(const fp8_t* p) {
 // The 64x64 tile is used when the 128x128 grid would leave most of the chip idle (prefill of one utterance
 // through the N = 2048 projections: 4 x 16 tiles).
 // BKT = k-step (64 when K % 64 == 0: half the barriers per weight byte, 144-byte LDS rows; else 32)
-template <typename WT, int EPI, int BT, int BKT, bool AP>
+// NPL = activation planes multiplied per weight fragment: 3 (exact fp32 activations) or 1 (bf16 activations, AP only)
+template <typename WT, int EPI, int BT, int BKT, bool AP, int NPL = 3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
+  static_assert(NPL == 3 || (NPL == 1 && AP), "the one-plane form reads producer-written planes");
   constexpr int BM = BT, BN = BT, BK = BKT, LDK = BK + 8;   // bf16 elements per LDS row (80 / 144 bytes: conflict-free b128 reads)
   constexpr int A4 = BK / 4, W8N = BK / 8;                        // f32x4 pieces per A row, 8-weight pieces per W row
   constexpr int NA = BM * A4 / 256, NWL = BN * W8N / 256;         // pieces per thread per k-step
   constexpr int NP = BM * W8N / 256;                              // AP: 8-element pieces per plane per thread
   constexpr int TI = BT / 64;                              // MFMA tiles per wave per dimension
-  __shared__ __attribute__((aligned(16))) bf16_t Ap[3][BM * LDK];
+  __shared__ __attribute__((aligned(16))) bf16_t Ap[NPL][BM * LDK];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[BN * LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -166,8 +186,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   // register prefetch: the global loads of k-step s+1 are issued right after the staging barrier of step s and fly
   // under its LDS reads and MFMAs (at R = 512 the grid is one workgroup per CU, so nothing else hides them)
   f32x4 pa[AP ? 1 : NA];
-  u32x4 pp[AP ? 3 * NP : 1];
+  u32x4 pp[AP ? NPL * NP : 1];
   u32x4 pw[NWL];
+  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
+  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0, kend = kbeg + kspan;
   auto fetch = [&](int k0) {
     if (AP) {
 #pragma unroll
@@ -176,9 +198,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
         const int row = idx / W8N, c8 = idx % W8N;
         const bf16_t* src = a.Aplanes + (size_t)(r0 + row) * a.K + k0 + c8 * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          pp[3 * i + p] = (u32x4)(0u);
-          if (r0 + row < a.R) pp[3 * i + p] = *reinterpret_cast<const u32x4*>(src + p * a.a_plane_stride);
+        for (int p = 0; p < NPL; ++p) {
+          pp[NPL * i + p] = (u32x4)(0u);
+          if (r0 + row < a.R) pp[NPL * i + p] = *reinterpret_cast<const u32x4*>(src + p * a.a_plane_stride);
         }
       }
     } else {
@@ -197,8 +219,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
       pw[i] = load_w8_as_bf16<WT>(W + (size_t)(n0 + row) * a.K + k0 + c8 * 8);
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     // ---- stage A: ready-made planes, or fp32 -> three bf16 planes --------------------------------
     if (AP) {
 #pragma unroll
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
         const int idx = tid + i * 256;
         const int row = idx / W8N, c8 = idx % W8N;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&Ap[p][row * LDK + c8 * 8]) = pp[3 * i + p];
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(&Ap[p][row * LDK + c8 * 8]) = pp[NPL * i + p];
       }
     }
 #pragma unroll
@@ -228,8 +250,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
       }
       const int off = row * LDK + c4 * 4;
       *reinterpret_cast<uint2*>(&Ap[0][off]) = make_uint2(h[0], h[1]);
-      *reinterpret_cast<uint2*>(&Ap[1][off]) = make_uint2(m[0], m[1]);
-      *reinterpret_cast<uint2*>(&Ap[2][off]) = make_uint2(l[0], l[1]);
+      if (NPL == 3) {
+        *reinterpret_cast<uint2*>(&Ap[NPL - 2][off]) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(&Ap[NPL - 1][off]) = make_uint2(l[0], l[1]);
+      }
     }
     // ---- stage W (bf16 as is, fp8 widened exactly) -------------------------------------------------
 #pragma unroll
@@ -239,15 +263,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
       *reinterpret_cast<u32x4*>(&Ws[row * LDK + c8 * 8]) = pw[i];
     }
     lds_barrier();
-    if (k0 + BK < a.K) fetch(k0 + BK);
+    if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       const int ko = kk + (lane >> 5) * 8;
-      g_bf16x8 af[TI][3], bf[TI];
+      g_bf16x8 af[TI][NPL], bf[TI];
 #pragma unroll
       for (int mi = 0; mi < TI; ++mi)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
           *reinterpret_cast<u32x4*>(&af[mi][p]) =
               *reinterpret_cast<const u32x4*>(&Ap[p][(wr * (BM / 2) + mi * 32 + (lane & 31)) * LDK + ko]);
 #pragma unroll
@@ -257,8 +281,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
       for (int mi = 0; mi < TI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TI; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][2], bf[ni], acc[mi][ni], 0, 0, 0);  // lo
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], bf[ni], acc[mi][ni], 0, 0, 0);  // mid
+          if (NPL == 3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][NPL - 1], bf[ni], acc[mi][ni], 0, 0, 0);  // lo
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][NPL - 2], bf[ni], acc[mi][ni], 0, 0, 0);  // mid
+          }
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[ni], acc[mi][ni], 0, 0, 0);  // hi
         }
     }
@@ -282,7 +308,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
             else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
           }
         } else if (r < a.R) {
-          if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
+          if (EPI == GEPI_PARTIAL) a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
+          else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
         }
       }

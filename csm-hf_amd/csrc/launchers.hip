@@ -44,6 +44,23 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
 template <typename WT, int BT, int BK>
 static int launch_gemm_x3_bk(hipStream_t st, int epi, const GemmArgs& a) {
   const int grid = ((a.R + BT - 1) / BT) * (a.N / BT);
+  if (epi == GEPI_PARTIAL) {   // split-K partial products (64 x 64 tiles, producer-written planes)
+    if (!a.Aplanes || a.ksplit < 1 || a.K % (BK * a.ksplit) || !a.Cpart) return -1;
+    const dim3 g2(grid, a.ksplit);
+    if (a.a_plane_stride == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_PARTIAL, BT, BK, true, 1>), g2, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_PARTIAL, BT, BK, true, 3>), g2, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
+  if (a.Aplanes && a.a_plane_stride == 0) {   // one plane: activations rounded to bf16 by the producer (prefill_precision = bf16)
+    if (a.K % 8) return -1;
+    switch (epi) {
+      case GEPI_STORE: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_STORE, BT, BK, true, 1>), dim3(grid), dim3(256), 0, st, a); break;
+      case GEPI_RESID: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_RESID, BT, BK, true, 1>), dim3(grid), dim3(256), 0, st, a); break;
+      case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_bf16x3_kernel<WT, GEPI_SWIGLU, BT, BK, true, 1>), dim3(grid), dim3(256), 0, st, a); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   if (a.Aplanes) {
     if (a.K % 8) return -1;
     switch (epi) {
@@ -71,6 +88,7 @@ static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
 template <typename WT>
 static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
   // 128x128 tiles unless they would occupy fewer than 256 workgroups
+  if (epi == GEPI_PARTIAL) return a.K % 64 ? -1 : launch_gemm_x3_bk<WT, 64, 64>(st, epi, a);
   if (((a.R + 127) / 128) * (a.N / 128) < 256) return launch_gemm_x3_bt<WT, 64>(st, epi, a);
   return launch_gemm_x3_bt<WT, 128>(st, epi, a);
 }
@@ -104,10 +122,11 @@ int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
 }
 
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
-                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes, size_t plane_stride) {
+                   int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes, size_t plane_stride,
+                   const float* part, int nsplit, size_t part_stride, int ldp) {
   if (H % 4 != 0) return -1;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, H, eps, out, ldo, frame_ptr,
-                     frame_stride, frame_add, planes, plane_stride);
+                     frame_stride, frame_add, planes, plane_stride, part, nsplit, part_stride, ldp);
   return (int)hipGetLastError();
 }
 

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, const float* w, int H, float eps,
                                                       float* out, int ldo, const int* frame_ptr,
                                                       size_t frame_stride, int frame_add, bf16_t* planes,
-                                                      size_t plane_stride) {
+                                                      size_t plane_stride, const float* part, int nsplit,
+                                                      size_t part_stride, int ldp) {
+  // part != nullptr: the row first takes up the split-K partial products of the preceding residual GEMM
+  // (gemm.h GEPI_PARTIAL): x[row] += part[0][row] + part[1][row] + ... in that order, written back in place
   // planes != nullptr: the normed row goes out as three exact bf16 planes [3][rows][H] for the prefill GEMM
   // (split once here instead of once per column block of every GEMM that reads it); `out` is then not written
   __shared__ float red[4];
@@ -105,7 +108,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
   if (frame_ptr) o += (size_t)(*frame_ptr + frame_add) * frame_stride;
   float ss = 0.f;
   for (int k = tid * 4; k < H; k += 1024) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+    if (part) {
+      const float* pr = part + (size_t)row * ldp + k;
+      for (int sp = 0; sp < nsplit; ++sp) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pr + (size_t)sp * part_stride);
+        v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+      }
+      *reinterpret_cast<f32x4*>(const_cast<float*>(xr) + k) = v;   // same thread re-reads it below
+    }
     ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   ss = wave_sum(ss);

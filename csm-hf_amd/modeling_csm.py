@@ -148,6 +148,7 @@ class CSMModel(nn.Module):
         self.kv_dtype = torch.float32
         self.weight_format = "native"   # "fp8": linear weights as e4m3fn + per-row scales (BASELINE config 5)
         self.use_graph = True
+        self.prefill_precision = "exact"   # "bf16": context GEMMs on bf16-rounded activations (one MFMA pass instead of three)
         self.seed = 0
         self.row_offset = 0             # global index of row 0 of this model's batch (batch-sharded generation)
 
@@ -255,6 +256,12 @@ class CSMModel(nn.Module):
                 eng.adopt_state(old)
                 old.close()
             self._engine = eng
+        if self.prefill_precision not in ("exact", "bf16"):
+            raise ValueError(f"prefill_precision must be 'exact' or 'bf16', got {self.prefill_precision!r}")
+        want = 1 if self.prefill_precision == "bf16" else 0
+        if getattr(self._engine, "_prefill_bf16", 0) != want:
+            self._engine.set_option("prefill_bf16", want)
+            self._engine._prefill_bf16 = want
         return self._engine
 
     # ---- helpers -----------------------------------------------------------------------------------------------

@@ -293,6 +293,37 @@ def test_csm1b_prefill512_hidden_state(gold, csm1b_bf16):
     assert rel_l2(eng_lh.cpu(), torch.from_numpy(gb["last_h"][0])) < 5e-2
 
 
+def test_csm1b_prefill_precision_bf16(gold, csm1b_bf16):
+    """prefill_precision = "bf16" (VERDICT r1 item 6): the context GEMMs read activations rounded to bf16 -- what the
+    reference's own bf16 execution does at every op -- on ONE bf16 MFMA pass instead of the exact three.  Stated
+    tolerance (BASELINE north_star "backbone hidden states within a stated bf16 tolerance"): last_hidden_state rel-L2
+    <= 5e-2 against the reference's bf16 run and <= 2.8e-2 (the reference's own bf16-vs-fp32 distance) against its
+    fp32 run; the codebook-0 argmax lies in the fp32 reference's top-4.  The exact mode is untouched by the switch."""
+    m = csm1b_bf16
+    g = gold("csm1b_prefill512_bf16w_fp32")
+    gb = gold("csm1b_prefill512_bf16")
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    m.prefill_precision = "bf16"
+    try:
+        m.forward(ids.to(DEV), mask.to(DEV), use_cache=True)
+        lh, lg = m._engine.get_state()
+    finally:
+        m.prefill_precision = "exact"
+    lh, lg = lh.cpu(), lg.cpu()
+    d32, d16 = rel_l2(lh, torch.from_numpy(g["last_h"][0])), rel_l2(lh, torch.from_numpy(gb["last_h"][0]))
+    assert 1e-5 < d32 < 2.8e-2 and d16 < 5e-2, (d32, d16)
+    assert int(lg.argmax(-1)[0]) in set(g["top_idx"][0, 0, 0, :4].tolist())
+    m.forward(ids.to(DEV), mask.to(DEV), use_cache=True)
+    assert rel_l2(m._engine.get_state()[0].cpu(), torch.from_numpy(g["last_h"][0])) < 1e-4
+    # a generation after a bf16 prefill runs the exact decode kernels on the approximate context: tokens stay in range
+    m.prefill_precision = "bf16"
+    try:
+        out = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False)
+    finally:
+        m.prefill_precision = "exact"
+    assert out.shape == (1, 3, 32) and int(out.min()) >= 0 and int(out.max()) < m.config.audio_vocab_size
+
+
 def test_csm1b_config2_200_frames(gold, csm1b_bf16):
     """BASELINE config 2 (the benchmarked workload): 512-frame context + 200 greedy frames, hipGraph
     replay, vs the reference's fp32-arithmetic run on the same weights."""
