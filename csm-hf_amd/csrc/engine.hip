@@ -76,7 +76,7 @@ struct Stack {
 // What a captured frame-step depends on.  The sampling seed and the shard's row offset are NOT here: they live in
 // device memory (d_rng) and are rewritten before every launch, like the frame index and the backbone length.
 struct GraphKey {
-  int B, topk, nsplit;
+  int B, topk, nsplit, per_row;
   float temperature;
   const void *noise, *forced, *ltrace, *htrace;
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
@@ -104,6 +104,8 @@ struct csm_engine {
   int* d_len = nullptr;
   int* d_frame = nullptr;
   int* d_kv_start = nullptr;
+  int* d_zero_count = nullptr;   // [max_frames] rows whose frame was all-zero (stop test without a per-frame host sync)
+  int* d_row_done = nullptr;     // [max_batch] rows that have emitted an all-zero frame
   uint64_t* d_rng = nullptr;   // {seed, global index of row 0}: read by the sampler, written before every launch
   int64_t* ring = nullptr;
   // decode scratch
@@ -266,6 +268,9 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->d_rng, 2)))
     return r;
   HIPCK(hipMemsetAsync(e->d_rng, 0, 2 * sizeof(uint64_t), e->stream));
+  if ((r = dalloc(e, &e->d_zero_count, (size_t)cfg->max_frames)) || (r = dalloc(e, &e->d_row_done, (size_t)B))) return r;
+  HIPCK(hipMemsetAsync(e->d_zero_count, 0, (size_t)cfg->max_frames * sizeof(int), e->stream));
+  HIPCK(hipMemsetAsync(e->d_row_done, 0, (size_t)B * sizeof(int), e->stream));
   if ((r = dalloc(e, &e->ring, (size_t)B * cfg->max_frames * C))) return r;
   HIPCK(hipMemsetAsync(e->ring, 0, (size_t)B * cfg->max_frames * C * sizeof(int64_t), e->stream));
   HIPCK(hipMemsetAsync(e->d_kv_start, 0, B * sizeof(int), e->stream));
@@ -442,6 +447,8 @@ extern "C" int csm_reset(csm_engine_t* e) {
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   HIPCK(hipMemsetAsync(e->d_kv_start, 0, e->cfg.max_batch * sizeof(int), e->stream));
+  HIPCK(hipMemsetAsync(e->d_zero_count, 0, (size_t)e->cfg.max_frames * sizeof(int), e->stream));
+  HIPCK(hipMemsetAsync(e->d_row_done, 0, (size_t)e->cfg.max_batch * sizeof(int), e->stream));
   e->h_len = e->h_frame = 0;
   e->ready = false;
   e->B = 0;
@@ -687,6 +694,8 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
     em.ring = (s && s->forced) ? s->forced : e->ring;
     em.frame_ptr = e->d_frame;
     em.max_frames = e->cfg.max_frames;
+    em.zero_count = e->d_zero_count;
+    em.row_done = e->d_row_done;
   }
   em.out = e->h_bb;
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
@@ -715,6 +724,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     a.cb = cb; a.C = C; a.B = B; a.frame_ptr = e->d_frame; a.max_frames = e->cfg.max_frames;
     a.ring = e->ring; a.forced = s->forced; a.proj_table = e->w.proj_table; a.Hd = Hd; a.dec_x = e->dec_x;
     a.logits_trace = s->logits_trace;
+    a.row_done = s->per_row_stop ? e->d_row_done : nullptr;
     if (planes_on(e, e->dec, B) && (e->use_planes & 8)) {
       a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16;
     }
@@ -1009,7 +1019,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
   HIPCK(hipEventRecord(e->ev0, e->stream));
   if (use_graph && n_frames > 0) {
     GraphKey k{};
-    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature;
+    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature; k.per_row = s->per_row_stop && e->B > 1;
     k.noise = s->noise; k.forced = s->forced; k.ltrace = s->logits_trace; k.htrace = s->last_h_trace;
     const bool greedy = s->topk <= 1 || s->temperature == 0.f;
     if (greedy) { k.topk = 1; k.temperature = 0.f; }   // every greedy setting runs the same launches
@@ -1102,9 +1112,18 @@ extern "C" int csm_read_frames(csm_engine_t* e, int64_t* frames_out, int first, 
   return 0;
 }
 
+extern "C" int csm_read_zero_counts(csm_engine_t* e, int32_t* out_host, int first, int n) {
+  if (!e || !out_host || first < 0 || n < 0 || first + n > e->cfg.max_frames) return fail(CSM_ERR_ARG, "bad frame range");
+  if (n == 0) return 0;
+  HIPCK(hipMemcpyAsync(out_host, e->d_zero_count + first, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 extern "C" int csm_rewind_frames(csm_engine_t* e) {
   if (!e) return fail(CSM_ERR_ARG, "null engine");
   LCK(launch_set_int(e->stream, e->d_frame, 0));
+  HIPCK(hipMemsetAsync(e->d_zero_count, 0, (size_t)e->cfg.max_frames * sizeof(int), e->stream));
   e->h_frame = 0;
   return 0;
 }
@@ -1185,6 +1204,8 @@ extern "C" int csm_kv_copy(csm_engine_t* dst, csm_engine_t* src) {
                              (size_t)src->cfg.max_frames * C * sizeof(int64_t), (size_t)nf * C * sizeof(int64_t), B,
                              hipMemcpyDeviceToDevice, st));
     HIPCK(hipMemcpyAsync(dst->d_kv_start, src->d_kv_start, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(dst->d_row_done, src->d_row_done, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (nf > 0) HIPCK(hipMemcpyAsync(dst->d_zero_count, src->d_zero_count, (size_t)nf * sizeof(int), hipMemcpyDeviceToDevice, st));
     HIPCK(hipMemcpyAsync(dst->head_out, src->head_out, (size_t)B * src->ld_head * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCK(hipMemcpyAsync(dst->last_h, src->last_h, (size_t)B * src->cfg.backbone.hidden * sizeof(float), hipMemcpyDeviceToDevice, st));
   }

@@ -21,6 +21,10 @@ struct EmbedArgs {
   const int* frame_ptr;
   int max_frames;
   float* out;  // [rows][H]
+  // ring mode: stop bookkeeping on the device (no host sync per frame).  zero_count[f] += 1 for every row whose
+  // frame f is all-zero; row_done[row] = 1 from then on (read by the sampler when per-row stop is on)
+  int* zero_count;   // [max_frames] nullable
+  int* row_done;     // [rows] nullable
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -30,6 +34,7 @@ struct EmbedArgs {
 template <typename WT>
 __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
   __shared__ float part[4][512];
+  __shared__ int nz[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = blockIdx.y * 512 + lane * 8;
   const WT* te = reinterpret_cast<const WT*>(a.text_emb);
@@ -41,6 +46,12 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (!a.ids && a.zero_count && blockIdx.y == 0) {   // any non-zero audio token among this wave's share of the frame?
+    int any = 0;
+    for (int c = c0 + lane; c < c1 && c < a.C; c += 64) any |= a.ring[((size_t)row * a.max_frames + f) * a.C + c] != 0;
+    const unsigned long long bal = __ballot(any);
+    if (lane == 0) nz[wave] = bal != 0ull;
+  }
   if (k < a.H) {
     constexpr int MAXT = 16;
     W8<WT> w[MAXT];
@@ -81,6 +92,10 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
   for (int i = tid; i < 512; i += 256) {
     const int kk = blockIdx.y * 512 + i;
     if (kk < a.H) a.out[(size_t)row * a.H + kk] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+  }
+  if (!a.ids && a.zero_count && blockIdx.y == 0 && tid == 0 && !(nz[0] | nz[1] | nz[2] | nz[3])) {
+    atomicAdd(a.zero_count + f, 1);
+    if (a.row_done) a.row_done[row] = 1;
   }
 }
 
@@ -229,6 +244,7 @@ struct SampleArgs {
   const float* oln;
   float* oss;
   int oss_ld, oss_n;
+  const int* row_done;  // nullable: rows flagged here are frozen -- they emit token 0 (per-row stop)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -513,6 +529,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     choice = block_argmax(bv, bi, s_val, s_idx);
   }
 
+  if (a.row_done && a.row_done[row]) choice = 0;   // per-row stop: a finished row stays silent
   int64_t feed = choice;
   const size_t slot = ((size_t)row * a.max_frames + f) * a.C + a.cb;
   if (a.forced) feed = a.forced[slot];

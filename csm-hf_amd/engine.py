@@ -27,7 +27,7 @@ EXPORTS = [
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
-    "csm_set_debug_buffer", "csm_last_geoms",
+    "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
 ]
 
 
@@ -63,7 +63,7 @@ class Weights(C.Structure):
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("topk", C.c_int32), ("seed", C.c_uint64), ("noise", C.c_void_p),
                 ("forced", C.c_void_p), ("logits_trace", C.c_void_p), ("last_h_trace", C.c_void_p),
-                ("row_offset", C.c_int32), ("reserved", C.c_int32)]
+                ("row_offset", C.c_int32), ("per_row_stop", C.c_int32)]
 
 
 _lib = None
@@ -119,6 +119,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_graph_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.csm_kv_copy.argtypes = [vp, vp]
     lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.csm_read_zero_counts.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.csm_set_debug_buffer.argtypes = [vp, vp, i32]
     lib.csm_last_geoms.argtypes = [vp, C.POINTER(C.c_int32), i32, C.POINTER(i32)]
     if path is None:
@@ -391,10 +392,11 @@ class Engine:
         return lh, lg
 
     def sampling(self, temperature=1.0, topk=50, seed=0, noise=None, forced=None, logits_trace=None,
-                 last_h_trace=None, row_offset=0) -> Sampling:
+                 last_h_trace=None, row_offset=0, per_row_stop=False) -> Sampling:
         s = Sampling()
         s.temperature, s.topk, s.seed = float(temperature), int(topk), int(seed) & (2 ** 64 - 1)
         s.row_offset = int(row_offset)
+        s.per_row_stop = 1 if per_row_stop else 0
         s.noise = None if noise is None else noise.data_ptr()
         s.forced = None if forced is None else forced.data_ptr()
         s.logits_trace = None if logits_trace is None else logits_trace.data_ptr()
@@ -435,6 +437,12 @@ class Engine:
         _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
         self.sync()
         return lh, lg
+
+    def zero_counts(self, first: int, n: int):
+        """rows whose frame was all-zero, for frames first .. first+n-1 (one stream sync)."""
+        a = (C.c_int32 * max(n, 1))()
+        _ck(self.lib, self.lib.csm_read_zero_counts(self._h, a, int(first), int(n)))
+        return [int(a[i]) for i in range(n)]
 
     def rewind_frames(self):
         """generate_frame streaming: frames already handed to the caller free their ring slots."""

@@ -148,6 +148,8 @@ class CSMModel(nn.Module):
         self.kv_dtype = torch.float32
         self.weight_format = "native"   # "fp8": linear weights as e4m3fn + per-row scales (BASELINE config 5)
         self.use_graph = True
+        self.stop_check_interval = 8     # stop_on_all_zeros: frames replayed between two reads of the device-side stop counters
+        self.last_row_lengths = None     # per-row frame counts of the last generate(per_row_stop=True)
         self.prefill_precision = "exact"   # "bf16": context GEMMs on bf16-rounded activations (one MFMA pass instead of three)
         self.seed = 0
         self.row_offset = 0             # global index of row 0 of this model's batch (batch-sharded generation)
@@ -356,9 +358,12 @@ class CSMModel(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: int = 100,
                  temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True,
-                 *, seed: Optional[int] = None):
+                 *, seed: Optional[int] = None, per_row_stop: bool = False):
         """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.  `seed` (extension, default: drawn
-        from torch's seed and a call counter) keys the device Philox stream of the sampler.
+        from torch's seed and a call counter) keys the device Philox stream of the sampler.  `per_row_stop` (extension,
+        SURVEY.md section 8 f-4): a row that has emitted an all-zero frame is frozen (emits zeros from then on), generation
+        ends when the last row has finished, `self.last_row_lengths` holds every row's own frame count; the default keeps
+        the reference's global rule (:662: stop when ALL rows emit an all-zero frame in the same step).
 
         One prefill, then per frame one replay of the captured hipGraph (31-step decoder loop + next
         backbone step).  With `stop_on_all_zeros` the host checks each frame (one sync per frame, like the
@@ -374,18 +379,32 @@ class CSMModel(nn.Module):
         eng.set_kv_start(self._kv_starts(attention_mask, B, T))
         eng.prefill(input_ids, attention_mask, want_outputs=False)
         s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed() if seed is None else int(seed),
-                         row_offset=self.row_offset)
+                         row_offset=self.row_offset, per_row_stop=per_row_stop and stop_on_all_zeros)
         n = 0
         if stop_on_all_zeros:
+            # The reference syncs once per frame (`torch.all(new_frame == 0)`, :662).  Here every backbone step counts the
+            # all-zero rows of its frame on the device; k frames are replayed, k counters read with ONE sync, and the
+            # result is cut at the first frame all B rows left empty -- exactly the frames the per-frame test returns
+            # (rows are independent; the frames replayed past the cut are discarded).
+            k = max(1, int(self.stop_check_interval))
             while n < max_new_frames:
-                eng.generate(s, 1, self.use_graph)
-                frame = eng.read_frames(n, 1)
-                if bool(torch.all(frame == 0)):
+                step = min(k, max_new_frames - n)
+                eng.generate(s, step, self.use_graph)
+                counts = eng.zero_counts(n, step)
+                hit = next((i for i, c in enumerate(counts) if c >= B), None)
+                if hit is not None:
+                    n += hit
                     break
-                n += 1
+                n += step
         else:
             eng.generate(s, max_new_frames, self.use_graph)
             n = max_new_frames
         out = eng.read_frames(0, n) if n else torch.zeros(B, 0, C, dtype=torch.long, device=eng.device)
+        if per_row_stop:
+            first = torch.full((B,), n, dtype=torch.long, device=out.device)
+            if n:
+                zero = (out == 0).all(dim=2)                              # [B, n]
+                first = torch.where(zero.any(dim=1), zero.float().argmax(dim=1), first)
+            self.last_row_lengths = first.to(input_ids.device)
         self._epoch += 1  # generate() does not hand out a cache handle
         return out.to(input_ids.device)

@@ -111,7 +111,10 @@ typedef struct {
   int32_t row_offset;    /* global index of this engine's row 0 (batch-sharded generation): the
                             Philox counter uses row_offset + local row, so shards draw distinct, world-size-independent
                             streams.  No reference counterpart (torch's global generator, modeling_csm.py:175) */
-  int32_t reserved;
+  int32_t per_row_stop;  /* 1: a row that has emitted an all-zero frame is FROZEN (it keeps emitting zeros), so the all-zero
+                            test fires when the last row finishes -- per-row end of utterance.
+                            0: the reference's rule (modeling_csm.py:662): rows keep generating until ALL rows emit an
+                            all-zero frame in the same step */
 } csm_sampling_t;
 
 /* ---- lifecycle: CSMModel.__init__ / setup_caches / reset_caches (modeling_csm.py:214-245, 284-290) */
@@ -160,6 +163,10 @@ int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logits_out);
  * csm_read_frames.  No host sync inside. */
 int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_frames, int use_graph);
 int csm_read_frames(csm_engine_t* e, int64_t* frames_out /* device [B,n,C] */, int first, int n);
+/* Stop test without a host sync per frame (reference: `torch.all(new_frame == 0)`, modeling_csm.py:662, one sync per
+ * frame): every backbone step counts, on the device, the rows whose frame was all-zero; out[i] = that count for frame
+ * first + i.  generate() replays k frames, reads k counters once, and cuts at the first frame whose count == B. */
+int csm_read_zero_counts(csm_engine_t* e, int32_t* out_host, int first, int n);   /* syncs the stream */
 /* generate_frame-driven streaming (modeling_csm.py:484-589 hands every frame to the caller): restart the on-device
  * frame ring at slot 0 once the caller has read what it holds, so a stream is not limited to max_frames frames */
 int csm_rewind_frames(csm_engine_t* e);

@@ -179,6 +179,50 @@ def test_weight_streamer_is_transparent(dtype):
     assert torch.equal(a, b)
 
 
+def test_stop_test_without_per_frame_sync_and_per_row_stop():
+    """SURVEY.md section 8 f-4 / VERDICT r1 item 8.  (i) generate(stop_on_all_zeros=True) replays k frames between two
+    reads of the device-side stop counters and returns exactly what the reference's per-frame test returns (oracle);
+    (ii) the counters: with scripted (teacher-forced) rows that fall silent at frames 2 / 5 / never, zero_count[f] is
+    the number of silent rows at frame f; (iii) per_row_stop freezes a silent row (it emits zeros from the next frame
+    on) while the default lets it keep generating, as the reference does."""
+    cfg, sd, m = tiny_model()
+    ids, mask = synth_context(cfg, 3, 3, 5, seed=14)
+    want = O.generate(sd, cfg, ids, mask, max_new_frames=13, topk=1, stop_on_all_zeros=True)
+    for k in (1, 5, 8):
+        m.stop_check_interval = k
+        got = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=13, topk=1, stop_on_all_zeros=True).cpu()
+        assert torch.equal(got, want), k
+    # (ii) + (iii): engine level, forced feedback decides when a row is silent
+    n = 9
+    eng = m._ensure_engine(3, 8 + n + 1, n, 3 * 8)
+    ends = [2, 5, 99]
+    for per_row in (False, True):
+        eng.reset()
+        eng.set_kv_start([0, 0, 0])
+        eng.prefill(ids, mask)
+        fz = torch.randint(1, cfg.audio_vocab_size, (3, eng.max_frames, 32), dtype=torch.int64, device=DEV)
+        for b, L in enumerate(ends):
+            fz[b, L:] = 0
+        eng.generate(eng.sampling(temperature=1.0, topk=1, forced=fz, per_row_stop=per_row), n, True)
+        counts = eng.zero_counts(0, n)
+        assert counts == [sum(1 for L in ends if f >= L) for f in range(n)], counts
+        toks = eng.read_frames(0, n).cpu()
+        if per_row:   # frozen from the frame AFTER the one that was fed back as silence
+            assert int(toks[0, 3:].abs().sum()) == 0 and int(toks[1, 6:].abs().sum()) == 0 and int(toks[2].abs().sum()) > 0
+            assert int(toks[0, :3].abs().sum()) > 0
+        else:
+            assert int(toks[0, 3:].abs().sum()) > 0   # the reference keeps generating for a finished row
+    # model level: all-silent model stops at once under both rules and reports row lengths
+    sd0 = dict(sd)
+    sd0["codebook0_head.weight"] = torch.zeros_like(sd["codebook0_head.weight"])
+    sd0["audio_head"] = torch.zeros_like(sd["audio_head"])
+    m0 = CSMModel(cfg)
+    m0.load_state_dict(sd0)
+    m0 = m0.to(DEV).eval()
+    out = m0.generate(ids.to(DEV), mask.to(DEV), max_new_frames=20, topk=1, stop_on_all_zeros=True, per_row_stop=True)
+    assert out.shape == (3, 0, 32) and m0.last_row_lengths.tolist() == [0, 0, 0]
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)

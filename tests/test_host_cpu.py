@@ -96,7 +96,7 @@ def test_api_surface_matches_reference_signatures():
     # the reference's parameters, in order; extensions (seed) are keyword-only so positional callers are unaffected
     pos = [k for k, v in g.items() if v.kind == v.POSITIONAL_OR_KEYWORD]
     assert pos[1:] == ["input_ids", "attention_mask", "max_new_frames", "temperature", "topk", "use_cache", "stop_on_all_zeros"]
-    assert all(v.kind == v.KEYWORD_ONLY and v.default is None for k, v in g.items() if k not in pos)
+    assert all(v.kind == v.KEYWORD_ONLY and v.default in (None, False) for k, v in g.items() if k not in pos)
     assert (g["max_new_frames"].default, g["temperature"].default, g["topk"].default) == (100, 1.0, 50)
     f = inspect.signature(CSMModel.generate_frame).parameters
     assert list(f)[1:] == ["input_ids", "attention_mask", "position_ids", "temperature", "topk", "past_key_values",
