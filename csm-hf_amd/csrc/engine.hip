@@ -1050,6 +1050,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       hipGraphExec_t ge = nullptr;
       HIPCK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       HIPCK(hipGraphDestroy(g));
+      hipGraphUpload(ge, e->stream);   // the first launch then starts like every later one (the weight streamer waits for it)
       GraphEntry ent{};
       ent.exec = ge;
       e->last_geoms = geoms;

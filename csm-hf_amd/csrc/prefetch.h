@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
       if (lane == 0) *v_cur = c;
       const long long now = __builtin_amdgcn_s_memrealtime();
       if (c != last) { last = c; t_last = now; }
-      if (now - t_last > a.budget_ticks) {
+      // before the first launch has started the chain may still be on its way through the host (first launch of a freshly
+      // instantiated graph): ten budgets; afterwards one budget without progress ends the streamer
+      if (now - t_last > (c == 0 ? 10 * a.budget_ticks : a.budget_ticks)) {
         if (lane == 0) { *v_state = 2; atomicAdd(a.status, 1u); }
         return;
       }
