@@ -1,0 +1,69 @@
+#!/bin/bash
+# Round-2 profile collection on a 1-GPU MI355X box (run from the repo root through gpurun); every leg is bounded.
+# usage: bash tools/collect_profiles_r02.sh [outdir]
+O=${1:-gpurun_out/r02}
+mkdir -p $O; export TMPDIR=/tmp
+R=$PWD
+timeout 500 python bench.py > $O/bench.json 2> $O/bench.err
+: > $O/bench_other_configs.jsonl
+for extra in "--opt weight_prefetch=0" "--batch 16 --steps 100" "--batch 16 --topk 50 --temperature 1.0 --steps 100" \
+             "--weights fp8 --steps 300" "--ctx 2048" "--weights fp8 --ctx 2048 --steps 500 --warmup 4" \
+             "--topk 50 --temperature 0.9" "--no-graph --steps 100" "--weights fp8 --batch 16 --steps 100"; do
+  timeout 300 python bench.py --no-cpu-baseline $extra >> $O/bench_other_configs.jsonl 2>> $O/bench_other.err
+done
+for c in 512 2048; do timeout 200 python tools/prefill_bench.py $c 1 5; done > $O/prefill.txt 2>&1
+timeout 200 python tools/prefill_bench.py 512 16 3 >> $O/prefill.txt 2>&1
+# kernel-level split of the benchmarked command (streamer off under the profiler: it is one persistent launch that
+# would dwarf every row; the bench line above is the un-profiled number)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o r02 -- python $R/bench.py --steps 20 --warmup 4 --lean --opt weight_prefetch=0 > $R/$O/stats.log 2>&1
+cd $R
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 4 --lean --opt weight_prefetch=0"
+  echo "# (24 frame-steps + the prefills; at::native::* kernels are the synthetic-weight generation in setup, not the path)"; echo
+  python tools/rocprof_summary.py $O/stats/r02_results.db 24; } > $O/bench_kernel_stats.md 2>&1
+rm -rf $O/stats
+# config 5 (fp8 weights, 2048-frame prefill, 500 frames): kernel split, then HBM bytes + matrix-pipe busy in separate --pmc passes
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/c5 -o c5 -- python $R/bench.py --weights fp8 --ctx 2048 --steps 40 --warmup 4 --lean --opt weight_prefetch=0 > $R/$O/c5.log 2>&1
+cd $R
+{ echo "# BASELINE configs[4]: rocprofv3 --kernel-trace --stats -- python bench.py --weights fp8 --ctx 2048 --steps 40 --warmup 4 --lean --opt weight_prefetch=0"; echo
+  python tools/rocprof_summary.py $O/c5/c5_results.db 44; } > $O/config5_kernel_stats.md 2>&1
+rm -rf $O/c5
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  d=c5pmc_$(echo $c | cut -d' ' -f1 | tr A-Z a-z)
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/$O/$d -o c5 -- python $R/bench.py --weights fp8 --ctx 2048 --steps 4 --warmup 2 --lean --opt weight_prefetch=0 > $R/$O/$d.log 2>&1
+  echo "$c rc=$?"
+done
+cd $R
+python tools/pmc_summary.py $O/c5pmc_fetch_size/c5_results.db 6 $O/c5pmc_write_size/c5_results.db > $O/config5_pmc_hbm.json 2> $O/config5_pmc.err
+python - $O <<'PY' > $O/config5_pmc_mfma.md 2>> $O/config5_pmc.err
+import sqlite3, sys, collections
+o = sys.argv[1]
+db = sqlite3.connect(f"{o}/c5pmc_sq_valu_mfma_busy_cycles/c5_results.db")
+rows = db.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name").fetchall()
+t = collections.defaultdict(dict)
+for n, c, k, v in rows:
+    t[n][c] = (k, v)
+print("# config 5: matrix-pipe busy per kernel (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs), prefill + decode kernels")
+print("| kernel | launches | MFMA busy % of the chip's matrix pipes | GRBM_GUI_ACTIVE cycles / launch |")
+print("|---|---|---|---|")
+for n, d in sorted(t.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1])[:14]:
+    if "GRBM_GUI_ACTIVE" not in d or not d["GRBM_GUI_ACTIVE"][1]: continue
+    busy = d.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1]
+    act = d["GRBM_GUI_ACTIVE"][1]
+    print(f"| `{n[:80]}` | {d['GRBM_GUI_ACTIVE'][0]} | {100.0 * busy / (128.0 * act):.1f} | {act / d['GRBM_GUI_ACTIVE'][0]:.0f} |")
+PY
+rm -rf $O/c5pmc_*
+# HBM traffic of the benchmarked command (B = 1, streamer off: counter passes serialise the dispatches)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=pmc_$(echo $c | tr A-Z a-z)
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $R/$O/$d -o r02 -- python $R/bench.py --steps 4 --warmup 2 --lean --opt weight_prefetch=0 > $R/$O/$d.log 2>&1
+done
+cd $R
+python tools/pmc_summary.py $O/pmc_fetch_size/r02_results.db 6 $O/pmc_write_size/r02_results.db > $O/pmc_hbm.json 2> $O/pmc_hbm.err
+rm -rf $O/pmc_fetch_size $O/pmc_write_size
+timeout 300 python tools/streamer_probe.py > $O/streamer_probe.txt 2>&1
+for p in 1 220 512; do echo "== pool_mb=$p nt=0"; timeout 200 python tools/bench_gemv.py pool_mb=$p nt=0 2>/dev/null | tail -10; done > $O/gemv_pool_microbench.txt 2>&1
+ls -la $O | head -40; cat $O/bench.json | head -5

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the probe is compiled in only in the -DCSM_PROBE variant of the library (even a disabled probe costs 6 % per frame)
 PROBE_LIB = os.environ.get("CSM_PROBE_LIB") or os.path.join(ROOT, "csm-hf_amd", "libcsm_hip_probe.so")
-if not os.path.exists(PROBE_LIB):
-    from csm_hf_amd.build import build_library
-    build_library(force=True, defines=("CSM_PROBE",), out=PROBE_LIB)
+from csm_hf_amd.build import build_library, LIB, _sources_mtime  # noqa: E402
+if not os.environ.get("CSM_PROBE_LIB") and (not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < _sources_mtime()):
+    build_library(force=True, defines=("CSM_PROBE",), out=PROBE_LIB)   # stale or missing: rebuild (hipcc, ~2 min)
 os.environ["CSM_HIP_LIB"] = PROBE_LIB
 from csm_hf_amd import CSMConfig, CSMModel  # noqa: E402
 from csm_hf_amd.synth import synth_state_dict, synth_context  # noqa: E402
