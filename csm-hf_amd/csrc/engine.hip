@@ -33,6 +33,7 @@ int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int 
                    size_t plane_stride = 0, const float* part = nullptr, int nsplit = 0, size_t part_stride = 0, int ldp = 0);
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
+int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
 int launch_set_int(hipStream_t st, int* p, int v);
 int launch_set_rng(hipStream_t st, uint64_t* p, uint64_t seed, uint64_t row_offset);
@@ -821,8 +822,47 @@ extern "C" int csm_backbone_step_ids(csm_engine_t* e, const int64_t* ids, const 
   return 0;
 }
 
+static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* rope_pos,
+                        float* last_h_out, float* c0_logits_out);
+
 extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, float* last_h_out,
                            float* c0_logits_out) {
+  return prefill_impl(e, ids, mask, B, S, nullptr, last_h_out, c0_logits_out);
+}
+
+extern "C" int csm_prefill_pos(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S,
+                               const int32_t* position_ids, float* last_h_out, float* c0_logits_out) {
+  return prefill_impl(e, ids, mask, B, S, position_ids, last_h_out, c0_logits_out);
+}
+
+static int kv_convert(csm_engine_t* e, int layer, float* K, float* V, int B, int len, int to_engine) {
+  if (!e || !K || !V) return fail(CSM_ERR_ARG, "null argument");
+  Stack& s = e->bb;
+  if (layer < 0 || layer >= s.c.layers) return fail(CSM_ERR_ARG, "bad layer %d", layer);
+  if (B < 1 || B > e->cfg.max_batch || len < 0 || len > s.lmax) return fail(CSM_ERR_CAPACITY, "batch %d / length %d exceed the engine's cache (%d, %d)", B, len, e->cfg.max_batch, s.lmax);
+  KvConvArgs a{};
+  a.kcache = s.kc[layer]; a.vcache = s.vc[layer]; a.k_hf = K; a.v_hf = V; a.B = B; a.n_kv = s.c.n_kv; a.hd = s.c.head_dim;
+  a.lmax = s.lmax; a.len = len; a.to_engine = to_engine;
+  LCK(launch_kv_convert(e->stream, e->cfg.kv_dtype, a));
+  return 0;
+}
+
+extern "C" int csm_kv_export(csm_engine_t* e, int layer, float* k_out, float* v_out, int len) {
+  return kv_convert(e, layer, k_out, v_out, e ? e->B : 0, len, 0);
+}
+extern "C" int csm_kv_import(csm_engine_t* e, int layer, const float* k_in, const float* v_in, int B, int len) {
+  return kv_convert(e, layer, const_cast<float*>(k_in), const_cast<float*>(v_in), B, len, 1);
+}
+// after csm_kv_import of every layer: the engine continues from `len` cached positions of a batch of B
+extern "C" int csm_set_length(csm_engine_t* e, int B, int len) {
+  if (!e || B < 1 || B > e->cfg.max_batch || len < 0 || len > e->cfg.max_len) return fail(CSM_ERR_ARG, "bad batch / length");
+  LCK(launch_set_int(e->stream, e->d_len, len));
+  e->B = B; e->h_len = len; e->ready = false;
+  return 0;
+}
+
+static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* rope_pos,
+                        float* last_h_out, float* c0_logits_out) {
   if (!e || !e->bound || !ids) return fail(CSM_ERR_STATE, "weights not bound / null ids");
   if (B < 1 || B > e->cfg.max_batch || S < 1) return fail(CSM_ERR_ARG, "bad batch/sequence (%d, %d)", B, S);
   if (e->B && B != e->B) return fail(CSM_ERR_ARG, "batch %d does not match active batch %d (call csm_reset)", B, e->B);
@@ -863,7 +903,7 @@ extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* m
     RopeArgs ra{};
     ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
     ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
-    ra.qbuf = e->p_q; ra.kcache = s.kc[l]; ra.vcache = s.vc[l]; ra.lmax = s.lmax;
+    ra.qbuf = e->p_q; ra.kcache = s.kc[l]; ra.vcache = s.vc[l]; ra.lmax = s.lmax; ra.rope_pos = rope_pos;
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;

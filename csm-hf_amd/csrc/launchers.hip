@@ -140,6 +140,15 @@ int configure_sample() {   // once per process, outside any capture: the top-k p
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(160 * 1024 - 4096));
 }
+int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a) {
+  const size_t n = (size_t)a.B * a.n_kv * a.len * a.hd;
+  if (n == 0) return 0;
+  const int grid = (int)((n + 255) / 256);
+  if (kvdtype == 1) hipLaunchKernelGGL((kv_convert_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((kv_convert_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a) {
   const bool greedy = a.topk <= 1 || a.temperature == 0.f;
   // top-k: scaled logits | survivor values | survivor indices in LDS; greedy streams the row from memory

@@ -168,13 +168,47 @@ struct RopeArgs {
   void* kcache;
   void* vcache;
   int lmax;
+  const int* rope_pos;  // nullable: caller-supplied RoPE positions (reference `position_ids`, modeling_csm.py:296,349);
+                        // the cache slot stays row_pos -- HF masks by cache index and rotates by position_ids
+};
+
+// ---- KV-cache interchange with the HF layout [B][n_kv][len][hd] fp32 (transformers DynamicCache layers) ----------------
+struct KvConvArgs {
+  void* kcache;    // engine layout K [B][n_kv][hd/4][lmax][4], V [B][n_kv][lmax][hd]
+  void* vcache;
+  float* k_hf;
+  float* v_hf;
+  int B, n_kv, hd, lmax, len;
+  int to_engine;   // 1: HF -> engine (import), 0: engine -> HF (export)
 };
 
 #ifndef CSM_ARGS_ONLY
 template <typename KT>
+__global__ __launch_bounds__(256) void kv_convert_kernel(KvConvArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)a.B * a.n_kv * a.len * a.hd;
+  if (i >= n) return;
+  const int d = (int)(i % a.hd);
+  const int t = (int)((i / a.hd) % a.len);
+  const size_t bj = i / ((size_t)a.hd * a.len);    // b * n_kv + j
+  KT* kc = reinterpret_cast<KT*>(a.kcache);
+  KT* vc = reinterpret_cast<KT*>(a.vcache);
+  const size_t ki = ((bj * (a.hd >> 2) + (d >> 2)) * a.lmax + t) * 4 + (d & 3);
+  const size_t vi = (bj * a.lmax + t) * a.hd + d;
+  if (a.to_engine) {
+    store_kv(kc + ki, a.k_hf[i]);
+    store_kv(vc + vi, a.v_hf[i]);
+  } else {
+    a.k_hf[i] = to_f32(kc[ki]);
+    a.v_hf[i] = to_f32(vc[vi]);
+  }
+}
+
+template <typename KT>
 __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
   const int row = blockIdx.x;
   const int b = a.row_seq[row], pos = a.row_pos[row];
+  const int rpos = a.rope_pos ? a.rope_pos[row] : pos;
   const int half = a.hd >> 1;
   const int nh = a.n_q + 2 * a.n_kv;
   const float* src = a.qkv + (size_t)row * nh * a.hd;
@@ -184,7 +218,7 @@ __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
     const int head = p / half, i = p - head * half;
     if (head < a.n_q + a.n_kv) {
       const float v0 = src[head * a.hd + i], v1 = src[head * a.hd + i + half];
-      const float c = a.cos_tab[(size_t)pos * half + i], s = a.sin_tab[(size_t)pos * half + i];
+      const float c = a.cos_tab[(size_t)rpos * half + i], s = a.sin_tab[(size_t)rpos * half + i];
       const float o0 = v0 * c - v1 * s, o1 = v1 * c + v0 * s;
       if (head < a.n_q) {
         float* q = a.qbuf + (size_t)row * a.n_q * a.hd + head * a.hd;

@@ -28,6 +28,7 @@ EXPORTS = [
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
+    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length",
 ]
 
 
@@ -120,6 +121,10 @@ def load_library(path: Optional[str] = None):
     lib.csm_kv_copy.argtypes = [vp, vp]
     lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     lib.csm_read_zero_counts.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
+    lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
+    lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
+    lib.csm_set_length.argtypes = [vp, i32, i32]
     lib.csm_set_debug_buffer.argtypes = [vp, vp, i32]
     lib.csm_last_geoms.argtypes = [vp, C.POINTER(C.c_int32), i32, C.POINTER(i32)]
     if path is None:
@@ -350,10 +355,17 @@ class Engine:
         torch.cuda.current_stream().synchronize()
         return ids, m
 
-    def prefill(self, ids: torch.Tensor, mask: Optional[torch.Tensor], want_outputs: bool = True):
-        """ids/mask [B,S,C+1].  Appends S positions; returns (last_h [B,Hb], c0_logits [B,V]) fp32."""
+    def prefill(self, ids: torch.Tensor, mask: Optional[torch.Tensor], want_outputs: bool = True,
+                position_ids: Optional[torch.Tensor] = None):
+        """ids/mask [B,S,C+1].  Appends S positions; returns (last_h [B,Hb], c0_logits [B,V]) fp32.
+        `position_ids` [B,S] (or [1,S]): caller-supplied RoPE positions (the reference forwards them to LlamaModel)."""
         B, S = ids.shape[0], ids.shape[1]
         ids, m = self._prep_ids(ids, mask)
+        pos = None
+        if position_ids is not None:
+            pos = position_ids.to(self.device).expand(B, S).to(torch.int32).contiguous()
+            if int(pos.min()) < 0 or int(pos.max()) >= self.packed["backbone"]["npos"]:
+                raise ValueError(f"position_ids must lie in [0, {self.packed['backbone']['npos']}) (RoPE table of the engine)")
         lh = torch.empty(B, self.Hb, dtype=torch.float32, device=self.device) if want_outputs else None
         lg = torch.empty(B, self.V, dtype=torch.float32, device=self.device) if want_outputs else None
         torch.cuda.current_stream().synchronize()
@@ -365,7 +377,11 @@ class Engine:
             ci = ids[:, done:done + n].contiguous()
             cm = m[:, done:done + n].contiguous() if m is not None else None
             torch.cuda.current_stream().synchronize()
-            if n == 1 and self.length > 0:
+            if pos is not None:
+                cp = pos[:, done:done + n].contiguous()
+                torch.cuda.current_stream().synchronize()
+                _ck(self.lib, self.lib.csm_prefill_pos(self._h, _ptr(ci), _ptr(cm), B, n, _ptr(cp), _ptr(lh), _ptr(lg)))
+            elif n == 1 and self.length > 0:
                 _ck(self.lib, self.lib.csm_backbone_step_ids(self._h, _ptr(ci), _ptr(cm), B, 0))
                 _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
             else:
@@ -437,6 +453,38 @@ class Engine:
         _ck(self.lib, self.lib.csm_get_state(self._h, _ptr(lh), _ptr(lg)))
         self.sync()
         return lh, lg
+
+    def export_kv(self):
+        """Backbone KV cache of the resident batch in the HF layout: list over layers of (keys, values), each
+        [B, n_kv, length, head_dim] fp32 on the device (what transformers' DynamicCache holds per layer)."""
+        lc = self.cfg.backbone_config
+        out = []
+        for l in range(lc.num_hidden_layers):
+            k = torch.empty(self.batch, lc.num_key_value_heads, self.length, lc.head_dim, dtype=torch.float32, device=self.device)
+            v = torch.empty_like(k)
+            torch.cuda.current_stream().synchronize()
+            _ck(self.lib, self.lib.csm_kv_export(self._h, l, _ptr(k), _ptr(v), self.length))
+            out.append((k, v))
+        self.sync()
+        return out
+
+    def import_kv(self, layers):
+        """Inverse of export_kv: the engine continues from the caller's per-layer (keys, values)."""
+        lc = self.cfg.backbone_config
+        if len(layers) != lc.num_hidden_layers:
+            raise ValueError(f"expected {lc.num_hidden_layers} layers of (keys, values), got {len(layers)}")
+        B, _, L, _ = layers[0][0].shape
+        for l, (k, v) in enumerate(layers):
+            if tuple(k.shape) != (B, lc.num_key_value_heads, L, lc.head_dim) or tuple(v.shape) != tuple(k.shape):
+                raise ValueError(f"layer {l}: keys/values must be [B, {lc.num_key_value_heads}, L, {lc.head_dim}]")
+            k = k.to(self.device, torch.float32).contiguous()
+            v = v.to(self.device, torch.float32).contiguous()
+            torch.cuda.current_stream().synchronize()
+            _ck(self.lib, self.lib.csm_kv_import(self._h, l, _ptr(k), _ptr(v), B, L))
+            self.sync()
+        _ck(self.lib, self.lib.csm_set_length(self._h, B, L))
+        self.sync()
+        self.batch, self.length = B, L
 
     def zero_counts(self, first: int, n: int):
         """rows whose frame was all-zero, for frames first .. first+n-1 (one stream sync)."""

@@ -54,11 +54,35 @@ class CSMKVCache:
     place), this object only proves which engine state a later call continues from."""
 
     def __init__(self, model: "CSMModel", epoch: int, length: int, batch: int, frame_pending: bool):
+        import weakref
         self._model_id = id(model)
+        self._model_ref = weakref.ref(model)
         self.epoch, self.length, self.batch, self.frame_pending = epoch, length, batch, frame_pending
 
     def get_seq_length(self) -> int:
         return self.length
+
+    def to_legacy_cache(self):
+        """The cache in the HF layout the reference hands out (`DynamicCache`, modeling_csm.py:355-358): a tuple over
+        backbone layers of (keys, values), each `[B, n_kv, length, head_dim]` fp32 on the device.  A copy: it can be
+        kept, forked or edited and passed back as `past_key_values` later (the engine imports it)."""
+        m = self._model_ref()
+        if m is None or m._engine is None or self.epoch != m._epoch or self.length != m._engine.length:
+            raise ValueError("stale cache handle: only the handle returned by the most recent call can be exported")
+        return tuple(m._engine.export_kv())
+
+
+def _hf_cache_layers(pkv):
+    """(keys, values) per layer out of a legacy tuple / list, a transformers >= 4.56 DynamicCache (`.layers[i].keys`)
+    or an older one (`.key_cache` / `.value_cache`); None if `pkv` is none of these."""
+    if isinstance(pkv, (tuple, list)) and pkv and isinstance(pkv[0], (tuple, list)) and len(pkv[0]) >= 2 \
+            and torch.is_tensor(pkv[0][0]):
+        return [(l[0], l[1]) for l in pkv]
+    if hasattr(pkv, "layers") and len(getattr(pkv, "layers")) and hasattr(pkv.layers[0], "keys"):
+        return [(l.keys, l.values) for l in pkv.layers]
+    if hasattr(pkv, "key_cache") and hasattr(pkv, "value_cache"):
+        return list(zip(pkv.key_cache, pkv.value_cache))
+    return None
 
 
 _default_engine_for_sampling = {}
@@ -293,11 +317,24 @@ class CSMModel(nn.Module):
         as in the reference."""
         if labels is not None:
             raise NotImplementedError("the training branch (labels=) is out of scope of csm_hf_amd")
-        if position_ids is not None:
-            raise NotImplementedError("explicit position_ids are not supported (the reference passes None)")
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         use_cache = use_cache if use_cache is not None else self._using_kv_cache
         B, S = input_ids.shape[0], input_ids.shape[1]
+        if position_ids is not None and tuple(position_ids.shape) not in ((B, S), (1, S)):
+            raise ValueError(f"position_ids must be [B, S] or [1, S], got {tuple(position_ids.shape)}")
+        hf_layers = None if isinstance(past_key_values, CSMKVCache) else _hf_cache_layers(past_key_values)
+        if hf_layers is not None:
+            # a cache in the HF layout (exported earlier, forked, or built elsewhere): import it and continue from it
+            L = hf_layers[0][0].shape[2]
+            if hf_layers[0][0].shape[0] != B:
+                raise ValueError("past_key_values batch does not match input_ids")
+            eng = self._ensure_engine(B, L + S + 1, 1, B * S)
+            eng.reset()
+            self._epoch += 1
+            self._frame_pending = False
+            eng.set_kv_start([0] * B)
+            eng.import_kv(hf_layers)
+            past_key_values = CSMKVCache(self, self._epoch, L, B, False)
         cont = past_key_values is not None
         if cont:
             if not isinstance(past_key_values, CSMKVCache) or past_key_values.epoch != self._epoch or \
@@ -312,12 +349,13 @@ class CSMModel(nn.Module):
             self._epoch += 1
             self._frame_pending = False
             eng.set_kv_start(self._kv_starts(attention_mask, B, S))
-        if cont and S == 1:
+        if cont and S == 1 and position_ids is None and eng.length > 0:
             last_h, c0 = eng.step_ids(input_ids, attention_mask, advance_frame=self._frame_pending)
         else:
             if cont and self._frame_pending:
-                raise NotImplementedError("multi-frame continuation right after generate_frame is not supported")
-            last_h, c0 = eng.prefill(input_ids, attention_mask)
+                raise NotImplementedError("right after generate_frame only the reference's own continuation is supported: "
+                                          "ONE frame, no position_ids (multi-frame / re-positioned steps are not)")
+            last_h, c0 = eng.prefill(input_ids, attention_mask, position_ids=position_ids)
         self._frame_pending = False
         pkv = CSMKVCache(self, self._epoch, eng.length, B, False) if use_cache else None
         last_h, c0 = self._out_dtype(last_h), self._out_dtype(c0)
@@ -329,8 +367,10 @@ class CSMModel(nn.Module):
     @torch.no_grad()
     def generate_frame(self, input_ids, attention_mask, position_ids=None, temperature=1.0, topk=50,
                        past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
-                       return_dict=None):
-        """reference :484-589."""
+                       return_dict=None, *, noise: Optional[torch.Tensor] = None):
+        """reference :484-589.  `noise` (extension) `[B, 32, V]`: explicit Exp(1) draws that replace the device RNG -- the
+        reference's `torch.empty_like(probs).exponential_(1)` (:175) made reproducible: with the reference's own draws the
+        sampled tokens are the reference's."""
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         use_cache = use_cache if use_cache is not None else self._using_kv_cache
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
@@ -340,7 +380,8 @@ class CSMModel(nn.Module):
             # every frame of this path has already been handed to the caller (the reference keeps none either,
             # :578-589): restart the on-device ring instead of limiting a stream to max_frames frames
             eng.rewind_frames()
-        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed(), row_offset=self.row_offset)
+        nz = None if noise is None else self._check_noise(noise, eng.batch).to(eng.device, torch.float32).contiguous()
+        s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed(), row_offset=self.row_offset, noise=nz)
         eng.decode_frame(s)
         tokens = eng.read_frames(eng.frames, 1)[:, 0, :]
         self._frame_pending = True
@@ -351,6 +392,12 @@ class CSMModel(nn.Module):
             return tokens
         return CSMOutput(last_hidden_state=out.last_hidden_state, logits=out.logits, past_key_values=pkv, samples=tokens)
 
+    def _check_noise(self, noise: torch.Tensor, B: int) -> torch.Tensor:
+        want = (B, self.config.audio_num_codebooks, self.config.audio_vocab_size)
+        if tuple(noise.shape) != want:
+            raise ValueError(f"noise must be {want} (one Exp(1) draw per row, codebook and vocabulary entry), got {tuple(noise.shape)}")
+        return noise
+
     def _next_seed(self) -> int:
         self.seed += 1
         return (int(torch.initial_seed()) * 1000003 + self.seed) & (2 ** 63 - 1)
@@ -358,12 +405,13 @@ class CSMModel(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: int = 100,
                  temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True,
-                 *, seed: Optional[int] = None, per_row_stop: bool = False):
+                 *, seed: Optional[int] = None, per_row_stop: bool = False, noise: Optional[torch.Tensor] = None):
         """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.  `seed` (extension, default: drawn
         from torch's seed and a call counter) keys the device Philox stream of the sampler.  `per_row_stop` (extension,
         SURVEY.md section 8 f-4): a row that has emitted an all-zero frame is frozen (emits zeros from then on), generation
         ends when the last row has finished, `self.last_row_lengths` holds every row's own frame count; the default keeps
-        the reference's global rule (:662: stop when ALL rows emit an all-zero frame in the same step).
+        the reference's global rule (:662: stop when ALL rows emit an all-zero frame in the same step).  `noise`
+        (extension) `[max_new_frames, B, 32, V]`: explicit Exp(1) draws instead of the device RNG (see generate_frame).
 
         One prefill, then per frame one replay of the captured hipGraph (31-step decoder loop + next
         backbone step).  With `stop_on_all_zeros` the host checks each frame (one sync per frame, like the
@@ -381,7 +429,19 @@ class CSMModel(nn.Module):
         s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed() if seed is None else int(seed),
                          row_offset=self.row_offset, per_row_stop=per_row_stop and stop_on_all_zeros)
         n = 0
-        if stop_on_all_zeros:
+        if noise is not None:
+            # one frame per launch: the engine takes one [B, 32, V] block of draws per call
+            if noise.shape[0] < max_new_frames:
+                raise ValueError("noise holds fewer frames than max_new_frames")
+            while n < max_new_frames:
+                nz = self._check_noise(noise[n], B).to(eng.device, torch.float32).contiguous()
+                s.noise = nz.data_ptr()
+                eng.generate(s, 1, self.use_graph)
+                eng.sync()
+                if stop_on_all_zeros and eng.zero_counts(n, 1)[0] >= B:
+                    break
+                n += 1
+        elif stop_on_all_zeros:
             # The reference syncs once per frame (`torch.all(new_frame == 0)`, :662).  Here every backbone step counts the
             # all-zero rows of its frame on the device; k frames are replayed, k counters read with ONE sync, and the
             # result is cut at the first frame all B rows left empty -- exactly the frames the per-frame test returns

@@ -146,6 +146,18 @@ int csm_set_option(csm_engine_t* e, const char* name, int value);
 int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S,
                 float* last_h_out, float* c0_logits_out);
 
+/* same with caller-supplied RoPE positions (reference `position_ids`, modeling_csm.py:296,349 -> LlamaModel): position_ids
+ * [B*S] int32 on the device, each < the bound RoPE table; the cache slot of a row stays (cached length + s), like HF,
+ * which masks by cache index and rotates by position_ids */
+int csm_prefill_pos(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* position_ids,
+                    float* last_h_out, float* c0_logits_out);
+/* backbone KV cache <-> the HF layout of `past_key_values` (transformers DynamicCache: per layer keys / values
+ * [B, n_kv, len, head_dim]; reference modeling_csm.py:355-358 returns it, :349 takes it back), fp32 on the device.
+ * Export reads the resident batch; import + csm_set_length continue a context the caller built, forked or edited. */
+int csm_kv_export(csm_engine_t* e, int layer, float* k_out, float* v_out, int len);
+int csm_kv_import(csm_engine_t* e, int layer, const float* k_in, const float* v_in, int B, int len);
+int csm_set_length(csm_engine_t* e, int B, int len);
+
 /* ---- CSMModel.generate_frame minus its backbone forward (modeling_csm.py:522-589): sample c0,
  * run the 31-step decoder loop, write the frame into the on-device ring at the current frame index. */
 int csm_decode_frame(csm_engine_t* e, const csm_sampling_t* s);

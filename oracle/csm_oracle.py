@@ -235,9 +235,10 @@ class FrameOut:
 # reference CSMModel.forward, inference branch (modeling_csm.py:321-365)
 # --------------------------------------------------------------------------------------------------
 def forward(sd, cfg, input_ids, attention_mask, cache: Optional[KVCache] = None, use_cache: bool = True,
-            hidden_trace: Optional[list] = None):
+            hidden_trace: Optional[list] = None, position_ids: Optional[torch.Tensor] = None):
+    """`position_ids` [B,S] | [1,S] | None: forwarded to the backbone as the reference does (modeling_csm.py:349)."""
     h, valid = embed_frames(sd, cfg, input_ids, attention_mask)
-    hb, cache = llama_forward(sd, "backbone", cfg.backbone_config, h, None, cache if use_cache else None,
+    hb, cache = llama_forward(sd, "backbone", cfg.backbone_config, h, position_ids, cache if use_cache else None,
                               new_valid=valid, hidden_trace=hidden_trace)
     c0_all = F.linear(hb, sd["codebook0_head.weight"])          # all S positions, like the reference
     return hb[:, -1, :], c0_all[:, -1, :], (cache if use_cache else None)
