@@ -135,7 +135,206 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
     }
   }
 }
+
+// ---- prefill_precision = bf16 ---------------------------------------------------------------------------------------
+// The same flash loop on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 2.5 PFLOP/s dense): Q, K, V and the
+// probabilities are rounded to the nearest bf16 (what the reference's bf16 SDPA does), scores, running max / sum and
+// the output accumulate in fp32.  64 keys per tile, both products transposed as above, so a lane still owns one query
+// row.  The second product contracts over keys in the order the two score accumulators hold them: the 8 keys of lane
+// half lh at 16-key step (hh, u) are 32hh + 16u + 4lh + {0..3} and 32hh + 16u + 8 + 4lh + {0..3}; the V tile is stored
+// transposed in LDS with its keys permuted so that those 8 are contiguous (one 16-byte read per operand).
+typedef __attribute__((ext_vector_type(8))) short ap_bf16x8;
+typedef __attribute__((ext_vector_type(2))) float ap_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ap_bf16x2;
+
+__device__ __forceinline__ uint32_t ap_pack2(float lo, float hi) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  const ap_f32x2 v = {lo, hi};
+  const ap_bf16x2 r = __builtin_convertvector(v, ap_bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+__device__ __forceinline__ ap_bf16x8 ap_pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  u32x4 w;
+  w[0] = ap_pack2(a0, a1); w[1] = ap_pack2(a2, a3); w[2] = ap_pack2(a4, a5); w[3] = ap_pack2(a6, a7);
+  return *reinterpret_cast<const ap_bf16x8*>(&w);
+}
+// position of key k (0..63) inside a row of the transposed V tile
+__device__ __forceinline__ int ap_vperm(int k) {
+  const int w = k & 15;
+  return (((k >> 4) * 2 + ((w >> 2) & 1)) * 8) + (w & 3) + 4 * (w >> 3);
+}
+
+template <typename KT>
+struct ApStage;   // one thread's share of a 64-key K / V tile, in flight in registers while the previous tile is computed
+template <>
+struct ApStage<float> {
+  f32x4 k[4], v[4];
+  __device__ __forceinline__ void load(const float* kc, const float* vc, int lmax, int kt0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int key = min(kt0 + (idx & 63), lmax - 1);
+      k[i] = *reinterpret_cast<const f32x4*>(kc + ((size_t)(idx >> 6) * lmax + key) * 4);
+    }
+    const float* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(vsrc + 4 * i);
+  }
+  __device__ __forceinline__ uint2 kword(int i) const { return make_uint2(ap_pack2(k[i][0], k[i][1]), ap_pack2(k[i][2], k[i][3])); }
+  // bf16 bits of V[key][16c + 2q] (low half) and V[key][16c + 2q + 1] (high half)
+  __device__ __forceinline__ uint32_t vpair(int q) const { return ap_pack2(v[q >> 1][(2 * q) & 3], v[q >> 1][(2 * q + 1) & 3]); }
+};
+template <>
+struct ApStage<bf16_t> {
+  uint2 k[4];
+  u32x4 v[2];
+  __device__ __forceinline__ void load(const bf16_t* kc, const bf16_t* vc, int lmax, int kt0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int key = min(kt0 + (idx & 63), lmax - 1);
+      k[i] = *reinterpret_cast<const uint2*>(kc + ((size_t)(idx >> 6) * lmax + key) * 4);
+    }
+    const bf16_t* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * 16;
+    v[0] = *reinterpret_cast<const u32x4*>(vsrc);
+    v[1] = *reinterpret_cast<const u32x4*>(vsrc + 8);
+  }
+  __device__ __forceinline__ uint2 kword(int i) const { return k[i]; }
+  __device__ __forceinline__ uint32_t vpair(int q) const { return v[q >> 2][q & 3]; }
+};
+
+template <typename KT>
+__global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
+  constexpr int HD = 64, LDK = 72;   // 144-byte LDS rows: 16-byte reads of 32 consecutive rows cover all banks evenly
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LDK];   // [key][d]
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * LDK];   // [d][ap_vperm(key)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = a.n_q / a.n_kv;
+  const int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
+  const int j = blockIdx.y, b = blockIdx.z;
+  const int s0 = qt * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool head_live = wave < G;
+  const int h = j * G + (head_live ? wave : 0);
+  const int kv_lo = a.kv_start ? a.kv_start[b] : 0;
+  const int s_last = min(a.S - 1, s0 + 31);
+  const int kmax = a.past + s_last;
+  const int s = s0 + li;
+  const bool row_live = s < a.S && head_live;
+  const int row_kmax = a.past + s;
+  const bool tile_full = s0 + 31 < a.S;   // every lane of the tile owns a real row
+
+  ap_bf16x8 qf[4];   // B operand of S^T = K Q^T: lane (row li, half lh) holds Q[row][16t + 8lh .. +7]
+  {
+    const float* qrow = a.q + ((size_t)b * a.S + (s < a.S ? s : a.S - 1)) * a.n_q * HD + (size_t)h * HD + 8 * lh;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(qrow + 16 * t), x1 = *reinterpret_cast<const f32x4*>(qrow + 16 * t + 4);
+      qf[t] = row_live ? ap_pack8(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]) : (ap_bf16x8)(0);
+    }
+  }
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+
+  f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);
+  float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units
+  constexpr float L2E = 1.4426950408889634f;
+
+  ApStage<KT> st;
+  int kt0 = kv_lo & ~63;
+  st.load(kc, vc, a.lmax, kt0, tid);
+  // where this thread's V share lands: rows d = 16*wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
+  const int vkey = tid & 63;
+  uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
+  for (; kt0 <= kmax; kt0 += 64) {
+    // ---- registers -> LDS ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = st.kword(i);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
+      const uint32_t mine = st.vpair(q);
+      const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
+      const uint32_t w = (vkey & 1) ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
+      vdst[(2 * q * LDK) / 2] = w;
+    }
+    __syncthreads();
+    if (kt0 + 64 <= kmax) st.load(kc, vc, a.lmax, kt0 + 64, tid);   // next tile in flight behind this tile's math
+    // ---- S^T[key][row] = sum_d K[key][d] Q[row][d], two 32-key halves ----------------------------------------------
+    f32x16 sc0 = (f32x16)(0.f), sc1 = (f32x16)(0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const ap_bf16x8 k0 = *reinterpret_cast<const ap_bf16x8*>(&Ks[li * LDK + 16 * t + 8 * lh]);
+      const ap_bf16x8 k1 = *reinterpret_cast<const ap_bf16x8*>(&Ks[(32 + li) * LDK + 16 * t + 8 * lh]);
+      sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], sc0, 0, 0, 0);
+      sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], sc1, 0, 0, 0);
+    }
+    // interior tiles (every key visible to every row) skip the mask
+    const bool interior = tile_full && kt0 >= kv_lo && kt0 + 63 <= a.past + s0;
+    if (!interior) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sc0[r] = (row_live && key >= kv_lo && key <= row_kmax) ? sc0[r] : -INFINITY;
+        sc1[r] = (row_live && key + 32 >= kv_lo && key + 32 <= row_kmax) ? sc1[r] : -INFINITY;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc0[r], sc1[r]));
+    mx = xor32_max(mx) * L2E;
+    const float m_new = fmaxf(m_run, mx);
+    const bool any = m_new > -INFINITY;
+    const float alpha = any ? exp2f(m_run - m_new) : 1.f;
+    const float neg_m = any ? -m_new : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc0[r] = exp2f(fmaf(sc0[r], L2E, neg_m));   // exp2(-inf) = 0 for masked keys
+      sc1[r] = exp2f(fmaf(sc1[r], L2E, neg_m));
+      sum += sc0[r] + sc1[r];
+    }
+    sum = xor32_sum(sum);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+    o0 *= alpha;
+    o1 *= alpha;
+    // ---- O^T[d][row] += sum_key V[key][d] P[row][key] -------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // u = 2*hh + step
+      const f32x16& sc = (u < 2) ? sc0 : sc1;
+      const int r0 = 8 * (u & 1);
+      const ap_bf16x8 pb = ap_pack8(sc[r0], sc[r0 + 1], sc[r0 + 2], sc[r0 + 3], sc[r0 + 4], sc[r0 + 5], sc[r0 + 6], sc[r0 + 7]);
+      const ap_bf16x8 v0 = *reinterpret_cast<const ap_bf16x8*>(&Vt[li * LDK + (2 * u + lh) * 8]);
+      const ap_bf16x8 v1 = *reinterpret_cast<const ap_bf16x8*>(&Vt[(32 + li) * LDK + (2 * u + lh) * 8]);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
+    }
+    __syncthreads();   // the tile is rewritten at the top of the next iteration
+  }
+  if (!row_live) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  float* dst = a.out + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int d = 8 * r4 + 4 * lh;
+    f32x4 v0, v1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v0[i] = o0[4 * r4 + i] * inv; v1[i] = o1[4 * r4 + i] * inv; }
+    if (a.oplanes) {
+      bf16_t* pd = a.oplanes + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
+      store_rowplanes4(pd + d, a.plane_stride, v0);
+      store_rowplanes4(pd + 32 + d, a.plane_stride, v1);
+    } else {
+      *reinterpret_cast<f32x4*>(dst + d) = v0;
+      *reinterpret_cast<f32x4*>(dst + 32 + d) = v1;
+    }
+  }
+}
 #endif  // CSM_ARGS_ONLY
 
 // returns -2 when the shape is not covered (head_dim != 64 or more than 4 q-heads per kv-head)
-int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a);
+// bf16_math: Q / K / V / P rounded to bf16 on the bf16 matrix pipe (prefill_precision = bf16) instead of exact fp32
+int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);

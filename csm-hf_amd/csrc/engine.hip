@@ -41,7 +41,7 @@ int configure_sample();
 int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz);
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
-int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a);
+int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -126,6 +126,7 @@ struct csm_engine {
   int prefill_splitk = 1;
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
+  int prefill_bf16_attn = 1;   // with prefill_bf16: the context attention on the bf16 matrix pipe too (0 = keep the fp32-MFMA flash kernel)
   // host mirrors
   int B = 0;
   int h_len = 0, h_frame = 0;
@@ -475,6 +476,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
+  else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
@@ -909,7 +911,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;
     fa.S = S; fa.past = e->h_len; fa.kv_start = e->d_kv_start; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
-    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa) : -2;
+    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, one && e->prefill_bf16_attn) : -2;
     bool att_pl = pl && fr != -2;
     if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
       AttnArgs t{};

@@ -270,6 +270,46 @@ def test_position_ids_cache_interchange_and_explicit_noise():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("kv_dtype", [torch.float32, torch.bfloat16])
+def test_prefill_bf16_attention_on_the_bf16_matrix_pipe(kv_dtype):
+    """prefill_precision = "bf16" runs the context attention on v_mfma_f32_32x32x16_bf16 (Q, K, V and the probabilities
+    rounded to bf16, fp32 accumulation).  Checked (i) against the oracle's fp32 forward (stated tolerance: rel-L2 3e-2,
+    the bf16 distance), (ii) against the same mode with the exact fp32-MFMA attention kernel (differs only by the
+    attention's own rounding), (iii) a left-padded row against its solo run, (iv) a continuation (past > 0, query rows
+    not starting at a tile boundary) against the one-shot prefill -- at a ragged length (77 = 2 tiles + 13 rows)."""
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=3, std=0.05, dtype=torch.bfloat16, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.kv_dtype = kv_dtype
+    sd32 = {k: v.float() for k, v in sd.items()}
+    ids, mask = synth_context(cfg, 2, 20, 57, seed=23)
+    want, _, _ = O.forward(sd32, cfg, ids, mask)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    m.prefill_precision = "bf16"
+    got = m.forward(ids.to(DEV), mask.to(DEV), use_cache=True).last_hidden_state.cpu()
+    assert 1e-6 < rel(got, want) < 3e-2, rel(got, want)
+    m._engine.set_option("prefill_bf16_attn", 0)
+    ref_attn = m.forward(ids.to(DEV), mask.to(DEV), use_cache=True).last_hidden_state.cpu()
+    m._engine.set_option("prefill_bf16_attn", 1)
+    assert 0 < rel(got, ref_attn) < 2e-2, rel(got, ref_attn)
+    # (iii) row 1 left-padded by 13 frames equals its solo run over the unpadded tail
+    pad = 13
+    ids_p, mask_p = ids.clone(), mask.clone()
+    ids_p[1, :pad] = 0
+    mask_p[1, :pad] = 0
+    padded = m.forward(ids_p.to(DEV), mask_p.to(DEV), use_cache=True).last_hidden_state.cpu()
+    solo = m.forward(ids[1:, pad:].to(DEV), mask[1:, pad:].to(DEV), use_cache=True).last_hidden_state.cpu()
+    assert rel(padded[1:], solo) < 1e-2, rel(padded[1:], solo)
+    assert torch.isfinite(padded).all()
+    # (iv) 45 frames, then 32 more on top of the cache
+    o1 = m.forward(ids[:, :45].to(DEV), mask[:, :45].to(DEV), use_cache=True)
+    o2 = m.forward(ids[:, 45:].to(DEV), mask[:, 45:].to(DEV), past_key_values=o1.past_key_values, use_cache=True)
+    assert rel(o2.last_hidden_state.cpu(), got) < 1e-2
+    m._drop_engine()
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
