@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcsm_hip.so")
-UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "launchers", "engine"]
+UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "attn_prefill", "launchers", "engine"]
+UNIT_FLAGS = {"attn_prefill": ["-mllvm", "--amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 
 
@@ -43,7 +44,7 @@ def build_library(force: bool = False, verbose: bool = False, defines=(), out: s
     os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(u):
-        cmd = [hipcc, *FLAGS, *[f"-D{d}=1" for d in defines], "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(obj_dir, u + ".o")]
+        cmd = [hipcc, *FLAGS, *UNIT_FLAGS.get(u, []), *[f"-D{d}=1" for d in defines], "-c", os.path.join(CSRC, u + ".hip"), "-o", os.path.join(obj_dir, u + ".o")]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {u}.hip:\n{r.stderr[-4000:]}")

@@ -21,7 +21,7 @@ struct PrefillAttnArgs {
   size_t plane_stride;
 };
 
-#ifndef CSM_ARGS_ONLY
+#ifdef CSM_ATTN_PREFILL_KERNELS   // defined by attn_prefill.hip only
 // Both products are computed TRANSPOSED so that a lane owns one query row end to end:
 //   S^T[key][row] = K Q^T   (A = K tile from LDS, B = Q from registers)  -> lane (row = lane&31, half) holds 16 keys
 //   O^T[d][row]   = V^T P^T (A = V tile from LDS, B = P straight from the score accumulator registers)
@@ -202,6 +202,12 @@ struct ApStage<bf16_t> {
   __device__ __forceinline__ uint32_t vpair(int q) const { return v[q >> 2][q & 3]; }
 };
 
+__device__ __forceinline__ float ap_max3(float a, float b, float c) {   // no NaN canonicalisation round trips
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 template <typename KT>
 __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
   constexpr int HD = 64, LDK = 72;   // 144-byte LDS rows: 16-byte reads of 32 consecutive rows cover all banks evenly
@@ -220,8 +226,11 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   const int kmax = a.past + s_last;
   const int s = s0 + li;
   const bool row_live = s < a.S && head_live;
-  const int row_kmax = a.past + s;
-  const bool tile_full = s0 + 31 < a.S;   // every lane of the tile owns a real row
+  // keys this lane's row may see: [row_lo, row_lo + row_span]; a dead row sees none
+  const int row_lo = kv_lo;
+  const unsigned row_span = row_live && a.past + s >= kv_lo ? (unsigned)(a.past + s - kv_lo) : 0u;
+  const bool row_any = row_live && a.past + s >= kv_lo;
+  const bool tile_full = s0 + 31 < a.S && G == 4;   // every lane of the workgroup owns a real row
 
   ap_bf16x8 qf[4];   // B operand of S^T = K Q^T: lane (row li, half lh) holds Q[row][16t + 8lh .. +7]
   {
@@ -236,8 +245,10 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
 
   f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);
-  float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units
-  constexpr float L2E = 1.4426950408889634f;
+  // running reference in log2 units.  It is NOT the running max: it only moves when a tile's max exceeds it by more than
+  // 2^8 (probabilities stay <= 256: harmless in bf16 / fp32), so the accumulator rescale is rare instead of per tile.
+  float m_run = -INFINITY, l_run = 0.f;
+  constexpr float L2E = 1.4426950408889634f, SLACK = 8.f;
 
   ApStage<KT> st;
   int kt0 = kv_lo & ~63;
@@ -245,6 +256,8 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   // where this thread's V share lands: rows d = 16*wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
   const int vkey = tid & 63;
   uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
+  // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
+  const uint32_t vsel = (vkey & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selector over {theirs, mine}
   for (; kt0 <= kmax; kt0 += 64) {
     // ---- registers -> LDS ------------------------------------------------------------------------------------
 #pragma unroll
@@ -254,11 +267,9 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
       const uint32_t mine = st.vpair(q);
       const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
-      const uint32_t w = (vkey & 1) ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
-      vdst[(2 * q * LDK) / 2] = w;
+      vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
     }
     __syncthreads();
     if (kt0 + 64 <= kmax) st.load(kc, vc, a.lmax, kt0 + 64, tid);   // next tile in flight behind this tile's math
@@ -274,33 +285,42 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
     // interior tiles (every key visible to every row) skip the mask
     const bool interior = tile_full && kt0 >= kv_lo && kt0 + 63 <= a.past + s0;
     if (!interior) {
+      const int base = kt0 + 4 * lh - row_lo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        sc0[r] = (row_live && key >= kv_lo && key <= row_kmax) ? sc0[r] : -INFINITY;
-        sc1[r] = (row_live && key + 32 >= kv_lo && key + 32 <= row_kmax) ? sc1[r] : -INFINITY;
+        const int rel = base + (r & 3) + 8 * (r >> 2);   // key - row_lo: valid iff 0 <= rel <= row_span
+        sc0[r] = (row_any && (unsigned)rel <= row_span) ? sc0[r] : -INFINITY;
+        sc1[r] = (row_any && (unsigned)(rel + 32) <= row_span) ? sc1[r] : -INFINITY;
       }
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc0[r], sc1[r]));
+    for (int r = 0; r < 16; ++r) mx = ap_max3(mx, sc0[r], sc1[r]);
     mx = xor32_max(mx) * L2E;
-    const float m_new = fmaxf(m_run, mx);
-    const bool any = m_new > -INFINITY;
-    const float alpha = any ? exp2f(m_run - m_new) : 1.f;
-    const float neg_m = any ? -m_new : 0.f;
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sc0[r] = exp2f(fmaf(sc0[r], L2E, neg_m));   // exp2(-inf) = 0 for masked keys
-      sc1[r] = exp2f(fmaf(sc1[r], L2E, neg_m));
-      sum += sc0[r] + sc1[r];
+    const bool move = mx > m_run + SLACK;   // also the first tile with a visible key (m_run = -inf)
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      const float m_new = move ? mx : m_run;
+      const float alpha = (move && m_run > -INFINITY) ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+      m_run = m_new;
+      l_run *= alpha;
+      o0 *= alpha;
+      o1 *= alpha;
     }
-    sum = xor32_sum(sum);
-    l_run = l_run * alpha + sum;
-    m_run = m_new;
-    o0 *= alpha;
-    o1 *= alpha;
+    const float neg_m = m_run > -INFINITY ? -m_run : 0.f;   // a row with no visible key so far: exp2(-inf) = 0 anyway
+    ap_f32x2 sum2 = {0.f, 0.f};
+    const ap_f32x2 l2e2 = {L2E, L2E}, nm2 = {neg_m, neg_m};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      ap_f32x2 x0 = {sc0[r], sc0[r + 1]}, x1 = {sc1[r], sc1[r + 1]};
+      x0 = x0 * l2e2 + nm2;
+      x1 = x1 * l2e2 + nm2;
+      x0[0] = __builtin_amdgcn_exp2f(x0[0]); x0[1] = __builtin_amdgcn_exp2f(x0[1]);
+      x1[0] = __builtin_amdgcn_exp2f(x1[0]); x1[1] = __builtin_amdgcn_exp2f(x1[1]);
+      sum2 += x0 + x1;
+      sc0[r] = x0[0]; sc0[r + 1] = x0[1];
+      sc1[r] = x1[0]; sc1[r + 1] = x1[1];
+    }
+    l_run += xor32_sum(sum2[0] + sum2[1]);
     // ---- O^T[d][row] += sum_key V[key][d] P[row][key] -------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < 4; ++u) {   // u = 2*hh + step
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
     }
   }
 }
-#endif  // CSM_ARGS_ONLY
+#endif  // CSM_ATTN_PREFILL_KERNELS
 
 // returns -2 when the shape is not covered (head_dim != 64 or more than 4 q-heads per kv-head)
 // bf16_math: Q / K / V / P rounded to bf16 on the bf16 matrix pipe (prefill_precision = bf16) instead of exact fp32

@@ -1,0 +1,19 @@
+// Prefill (q_len > 1) flash attention kernels in their own translation unit: compiled with the MFMA accumulators in
+// VGPRs (-mllvm --amdgpu-mfma-vgpr-form), because the softmax reads every score right after the product and the
+// round trip through the accumulation registers (v_accvgpr_read / write per element per tile) was a third of the loop.
+#define CSM_ATTN_PREFILL_KERNELS 1
+#include "attn_prefill.h"
+
+int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math) {
+  if (hd != 64 || a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 4 || a.S < 1) return -2;
+  const dim3 grid((a.S + 31) / 32, a.n_kv, B);
+  if (bf16_math) {
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
+  if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_prefill_kernel<float>), grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+

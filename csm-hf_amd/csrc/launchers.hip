@@ -33,19 +33,6 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   return e;
 }
 
-int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math) {
-  if (hd != 64 || a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 4 || a.S < 1) return -2;
-  const dim3 grid((a.S + 31) / 32, a.n_kv, B);
-  if (bf16_math) {
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);
-    return (int)hipGetLastError();
-  }
-  if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_kernel<bf16_t>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn_prefill_kernel<float>), grid, dim3(256), 0, st, a);
-  return (int)hipGetLastError();
-}
-
 template <typename WT, int BT, int BK>
 static int launch_gemm_x3_bk(hipStream_t st, int epi, const GemmArgs& a) {
   const int grid = ((a.R + BT - 1) / BT) * (a.N / BT);
