@@ -42,6 +42,7 @@ int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
+extern int g_gemm_wide, g_gemm_wide_depth, g_gemm_wide_krot;   // launchers.hip: 128 x 256 prefill GEMM tiles for one-plane activations (A/B switch)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -405,8 +406,13 @@ static int tile_one(csm_engine* e, const void* W, int N, int K) {
 }
 static int build_tiled(csm_engine* e) {
   drop_tiled(e);
-  if (!e->tile_weights || e->cfg.max_batch < 2 || e->cfg.weight_dtype == CSM_DTYPE_F32) return 0;
+  if (!e->tile_weights || e->cfg.weight_dtype == CSM_DTYPE_F32) return 0;
+  // the batched decode kernels (gemm16 / gemm32) stream every matrix from its copy; a one-sequence engine only needs the
+  // backbone's, for the wide prefill GEMM (gemm_wide_kernel), and only when its prefills can be large enough to use it
+  const bool decode_tiles = e->cfg.max_batch >= 2, prefill_tiles = e->cfg.max_prefill_rows >= 512;
+  if (!decode_tiles && !prefill_tiles) return 0;
   for (Stack* s : {&e->bb, &e->dec}) {
+    if (s == &e->dec && !decode_tiles) continue;
     const int H = s->c.hidden, F = s->c.ffn;
     for (auto& l : s->layers) {
       if (int r = tile_one(e, l.wqkv, s->nqkv(), H)) return r;
@@ -416,6 +422,7 @@ static int build_tiled(csm_engine* e) {
     }
   }
   const int Hb = e->bb.c.hidden, Hd = e->dec.c.hidden, V = e->cfg.audio_vocab, C = e->cfg.n_codebooks;
+  if (!decode_tiles) { HIPCK(hipStreamSynchronize(e->stream)); return 0; }
   if (int r = tile_one(e, e->w.proj_head0, Hd + V, Hb)) return r;
   for (int i = 0; i < C - 1; ++i)
     if (int r = tile_one(e, (const char*)e->w.audio_head_t + (size_t)i * V * Hd * w_esz(e), V, Hd)) return r;
@@ -477,6 +484,9 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
+  else if (!strcmp(name, "gemm_wide")) g_gemm_wide = value;
+  else if (!strcmp(name, "gemm_wide_depth")) g_gemm_wide_depth = value;
+  else if (!strcmp(name, "gemm_wide_krot")) g_gemm_wide_krot = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
@@ -863,6 +873,11 @@ extern "C" int csm_set_length(csm_engine_t* e, int B, int len) {
   return 0;
 }
 
+static const void* tiled_of(const csm_engine* e, const void* W) {
+  const auto it = e->tiled.find(W);
+  return it == e->tiled.end() ? nullptr : it->second;
+}
+
 static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* rope_pos,
                         float* last_h_out, float* c0_logits_out) {
   if (!e || !e->bound || !ids) return fail(CSM_ERR_STATE, "weights not bound / null ids");
@@ -890,7 +905,19 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
   // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
   const bool can_split = pl && e->prefill_splitk && e->p_part && R <= 4096;
-  const int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
+  int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
+  if (one && g_gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
+    // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
+    // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands
+    const long t = (long)((R + 127) / 128) * (Hb / 256);
+    auto wide_split = [&](int K, int cur) {
+      if (t >= 320) return 1;
+      const int ks = (int)((256 + t - 1) / t);
+      return (ks <= 4 && K % (256 * ks) == 0 && K / ks >= 1024 && t * ks >= 256) ? ks : cur;
+    };
+    ks_o = wide_split(nq * hd, ks_o);
+    ks_d = wide_split(F, ks_d);
+  }
   const size_t part_stride = R * (size_t)Hb;
   int pending = 0;   // splits waiting in p_part for the next RMSNorm
   for (int l = 0; l < s.c.layers; ++l) {
@@ -901,6 +928,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
+    g.Wt = tiled_of(e, w.wqkv);
     LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
     ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
@@ -922,6 +950,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
+    o.Wt = tiled_of(e, w.wo);
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
     if (att_pl && ks_o > 1) {
       o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
@@ -935,10 +964,12 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
+    gu.Wt = tiled_of(e, w.wgu);
     gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
+    d.Wt = tiled_of(e, w.wd);
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
     if (pl && ks_d > 1) {
       d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;

@@ -36,6 +36,9 @@ struct GemmArgs {
   int ksplit;
   float* Cpart;
   size_t part_stride;
+  // fragment-order copy of W (launchers.hip tile16_kernel; nullable): enables gemm_wide_kernel for one-plane activations
+  const void* Wt;
+  int krot;   // gemm_wide_kernel: start the k walk at a per-workgroup step (A/B; changes the fp32 summation order)
 };
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64
@@ -313,6 +316,171 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
           else a.C[(size_t)r * a.ldc + n] = v;
         }
       }
+}
+
+
+// ---- prefill_precision = bf16, launches with enough output tiles: 128 x 256 x 64 tile ------------------------------------
+// Four waves side by side along N (wave tile 128 x 64 = 8 x 4 MFMA tiles of 16 x 16, v_mfma_f32_16x16x32_bf16).  The
+// ACTIVATION tile goes through LDS (all four waves read all of it; double-buffered: one barrier per k-step); each wave
+// loads ITS OWN weight fragments straight from the fragment-order copy of the matrix (GemmArgs::Wt, the copy the decode
+// kernels stream: one fragment = one contiguous 1 KiB block per wavefront) into the MFMA operand registers -- nobody
+// else needs them, so they never touch LDS.  A fragment register is reloaded for the next k-step right after the MFMAs
+// that consumed it: every weight load has one whole k-step of matrix work in front of it.
+// Why: per k-step the square-tile kernel moves 2 KB through LDS per 32x32x16 MFMA (64 KB read + 32 KB written against
+// 512 matrix clocks per wave: 768 clocks of the 128 B/clk LDS port -> LDS-bound at 2/3 of the matrix rate before any
+// barrier); this one moves 16 KB written + 64 KB read against 1024 matrix clocks (640 port clocks).
+// (A first version read the fragments from the ROW-MAJOR matrix, lane = one weight row: 32-byte pieces of 32 different
+// lines per load instruction -- the texture path, not LDS, became the limit and it ran 1.4x SLOWER than the square tile.)
+// Roofline: bf16 MFMA, 2 R N K flops.
+typedef __attribute__((ext_vector_type(8))) short gw_bf16x8;
+template <typename WT, int EPI, int DEPTH>
+__global__ __launch_bounds__(256, DEPTH == 1 ? 2 : 1) void gemm_wide_kernel(GemmArgs a) {
+  // LDS rows of 160 bytes: with the lane groups ds_read_b128 / ds_write_b128 are serviced in ({0-3,12-15,20-27},
+  // {4-11,16-19,28-31}, +32) the operand reads (lane = row & 15, k group = lane >> 4) touch 16 distinct 16-byte bank
+  // slots per group at this stride (144 bytes, right for the 32x32x16 operand layout, gave 40 % conflict cycles here)
+  constexpr int BM = 128, BN = 256, BK = 64, LDK = BK + 16;
+  constexpr int MI = BM / 16, NI = BN / 4 / 16, KS = BK / 32;
+  __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m16 = lane & 15, g = lane >> 4;
+  const int nbm = (a.R + BM - 1) / BM, nbn = a.N / BN;
+  // tile order: workgroup b runs on XCD b % 8 (plus a per-stream rotation); the workgroups of one XCD walk the row
+  // blocks of ONE weight panel before moving to the next, so a panel is fetched from HBM once per XCD L2, not per row block
+  int bm, bn;
+  if (nbn % 8 == 0) {
+    const int q = (int)blockIdx.x >> 3;
+    bm = q % nbm;
+    bn = (q / nbm) * 8 + ((int)blockIdx.x & 7);
+  } else {
+    bm = (int)blockIdx.x % nbm;
+    bn = (int)blockIdx.x / nbm;
+  }
+  const int r0 = bm * BM, n0 = bn * BN + wave * (BN / 4);
+  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
+  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0, kend = kbeg + kspan;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4)(0.f);
+
+  // this thread's four 16-byte pieces of the activation tile: row = arow + 32 i, k piece ac8.  Each write lane group
+  // holds rows {r, r + 4} of its wave's 8 rows (slots 10 r + c and 10 (r + 4) + c = +8 mod 16: conflict-free)
+  const int l5 = lane & 31;
+  const bool wg2 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+  const int widx = wg2 ? (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16) : (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12);
+  const int arow = wave * 8 + (lane >> 5) * 2 + (wg2 ? 1 : 0) + 4 * (widx >> 3), ac8 = widx & 7;
+  const bf16_t* asrc = a.Aplanes + (size_t)(r0 + arow) * a.K + ac8 * 8;
+  u32x4 pa[4];
+  auto fetch_a = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pa[i] = (u32x4)(0u);
+      if (r0 + arow + 32 * i < a.R) pa[i] = *reinterpret_cast<const u32x4*>(asrc + (size_t)(32 * i) * a.K + k0);
+    }
+  };
+  auto stage_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[buf][(arow + 32 * i) * LDK + ac8 * 8]) = pa[i];
+  };
+  // fragment (16-row tile t, 32-wide k block kb) of the copy starts at (t * K/32 + kb) * 512 elements
+  const WT* wsrc = reinterpret_cast<const WT*>(a.Wt) + (size_t)(n0 >> 4) * a.K * 16 + lane * 8;
+  const size_t tstride = (size_t)a.K * 16;
+  // DEPTH k-steps of weight fragments in registers (one wave per SIMD: the register file is this wave's alone): the set
+  // of step s is reloaded for step s + DEPTH right after its MFMAs, i.e. every weight load has DEPTH k-steps of matrix
+  // work (DEPTH x 0.43 us at the full matrix rate) to cover an HBM round trip under load (~2 us)
+  u32x4 wf[DEPTH][NI][KS];
+  auto wload = [&](int set, int ni, int ks, int k0) {
+    wf[set][ni][ks] = load_w8_as_bf16<WT>(wsrc + ni * tstride + (size_t)((k0 >> 5) + ks) * 512);
+  };
+  // k is walked from a per-workgroup starting step, wrapping around: the workgroups of a launch would otherwise all sit
+  // at the same k at the same time, and with tiles 16 K elements (a power of two) apart every fragment request of that
+  // moment lands on the same few L2 / HBM channels (measured: ~1/4 of the L2 bandwidth, 24 % matrix-pipe busy)
+  const int nstep = kspan / BK;
+  const int s0 = a.krot ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nstep) : 0;
+  auto kof = [&](int i) {   // k of logical step i (0 <= i < nstep + DEPTH)
+    int t = s0 + i;
+    t = t >= nstep ? t - nstep : t;
+    t = t >= nstep ? t - nstep : t;
+    return kbeg + t * BK;
+  };
+  fetch_a(kof(0));
+#pragma unroll
+  for (int set = 0; set < DEPTH; ++set)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (set < nstep) wload(set, ni, ks, kof(set));
+  stage_a(0);
+  lds_barrier();
+  auto xload = [&](gw_bf16x8* xf, int buf, int ks) {   // B operands: lane (row m16, k group g) of the 8 row tiles
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      *reinterpret_cast<u32x4*>(&xf[mi]) = *reinterpret_cast<const u32x4*>(&As[buf][(mi * 16 + m16) * LDK + ks * 32 + g * 8]);
+  };
+  auto step = [&](int set, int buf, int i) {
+    const bool more = i + 1 < nstep, mored = i + DEPTH < nstep;
+    if (more) fetch_a(kof(i + 1));
+    const int kd = kof(i + DEPTH);
+    constexpr bool XDB = DEPTH > 1;   // room for both halves' operands only in the one-wave-per-SIMD form
+    gw_bf16x8 xf[XDB ? KS : 1][MI];
+    if (XDB) xload(xf[0], buf, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (!XDB) xload(xf[0], buf, ks);
+      else if (ks + 1 < KS) xload(xf[ks + 1], buf, ks + 1);   // the next half's operands fly under this half's MFMAs
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        gw_bf16x8 wfr;
+        *reinterpret_cast<u32x4*>(&wfr) = wf[set][ni][ks];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[XDB ? ks : 0][mi], acc[mi][ni], 0, 0, 0);
+        if (mored) wload(set, ni, ks, kd);
+      }
+    }
+    if (more) stage_a(buf ^ 1);
+    lds_barrier();   // LDS only: the weight loads of the next steps stay in flight
+  };
+  for (int i = 0; i < nstep; i += DEPTH) {   // the launcher guarantees a k span that is a multiple of DEPTH * BK
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) step(d, (i + d) & 1, i + d);
+  }
+  // ---- epilogue: C/D layout of 16x16x32 with the weights as the A operand: lane (m16, g) holds
+  //      C[row tile mi, row m16][col tile ni, columns 4g .. 4g+3] ----------------------------------------------------------
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int r = r0 + mi * 16 + m16;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + ni * 16 + 4 * g;
+      f32x4 v = acc[mi][ni];
+      if (a.wscale) {
+        const f32x4 ws = *reinterpret_cast<const f32x4*>(a.wscale + n);
+        v[0] *= ws[0]; v[1] *= ws[1]; v[2] *= ws[2]; v[3] *= ws[3];
+      }
+      if (EPI == GEPI_SWIGLU) {   // (gate, up) pairs: columns n/2, n/2 + 1 of the output
+        const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+        if (a.Cplanes) {
+          *reinterpret_cast<uint32_t*>(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1)) = (uint32_t)f32_to_bf16(h0) | ((uint32_t)f32_to_bf16(h1) << 16);
+        } else {
+          float* c = a.C + (size_t)r * a.ldc + (n >> 1);
+          c[0] = h0; c[1] = h1;
+        }
+      } else if (EPI == GEPI_PARTIAL) {
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+      } else if (EPI == GEPI_RESID) {
+        f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+        const f32x4 o = *c;
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        *c = v;
+      } else {
+        *reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n) = v;
+      }
+    }
+  }
 }
 
 #endif  // CSM_ARGS_ONLY

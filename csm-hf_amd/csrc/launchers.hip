@@ -77,8 +77,43 @@ static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
   return launch_gemm_x3_bk<WT, BT, 32>(st, epi, a);
 }
 
+// 128 x 256 tiles (gemm_wide_kernel) for one-plane activations when they fill the chip
+int g_gemm_wide = 1;   // A/B switch (csm_set_option "gemm_wide")
+int g_gemm_wide_krot = 0;
+int g_gemm_wide_depth = 1;   // A/B: weight-fragment sets in registers (1: two workgroups per CU; 4: one, 444 registers)
+template <typename WT, int DEPTH>
+static int launch_gemm_wide_d(hipStream_t st, int epi, const GemmArgs& a) {
+  const int tiles = ((a.R + 127) / 128) * (a.N / 256);
+  const dim3 grid(tiles, epi == GEPI_PARTIAL ? a.ksplit : 1);
+  switch (epi) {
+    case GEPI_STORE: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_STORE, DEPTH>), grid, dim3(256), 0, st, a); break;
+    case GEPI_RESID: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_RESID, DEPTH>), grid, dim3(256), 0, st, a); break;
+    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_SWIGLU, DEPTH>), grid, dim3(256), 0, st, a); break;
+    case GEPI_PARTIAL: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_PARTIAL, DEPTH>), grid, dim3(256), 0, st, a); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+template <typename WT>
+static int launch_gemm_wide(hipStream_t st, int epi, const GemmArgs& a) {
+  GemmArgs b = a;
+  b.krot = g_gemm_wide_krot;
+  return g_gemm_wide_depth == 4 ? launch_gemm_wide_d<WT, 4>(st, epi, b) : launch_gemm_wide_d<WT, 1>(st, epi, b);
+}
+static bool gemm_wide_ok(int epi, const GemmArgs& a) {
+  if (!g_gemm_wide || !a.Wt || !a.Aplanes || a.a_plane_stride != 0 || a.N % 256 || a.K % 256 || a.ldc % 4) return false;
+  if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return false;
+  const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
+  if (epi == GEPI_PARTIAL && (ks < 1 || a.K % (256 * ks) || !a.Cpart)) return false;
+  // measured (csm-1b shapes, tools/prefill_bench.py): at exactly one workgroup per CU the wide tile only ties the square
+  // one (gate/up at 512 rows: 59 vs 57 us; QKV at 2048 rows, 192 tiles: 52 vs 48 us); with two per CU it wins
+  // (gate/up at 2048 rows: 156 vs 187 us); the split-K partials win from one per CU on (67-84 vs 99 us)
+  return ((a.R + 127) / 128) * (a.N / 256) * ks >= (epi == GEPI_PARTIAL ? 256 : 320);
+}
+
 template <typename WT>
 static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
+  if (gemm_wide_ok(epi, a)) return launch_gemm_wide<WT>(st, epi, a);
   // 128x128 tiles unless they would occupy fewer than 256 workgroups
   if (epi == GEPI_PARTIAL) return a.K % 64 ? -1 : launch_gemm_x3_bk<WT, 64, 64>(st, epi, a);
   if (((a.R + 127) / 128) * (a.N / 128) < 256) return launch_gemm_x3_bt<WT, 64>(st, epi, a);

@@ -322,6 +322,32 @@ def test_csm1b_prefill_precision_bf16(gold, csm1b_bf16):
     finally:
         m.prefill_precision = "exact"
     assert out.shape == (1, 3, 32) and int(out.min()) >= 0 and int(out.max()) < m.config.audio_vocab_size
+    # the 128 x 256-tile GEMM (weight fragments straight from the fragment-order copy into the MFMA operand registers)
+    # against the square-tile kernel on the same bf16 activations.  Without a K split the two are BITWISE equal (the
+    # bf16 MFMA accumulates its products as one sequential fp32 chain in k order, whatever the instruction shape), which
+    # pins every path of the kernel: 1024 frames route gate/up through it, 2000 (ragged last row block) down_proj too.
+    # With the K split the wide launch prefers, the result moves by the distance two bf16-rounded trajectories have
+    # (a last-bit change flips bf16 roundings downstream): bounded by the mode's stated tolerance against the exact mode.
+    from csm_hf_amd.synth import synth_context
+    for ctx in (1024, 2000):
+        cids, cmask = synth_context(m.config, 1, ctx // 4, ctx - ctx // 4, seed=5)
+        outs = {}
+        for mode in ("exact", "bf16"):
+            for wide, splitk in ((1, 0), (0, 0), (1, 1)) if mode == "bf16" else ((1, 1),):
+                m.prefill_precision = mode
+                try:
+                    m.forward(cids.to(DEV), cmask.to(DEV), use_cache=True)          # engine exists from here on
+                    m._engine.set_option("gemm_wide", wide)
+                    m._engine.set_option("prefill_splitk", splitk)
+                    m.forward(cids.to(DEV), cmask.to(DEV), use_cache=True)
+                    outs[(mode, wide, splitk)] = m._engine.get_state()[0].cpu()    # fp32 hidden state
+                finally:
+                    m.prefill_precision = "exact"
+                    m._engine.set_option("gemm_wide", 1)
+                    m._engine.set_option("prefill_splitk", 1)
+        assert torch.isfinite(outs[("bf16", 1, 0)]).all()
+        assert torch.equal(outs[("bf16", 1, 0)], outs[("bf16", 0, 0)]), ctx
+        assert rel_l2(outs[("bf16", 1, 1)], outs[("exact", 1, 1)]) < 2.8e-2, ctx
 
 
 def test_csm1b_config2_200_frames(gold, csm1b_bf16):
