@@ -21,6 +21,7 @@
 #define CSM_ARGS_ONLY 1  // kernel definitions live in gemv.hip / launchers.hip
 #include "attn.h"
 #include "attn_prefill.h"
+#include "attn_oproj.h"
 #include "gemm.h"
 #include "gemm16.h"
 #include "gemm32.h"
@@ -133,6 +134,7 @@ struct csm_engine {
   int h_len = 0, h_frame = 0;
   bool ready = false;   // head_out holds valid c0 logits
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
+  int fuse_attn_oproj = 1;   // M = 1 decoder: attention + o_proj as one launch (attn_oproj.h)
   int fuse_dec_attn = 0;  // measured (round 1): separate 2-workgroup attention + register-path o_proj is 4 % faster per frame
   int use_mfma = 1;
   int flash_prefill = 1;
@@ -167,6 +169,7 @@ struct csm_engine {
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
   int pf_enable = 1, pf_window_mb = 24, pf_sub_kb = 4096, pf_grid = 256;
   int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
+  int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
   int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
   int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
@@ -187,7 +190,7 @@ struct csm_engine {
   // activations handed between the batched-decode launches as ready-made MFMA B operands (gemv.h: xplanes)
   bf16_t *pl_h = nullptr, *pl_act = nullptr;
   float* pl_ss = nullptr;
-  int use_planes = 15;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row
+  int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
@@ -312,6 +315,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   e->g16_slab_floats = (size_t)1 << 20;
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
   HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
+
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   // weight streamer: second stream, fork/join events, launch counter, and the dispatcher's workgroup -> XCD rotation
@@ -477,6 +481,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value;
   else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
+  else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
   else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
@@ -497,6 +502,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
   else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
+  else if (!strcmp(name, "g16_k16")) e->g16_k16 = value;
   else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_skip_late")) e->pf_skip_late = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 1 ? 1 : value;
@@ -570,6 +576,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       // capture of a single-group batch (M <= 16): the launch is paced / streamed (prefetch.h); larger batches re-stream
       // every matrix once per group and are left alone
       const bool rec = e->pf_rec && M <= 16 && e->pf_batched;
+      if (!a.g16_nw && e->g16_k16 && a.K == 2048 && a.xplanes) { a.g16_nw = e->g16_k16 & 0xff; a.g16_kb = (e->g16_k16 >> 8) & 0xff; }
       if (rec) { a.prog = e->d_prog; a.geom_out = &geom; }
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
@@ -637,7 +644,17 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   GemvArgs o{};
   o.nt = nt_small;
   o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
-  if (fuse_attn) {
+  int ao = -2;
+  if (M == 1 && e->fuse_attn_oproj && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
+    // single sequence, short cache: one launch for SDPA + o_proj (heads in parallel on the waves of each o_proj workgroup)
+    AttnOprojArgs f{};
+    f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
+    f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h;
+    ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
+    if (ao != -2) LCK(ao);
+  }
+  if (ao != -2) {
+  } else if (fuse_attn) {
     // short cache (decoder, <= 32 positions): SDPA runs as the prologue of the o_proj launch
     o.x = qb; o.n_q = nq; o.n_kv = nkv; o.hd = hd; o.pos_ptr = pos_ptr; o.pos_const = pos_const;
     o.kcache = s.kc[l]; o.vcache = s.vc[l]; o.lmax = s.lmax;
@@ -711,10 +728,13 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
     em.row_done = e->d_row_done;
   }
   em.out = e->h_bb;
+  // batched decode on planes: the embedding sum hands layer 0 its operands like every later producer does
+  const bool em_planes = planes_on(e, e->bb, B) && (e->use_planes & 16);
+  if (em_planes) { em.oplanes = e->pl_h; em.oln = e->bb.layers[0].ln1; em.oss = e->pl_ss; em.oss_ld = PL_SS_LD; }
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
     LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false,
-                     nullptr, false, l > 0, l + 1 < e->bb.c.layers ? e->bb.layers[l + 1].ln1 : e->bb.final_norm));
+                     nullptr, false, l > 0 || em_planes, l + 1 < e->bb.c.layers ? e->bb.layers[l + 1].ln1 : e->bb.final_norm));
   if (want_last_h) {
     LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
     if (s && s->last_h_trace)

@@ -54,13 +54,14 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
     KB = nchunks / 8;
     if (KB > 16 || nchunks % 8) return -2;
   }
-  if (a.g16_nw > 0 && a.g16_kb > 0 && a.g16_nw * a.g16_kb == nchunks && (pro != PRO_NORM || a.g16_kb == 1)) {
+  // (a K split of a normed launch needs the planes form: there the RMS scale multiplies the finished sum in the epilogue)
+  if (a.g16_nw > 0 && a.g16_kb > 0 && a.g16_nw * a.g16_kb == nchunks && (pro != PRO_NORM || a.g16_kb == 1 || a.xplanes)) {
     nw = a.g16_nw;
     KB = a.g16_kb;
   }
   if (nchunks % nw) return -2;
   if (epi == EPI_QKV) {
-    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || KB != 1) return -2;
+    if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128) || (KB != 1 && !a.xplanes)) return -2;
     if (kvdtype == 1) return launch_nw<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
     return launch_nw<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }

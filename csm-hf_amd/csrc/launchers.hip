@@ -1,7 +1,9 @@
 // Host launchers for attention / GEMM / misc kernels.
 #define CSM_PREFETCH_KERNELS 1
+#define CSM_ATTN_OPROJ_KERNEL 1
 #include "attn.h"
 #include "attn_prefill.h"
+#include "attn_oproj.h"
 #include "gemm.h"
 #include "misc.h"
 #include "prefetch.h"
@@ -137,6 +139,32 @@ int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
   if (wdtype == 2) return a.f32_mfma ? launch_gemm_t<fp8_t>(st, epi, a) : launch_gemm_x3<fp8_t>(st, epi, a);
   if (wdtype == 1) return a.f32_mfma ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_x3<bf16_t>(st, epi, a);
   return launch_gemm_t<float>(st, epi, a);
+}
+
+template <typename KT, typename WT>
+static int launch_attn_oproj_t(hipStream_t st, const AttnOprojArgs& a) {
+  const int K = a.n_q * a.hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * a.n_q / tpr;
+  const dim3 grid(a.N / rows), block(64 * a.n_q);
+  const size_t lds = ((size_t)2 * a.n_q * a.hd + (size_t)a.n_q * 32) * sizeof(float);
+  if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 64>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 128>), grid, block, lds, st, a);
+  return (int)hipGetLastError();
+}
+int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojArgs& a) {
+  if ((a.hd != 64 && a.hd != 128) || a.lmax > 32 || a.n_q % a.n_kv) return -2;
+  if (a.n_q != 2 && a.n_q != 4 && a.n_q != 8) return -2;
+  {
+    const int K = a.n_q * a.hd, tpr = K / (K >= 1024 ? 16 : 8);   // lanes per output row: half a wave or a wave
+    if ((tpr != 32 && tpr != 64) || a.N % (64 * a.n_q / tpr)) return -2;
+  }
+  if (kvdtype == 1) {
+    if (wdtype == 2) return launch_attn_oproj_t<bf16_t, fp8_t>(st, a);
+    if (wdtype == 1) return launch_attn_oproj_t<bf16_t, bf16_t>(st, a);
+    return launch_attn_oproj_t<bf16_t, float>(st, a);
+  }
+  if (wdtype == 2) return launch_attn_oproj_t<float, fp8_t>(st, a);
+  if (wdtype == 1) return launch_attn_oproj_t<float, bf16_t>(st, a);
+  return launch_attn_oproj_t<float, float>(st, a);
 }
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {

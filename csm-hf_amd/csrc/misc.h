@@ -25,6 +25,12 @@ struct EmbedArgs {
   // frame f is all-zero; row_done[row] = 1 from then on (read by the sampler when per-row stop is on)
   int* zero_count;   // [max_frames] nullable
   int* row_done;     // [rows] nullable
+  // batched decode on activation planes: the summed row also leaves as the B operands of the first layer's QKV launch
+  // (x * oln as three bf16 planes in fragment order, 16 rows per group) plus per-16-column sums of x^2 for its RMS scale
+  bf16_t* oplanes;   // nullable
+  const float* oln;  // [H] the consumer's norm weight
+  float* oss;        // [rows][oss_ld]
+  int oss_ld;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -91,7 +97,22 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
   __syncthreads();
   for (int i = tid; i < 512; i += 256) {
     const int kk = blockIdx.y * 512 + i;
-    if (kk < a.H) a.out[(size_t)row * a.H + kk] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+    const float v = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+    if (kk < a.H) {
+      a.out[(size_t)row * a.H + kk] = v;
+      if (a.oplanes) store_planes(a.oplanes + (size_t)(row >> 4) * 3 * 16 * a.H, (size_t)a.H * 16, kk, row & 15, v * a.oln[kk]);
+    }
+    if (a.oplanes) part[0][i] = kk < a.H ? v * v : 0.f;   // same thread read part[0][i] above
+  }
+  if (a.oplanes) {   // per-tile (16 columns) sums of squares, fixed order
+    __syncthreads();
+    if (tid < 32) {
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) q += part[0][tid * 16 + j];
+      const int tile = blockIdx.y * 32 + tid;
+      if (tile * 16 < a.H) a.oss[(size_t)row * a.oss_ld + tile] = q;
+    }
   }
   if (!a.ids && a.zero_count && blockIdx.y == 0 && tid == 0 && !(nz[0] | nz[1] | nz[2] | nz[3])) {
     atomicAdd(a.zero_count + f, 1);
