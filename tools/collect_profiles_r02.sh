@@ -11,7 +11,7 @@ for extra in "--opt weight_prefetch=0" "--batch 16 --steps 100" "--batch 16 --to
              "--topk 50 --temperature 0.9" "--no-graph --steps 100" "--weights fp8 --batch 16 --steps 100"; do
   timeout 300 python bench.py --no-cpu-baseline $extra >> $O/bench_other_configs.jsonl 2>> $O/bench_other.err
 done
-for c in 512 2048; do timeout 200 python tools/prefill_bench.py $c 1 5; done > $O/prefill.txt 2>&1
+for c in 512 1024 2048; do timeout 200 python tools/prefill_bench.py $c 1 5; done > $O/prefill.txt 2>&1
 timeout 200 python tools/prefill_bench.py 512 16 3 >> $O/prefill.txt 2>&1
 # kernel-level split of the benchmarked command (streamer off under the profiler: it is one persistent launch that
 # would dwarf every row; the bench line above is the un-profiled number)
@@ -22,6 +22,23 @@ cd $R
   echo "# (24 frame-steps + the prefills; at::native::* kernels are the synthetic-weight generation in setup, not the path)"; echo
   python tools/rocprof_summary.py $O/stats/r02_results.db 24; } > $O/bench_kernel_stats.md 2>&1
 rm -rf $O/stats
+# batch of 16 (BASELINE configs[2]): kernel split
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/b16 -o b16 -- python $R/bench.py --batch 16 --steps 40 --warmup 4 --lean > $R/$O/b16.log 2>&1
+cd $R
+{ echo "# BASELINE configs[2]: rocprofv3 --kernel-trace --stats -- python bench.py --batch 16 --steps 40 --warmup 4 --lean"; echo
+  python tools/rocprof_summary.py $O/b16/b16_results.db 44; } > $O/bench_b16_kernel_stats.md 2>&1
+rm -rf $O/b16
+# prefill kernels, prefill_precision = bf16, 2048 frames: per-kernel split and hardware counters (separate --pmc passes)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/pf -o pf -- python $R/tools/prefill_bench.py 2048 1 6 1 > $R/$O/pf.log 2>&1
+cd $R
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/prefill_bench.py 2048 1 6 1   (6 prefills of 2048 frames, prefill_precision = bf16)"; echo
+  python tools/rocprof_summary.py $O/pf/pf_results.db 6; } > $O/prefill2048_bf16_kernel_stats.md 2>&1
+rm -rf $O/pf
+GRAFT_REPO_ROOT=$R bash tools/pmc_prefill.sh 2048 $O/pmc_prefill > /dev/null 2>&1
+python tools/pmc_kernels.py $O/pmc_prefill > $O/prefill2048_bf16_pmc.txt 2>&1
+rm -rf $O/pmc_prefill
 # config 5 (fp8 weights, 2048-frame prefill, 500 frames): kernel split, then HBM bytes + matrix-pipe busy in separate --pmc passes
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/c5 -o c5 -- python $R/bench.py --weights fp8 --ctx 2048 --steps 40 --warmup 4 --lean --opt weight_prefetch=0 > $R/$O/c5.log 2>&1
