@@ -310,6 +310,46 @@ def test_prefill_bf16_attention_on_the_bf16_matrix_pipe(kv_dtype):
     m._drop_engine()
 
 
+@pytest.mark.parametrize("wdtype,kvdtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_decoder_attention_and_o_proj_as_one_launch(wdtype, kvdtype):
+    """csrc/attn_oproj.h: for a single sequence the decoder's SDPA and o_proj run as one launch (heads in parallel on the
+    waves of each o_proj workgroup).  Against the oracle (greedy tokens, fp32 checkpoint: bit-exact like every tiny
+    test), and against the two-launch form it replaces (fuse_attn_oproj = 0): same tokens, hidden states to fp32
+    summation-order error -- for fp32 / bf16 weights and fp32 / bf16 KV caches, graph replay and eager."""
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=7, std=0.05, dtype=wdtype, bf16_representable=wdtype != torch.float32)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.kv_dtype = kvdtype
+    ids, mask = synth_context(cfg, 1, 5, 9, seed=31)
+    n = 6
+
+    def run(use_graph):
+        """tokens of the public generate() plus the engine-level traces of the same run (logits of all 32 codebooks)"""
+        toks = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=n, topk=1, stop_on_all_zeros=False).cpu()
+        eng = m._ensure_engine(1, ids.shape[1] + n + 1, n, ids.shape[1])
+        eng.reset()
+        eng.set_kv_start([0])
+        lt = torch.zeros(eng.max_frames, 1, eng.C, eng.V, dtype=torch.float32, device=DEV)
+        eng.prefill(ids.to(DEV), mask.to(DEV))
+        eng.generate(eng.sampling(temperature=1.0, topk=1, seed=7, logits_trace=lt), n, use_graph)
+        assert torch.equal(eng.read_frames(0, n).cpu(), toks)
+        return toks, lt[:n].cpu()
+
+    fused, fused_lt = run(True)
+    assert torch.equal(run(False)[0], fused)                 # eager launches == graph replay
+    m._engine.set_option("fuse_attn_oproj", 0)
+    pair, pair_lt = run(True)
+    m._engine.set_option("fuse_attn_oproj", 1)
+    assert torch.equal(fused, pair)
+    assert float((fused_lt - pair_lt).abs().max()) < 2e-4    # logits of all 32 codebooks: summation order only
+    if wdtype == torch.float32 and kvdtype == torch.float32:
+        want = O.generate(sd, cfg, ids, mask, max_new_frames=n, topk=1, stop_on_all_zeros=False)
+        assert torch.equal(fused, want)
+    m._drop_engine()
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
