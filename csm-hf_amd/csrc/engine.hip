@@ -43,7 +43,7 @@ int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
-extern int g_gemm_wide, g_gemm_wide_depth, g_gemm_wide_krot;   // launchers.hip: 128 x 256 prefill GEMM tiles for one-plane activations (A/B switch)
+extern int g_gemm_wide, g_gemm_wide_depth, g_gemm_wide_krot, g_gemm_wide_exact;   // launchers.hip: 128 x 256 prefill GEMM tiles for one-plane activations (A/B switch)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -492,6 +492,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide")) g_gemm_wide = value;
   else if (!strcmp(name, "gemm_wide_depth")) g_gemm_wide_depth = value;
   else if (!strcmp(name, "gemm_wide_krot")) g_gemm_wide_krot = value;
+  else if (!strcmp(name, "gemm_wide_exact")) g_gemm_wide_exact = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
@@ -926,12 +927,12 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
   const bool can_split = pl && e->prefill_splitk && e->p_part && R <= 4096;
   int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
-  if (one && g_gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
+  if ((one || g_gemm_wide_exact) && g_gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
     // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
     // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands
     const long t = (long)((R + 127) / 128) * (Hb / 256);
     auto wide_split = [&](int K, int cur) {
-      if (t >= 320) return 1;
+      if (t >= (one ? 320 : 192)) return 1;
       const int ks = (int)((256 + t - 1) / t);
       return (ks <= 4 && K % (256 * ks) == 0 && K / ks >= 1024 && t * ks >= 256) ? ks : cur;
     };

@@ -333,14 +333,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 // lines per load instruction -- the texture path, not LDS, became the limit and it ran 1.4x SLOWER than the square tile.)
 // Roofline: bf16 MFMA, 2 R N K flops.
 typedef __attribute__((ext_vector_type(8))) short gw_bf16x8;
-template <typename WT, int EPI, int DEPTH>
-__global__ __launch_bounds__(256, DEPTH == 1 ? 2 : 1) void gemm_wide_kernel(GemmArgs a) {
+// NPL = activation planes: 1 (prefill_precision = bf16) or 3 (exact: every weight fragment is multiplied by the lo, mid and
+// hi plane, small terms first; 120 KB of LDS and ~300 registers: one workgroup per CU, three times the matrix work per
+// weight byte; measured slower than the square tile and off by default: launchers.hip g_gemm_wide_exact)
+template <typename WT, int EPI, int DEPTH, int NPL = 1>
+__global__ __launch_bounds__(256, (DEPTH == 1 && NPL == 1) ? 2 : 1) void gemm_wide_kernel(GemmArgs a) {
   // LDS rows of 160 bytes: with the lane groups ds_read_b128 / ds_write_b128 are serviced in ({0-3,12-15,20-27},
   // {4-11,16-19,28-31}, +32) the operand reads (lane = row & 15, k group = lane >> 4) touch 16 distinct 16-byte bank
   // slots per group at this stride (144 bytes, right for the 32x32x16 operand layout, gave 40 % conflict cycles here)
   constexpr int BM = 128, BN = 256, BK = 64, LDK = BK + 16;
   constexpr int MI = BM / 16, NI = BN / 4 / 16, KS = BK / 32;
-  __shared__ __attribute__((aligned(16))) bf16_t As[2][BM * LDK];
+  extern __shared__ __attribute__((aligned(16))) bf16_t As_all[];   // [2 buffers][NPL planes][BM * LDK]
+  auto As = [&](int buf, int p) { return As_all + (size_t)(buf * NPL + p) * (BM * LDK); };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, g = lane >> 4;
   const int nbm = (a.R + BM - 1) / BM, nbn = a.N / BN;
@@ -372,17 +376,21 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 2 : 1) void gemm_wide_kernel(Gemm
   const int widx = wg2 ? (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16) : (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12);
   const int arow = wave * 8 + (lane >> 5) * 2 + (wg2 ? 1 : 0) + 4 * (widx >> 3), ac8 = widx & 7;
   const bf16_t* asrc = a.Aplanes + (size_t)(r0 + arow) * a.K + ac8 * 8;
-  u32x4 pa[4];
+  u32x4 pa[NPL][4];
   auto fetch_a = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      pa[i] = (u32x4)(0u);
-      if (r0 + arow + 32 * i < a.R) pa[i] = *reinterpret_cast<const u32x4*>(asrc + (size_t)(32 * i) * a.K + k0);
-    }
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pa[p][i] = (u32x4)(0u);
+        if (r0 + arow + 32 * i < a.R) pa[p][i] = *reinterpret_cast<const u32x4*>(asrc + p * a.a_plane_stride + (size_t)(32 * i) * a.K + k0);
+      }
   };
   auto stage_a = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[buf][(arow + 32 * i) * LDK + ac8 * 8]) = pa[i];
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As(buf, p) + (arow + 32 * i) * LDK + ac8 * 8) = pa[p][i];
   };
   // fragment (16-row tile t, 32-wide k block kb) of the copy starts at (t * K/32 + kb) * 512 elements
   const WT* wsrc = reinterpret_cast<const WT*>(a.Wt) + (size_t)(n0 >> 4) * a.K * 16 + lane * 8;
@@ -415,28 +423,40 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 2 : 1) void gemm_wide_kernel(Gemm
         if (set < nstep) wload(set, ni, ks, kof(set));
   stage_a(0);
   lds_barrier();
-  auto xload = [&](gw_bf16x8* xf, int buf, int ks) {   // B operands: lane (row m16, k group g) of the 8 row tiles
+  auto xload = [&](gw_bf16x8* xf, int buf, int p, int ks) {   // B operands: lane (row m16, k group g) of the 8 row tiles
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
-      *reinterpret_cast<u32x4*>(&xf[mi]) = *reinterpret_cast<const u32x4*>(&As[buf][(mi * 16 + m16) * LDK + ks * 32 + g * 8]);
+      *reinterpret_cast<u32x4*>(&xf[mi]) = *reinterpret_cast<const u32x4*>(As(buf, p) + (mi * 16 + m16) * LDK + ks * 32 + g * 8);
   };
   auto step = [&](int set, int buf, int i) {
     const bool more = i + 1 < nstep, mored = i + DEPTH < nstep;
     if (more) fetch_a(kof(i + 1));
     const int kd = kof(i + DEPTH);
-    constexpr bool XDB = DEPTH > 1;   // room for both halves' operands only in the one-wave-per-SIMD form
-    gw_bf16x8 xf[XDB ? KS : 1][MI];
-    if (XDB) xload(xf[0], buf, 0);
+    constexpr bool XDB = DEPTH > 1 && NPL == 1;   // room for both halves' operands only in the one-plane one-wave-per-SIMD form
+    gw_bf16x8 xf[XDB ? KS : NPL][MI];
+    if (XDB) xload(xf[0], buf, 0, 0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (!XDB) xload(xf[0], buf, ks);
-      else if (ks + 1 < KS) xload(xf[ks + 1], buf, ks + 1);   // the next half's operands fly under this half's MFMAs
+      if (!XDB) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) xload(xf[p], buf, p, ks);
+      } else if (ks + 1 < KS) {
+        xload(xf[ks + 1], buf, 0, ks + 1);   // the next half's operands fly under this half's MFMAs
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         gw_bf16x8 wfr;
         *reinterpret_cast<u32x4*>(&wfr) = wf[set][ni][ks];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[XDB ? ks : 0][mi], acc[mi][ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) {
+          if (NPL == 3) {   // planes are stored hi, mid, lo: small terms first
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[2][mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[1][mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[0][mi], acc[mi][ni], 0, 0, 0);
+          } else {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[XDB ? ks : 0][mi], acc[mi][ni], 0, 0, 0);
+          }
+        }
         if (mored) wload(set, ni, ks, kd);
       }
     }
@@ -463,8 +483,11 @@ __global__ __launch_bounds__(256, DEPTH == 1 ? 2 : 1) void gemm_wide_kernel(Gemm
       }
       if (EPI == GEPI_SWIGLU) {   // (gate, up) pairs: columns n/2, n/2 + 1 of the output
         const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
-        if (a.Cplanes) {
+        if (a.Cplanes && a.c_plane_stride == 0) {
           *reinterpret_cast<uint32_t*>(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1)) = (uint32_t)f32_to_bf16(h0) | ((uint32_t)f32_to_bf16(h1) << 16);
+        } else if (a.Cplanes) {
+          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1), a.c_plane_stride, h0);
+          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1) + 1, a.c_plane_stride, h1);
         } else {
           float* c = a.C + (size_t)r * a.ldc + (n >> 1);
           c[0] = h0; c[1] = h1;

@@ -83,34 +83,55 @@ static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
 int g_gemm_wide = 1;   // A/B switch (csm_set_option "gemm_wide")
 int g_gemm_wide_krot = 0;
 int g_gemm_wide_depth = 1;   // A/B: weight-fragment sets in registers (1: two workgroups per CU; 4: one, 444 registers)
-template <typename WT, int DEPTH>
+template <typename WT, int EPI, int DEPTH, int NPL>
+static int launch_gemm_wide_k(hipStream_t st, const dim3& grid, const GemmArgs& a) {
+  constexpr size_t lds = (size_t)2 * NPL * 128 * 80 * sizeof(bf16_t);   // 40 KB (one plane) / 120 KB (three)
+  auto fn = gemm_wide_kernel<WT, EPI, DEPTH, NPL>;
+  static bool configured = false;
+  if (!configured && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    configured = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+template <typename WT, int DEPTH, int NPL>
 static int launch_gemm_wide_d(hipStream_t st, int epi, const GemmArgs& a) {
   const int tiles = ((a.R + 127) / 128) * (a.N / 256);
   const dim3 grid(tiles, epi == GEPI_PARTIAL ? a.ksplit : 1);
   switch (epi) {
-    case GEPI_STORE: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_STORE, DEPTH>), grid, dim3(256), 0, st, a); break;
-    case GEPI_RESID: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_RESID, DEPTH>), grid, dim3(256), 0, st, a); break;
-    case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_SWIGLU, DEPTH>), grid, dim3(256), 0, st, a); break;
-    case GEPI_PARTIAL: hipLaunchKernelGGL((gemm_wide_kernel<WT, GEPI_PARTIAL, DEPTH>), grid, dim3(256), 0, st, a); break;
+    case GEPI_STORE: return launch_gemm_wide_k<WT, GEPI_STORE, DEPTH, NPL>(st, grid, a);
+    case GEPI_RESID: return launch_gemm_wide_k<WT, GEPI_RESID, DEPTH, NPL>(st, grid, a);
+    case GEPI_SWIGLU: return launch_gemm_wide_k<WT, GEPI_SWIGLU, DEPTH, NPL>(st, grid, a);
+    case GEPI_PARTIAL: return launch_gemm_wide_k<WT, GEPI_PARTIAL, DEPTH, NPL>(st, grid, a);
     default: return -1;
   }
-  return (int)hipGetLastError();
 }
 template <typename WT>
 static int launch_gemm_wide(hipStream_t st, int epi, const GemmArgs& a) {
   GemmArgs b = a;
   b.krot = g_gemm_wide_krot;
-  return g_gemm_wide_depth == 4 ? launch_gemm_wide_d<WT, 4>(st, epi, b) : launch_gemm_wide_d<WT, 1>(st, epi, b);
+  if (a.a_plane_stride != 0) return launch_gemm_wide_d<WT, 1, 3>(st, epi, b);   // exact: three planes
+  return g_gemm_wide_depth == 4 ? launch_gemm_wide_d<WT, 4, 1>(st, epi, b) : launch_gemm_wide_d<WT, 1, 1>(st, epi, b);
 }
+int g_gemm_wide_exact = 0;   // A/B: the three-plane (exact) form of the wide tile.  Measured SLOWER than the square tile
+                             // (512 / 2048 frames: 5.50 / 20.4 vs 5.33 / 19.5 ms; 16 x 512: 70 vs 58 ms): with 120 KB of LDS and 436
+                             // registers one wave per SIMD has to cover its own LDS and load latencies, the square tile runs
+                             // two to three workgroups per CU
 static bool gemm_wide_ok(int epi, const GemmArgs& a) {
-  if (!g_gemm_wide || !a.Wt || !a.Aplanes || a.a_plane_stride != 0 || a.N % 256 || a.K % 256 || a.ldc % 4) return false;
-  if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return false;
+  if (!g_gemm_wide || !a.Wt || !a.Aplanes || a.N % 256 || a.K % 256 || a.ldc % 4) return false;
+  const bool exact = a.a_plane_stride != 0;
+  if (exact && !g_gemm_wide_exact) return false;
+  if (epi == GEPI_SWIGLU && a.Cplanes && (a.c_plane_stride != 0) != exact) return false;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (epi == GEPI_PARTIAL && (ks < 1 || a.K % (256 * ks) || !a.Cpart)) return false;
-  // measured (csm-1b shapes, tools/prefill_bench.py): at exactly one workgroup per CU the wide tile only ties the square
-  // one (gate/up at 512 rows: 59 vs 57 us; QKV at 2048 rows, 192 tiles: 52 vs 48 us); with two per CU it wins
-  // (gate/up at 2048 rows: 156 vs 187 us); the split-K partials win from one per CU on (67-84 vs 99 us)
-  return ((a.R + 127) / 128) * (a.N / 256) * ks >= (epi == GEPI_PARTIAL ? 256 : 320);
+  const long wgs = (long)((a.R + 127) / 128) * (a.N / 256) * ks;
+  // measured (csm-1b shapes, tools/prefill_bench.py), one plane: at exactly one workgroup per CU the wide tile only ties
+  // the square one (gate/up at 512 rows: 59 vs 57 us; QKV at 2048 rows, 192 tiles: 52 vs 48 us); with two per CU it wins
+  // (gate/up at 2048 rows: 156 vs 187 us); the split-K partials win from one per CU on (67-84 vs 99 us).
+  // Three planes: one workgroup per CU by construction (120 KB of LDS)
+  if (exact) return wgs >= 192;
+  return wgs >= (epi == GEPI_PARTIAL ? 256 : 320);
 }
 
 template <typename WT>
