@@ -43,7 +43,6 @@ int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
-extern int g_gemm_wide, g_gemm_wide_depth, g_gemm_wide_krot, g_gemm_wide_exact;   // launchers.hip: 128 x 256 prefill GEMM tiles for one-plane activations (A/B switch)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -128,6 +127,7 @@ struct csm_engine {
   int prefill_splitk = 1;
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
+  int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
   int prefill_bf16_attn = 1;   // with prefill_bf16: the context attention on the bf16 matrix pipe too (0 = keep the fp32-MFMA flash kernel)
   // host mirrors
   int B = 0;
@@ -489,10 +489,10 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
-  else if (!strcmp(name, "gemm_wide")) g_gemm_wide = value;
-  else if (!strcmp(name, "gemm_wide_depth")) g_gemm_wide_depth = value;
-  else if (!strcmp(name, "gemm_wide_krot")) g_gemm_wide_krot = value;
-  else if (!strcmp(name, "gemm_wide_exact")) g_gemm_wide_exact = value;
+  else if (!strcmp(name, "gemm_wide")) e->gemm_wide = value;
+  else if (!strcmp(name, "gemm_wide_depth")) e->gemm_wide_depth = value;
+  else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
+  else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
@@ -927,7 +927,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
   const bool can_split = pl && e->prefill_splitk && e->p_part && R <= 4096;
   int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
-  if ((one || g_gemm_wide_exact) && g_gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
+  if ((one || e->gemm_wide_exact) && e->gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
     // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
     // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands
     const long t = (long)((R + 127) / 128) * (Hb / 256);
@@ -949,7 +949,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv);
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot;
     LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
     ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
@@ -971,7 +971,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo);
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
     if (att_pl && ks_o > 1) {
       o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
@@ -985,12 +985,12 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu);
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot;
     gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd);
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
     if (pl && ks_d > 1) {
       d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;

@@ -38,7 +38,10 @@ struct GemmArgs {
   size_t part_stride;
   // fragment-order copy of W (launchers.hip tile16_kernel; nullable): enables gemm_wide_kernel for one-plane activations
   const void* Wt;
-  int krot;   // gemm_wide_kernel: start the k walk at a per-workgroup step (A/B; changes the fp32 summation order)
+  // gemm_wide_kernel switches (per engine, csm_set_option): wide = 0 keeps the square tile; wide_depth = weight-fragment
+  // sets in registers (1: two workgroups per CU, 4: one); wide_exact = 1 also routes three-plane (exact) launches to it
+  // (measured slower: off); krot = start the k walk at a per-workgroup step (changes the fp32 summation order: off)
+  int wide, wide_depth, wide_exact, krot;
 };
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 typedef __attribute__((ext_vector_type(8))) short gw_bf16x8;
 // NPL = activation planes: 1 (prefill_precision = bf16) or 3 (exact: every weight fragment is multiplied by the lo, mid and
 // hi plane, small terms first; 120 KB of LDS and ~300 registers: one workgroup per CU, three times the matrix work per
-// weight byte; measured slower than the square tile and off by default: launchers.hip g_gemm_wide_exact)
+// weight byte; measured slower than the square tile and off by default: GemmArgs::wide_exact)
 template <typename WT, int EPI, int DEPTH, int NPL = 1>
 __global__ __launch_bounds__(256, (DEPTH == 1 && NPL == 1) ? 2 : 1) void gemm_wide_kernel(GemmArgs a) {
   // LDS rows of 160 bytes: with the lane groups ds_read_b128 / ds_write_b128 are serviced in ({0-3,12-15,20-27},

@@ -79,10 +79,7 @@ static int launch_gemm_x3_bt(hipStream_t st, int epi, const GemmArgs& a) {
   return launch_gemm_x3_bk<WT, BT, 32>(st, epi, a);
 }
 
-// 128 x 256 tiles (gemm_wide_kernel) for one-plane activations when they fill the chip
-int g_gemm_wide = 1;   // A/B switch (csm_set_option "gemm_wide")
-int g_gemm_wide_krot = 0;
-int g_gemm_wide_depth = 1;   // A/B: weight-fragment sets in registers (1: two workgroups per CU; 4: one, 444 registers)
+// 128 x 256 tiles (gemm_wide_kernel) for one-plane activations when they fill the chip (GemmArgs::wide & co.)
 template <typename WT, int EPI, int DEPTH, int NPL>
 static int launch_gemm_wide_k(hipStream_t st, const dim3& grid, const GemmArgs& a) {
   constexpr size_t lds = (size_t)2 * NPL * 128 * 80 * sizeof(bf16_t);   // 40 KB (one plane) / 120 KB (three)
@@ -109,19 +106,16 @@ static int launch_gemm_wide_d(hipStream_t st, int epi, const GemmArgs& a) {
 }
 template <typename WT>
 static int launch_gemm_wide(hipStream_t st, int epi, const GemmArgs& a) {
-  GemmArgs b = a;
-  b.krot = g_gemm_wide_krot;
-  if (a.a_plane_stride != 0) return launch_gemm_wide_d<WT, 1, 3>(st, epi, b);   // exact: three planes
-  return g_gemm_wide_depth == 4 ? launch_gemm_wide_d<WT, 4, 1>(st, epi, b) : launch_gemm_wide_d<WT, 1, 1>(st, epi, b);
+  if (a.a_plane_stride != 0) return launch_gemm_wide_d<WT, 1, 3>(st, epi, a);   // exact: three planes
+  return a.wide_depth == 4 ? launch_gemm_wide_d<WT, 4, 1>(st, epi, a) : launch_gemm_wide_d<WT, 1, 1>(st, epi, a);
 }
-int g_gemm_wide_exact = 0;   // A/B: the three-plane (exact) form of the wide tile.  Measured SLOWER than the square tile
-                             // (512 / 2048 frames: 5.50 / 20.4 vs 5.33 / 19.5 ms; 16 x 512: 70 vs 58 ms): with 120 KB of LDS and 436
-                             // registers one wave per SIMD has to cover its own LDS and load latencies, the square tile runs
-                             // two to three workgroups per CU
+// The three-plane (exact) form of the wide tile measured SLOWER than the square tile (512 / 2048 frames: 5.50 / 20.4 vs
+// 5.33 / 19.5 ms; 16 x 512: 70 vs 58 ms): with 120 KB of LDS and 436 registers one wave per SIMD has to cover its own LDS and
+// load latencies, the square tile runs two to three workgroups per CU.  GemmArgs::wide_exact keeps it reachable for A/B.
 static bool gemm_wide_ok(int epi, const GemmArgs& a) {
-  if (!g_gemm_wide || !a.Wt || !a.Aplanes || a.N % 256 || a.K % 256 || a.ldc % 4) return false;
+  if (!a.wide || !a.Wt || !a.Aplanes || a.N % 256 || a.K % 256 || a.ldc % 4) return false;
   const bool exact = a.a_plane_stride != 0;
-  if (exact && !g_gemm_wide_exact) return false;
+  if (exact && !a.wide_exact) return false;
   if (epi == GEPI_SWIGLU && a.Cplanes && (a.c_plane_stride != 0) != exact) return false;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (epi == GEPI_PARTIAL && (ks < 1 || a.K % (256 * ks) || !a.Cpart)) return false;
