@@ -43,6 +43,10 @@ int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
+int launch_ce_rows(hipStream_t st, const CeArgs& a);
+int launch_ce_reduce(hipStream_t st, const float* row_loss, const int* labels, int V, int rows, double* acc);
+int launch_loss_finalize(hipStream_t st, const double* acc, int frames, float* out3);
+int launch_dec_input(hipStream_t st, int frames, const DecInArgs& a);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -123,6 +127,12 @@ struct csm_engine {
   int *p_row_seq = nullptr, *p_row_pos = nullptr;
   // prefill activations as row-major bf16 planes [3][rows][K] (bf16 / fp8 weights): split once by the producer
   bf16_t *p_pl_h = nullptr, *p_pl_act = nullptr;
+  // training forward (csm_forward_loss), allocated at the first call: head rows of every context position, scratch KV
+  // caches of the decoder pass over labelled frames (LOSS_FRAMES sequences of 32 positions), logits / labels / losses
+  float* loss_head = nullptr; size_t loss_head_rows = 0;
+  std::vector<void*> loss_kc, loss_vc;
+  float* loss_logits = nullptr; float* loss_rows = nullptr; int* loss_lab = nullptr; int* loss_idx = nullptr; double* loss_acc = nullptr;
+  size_t loss_lab_n = 0, loss_rows_n = 0;
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
   int prefill_planes = 1;
@@ -856,7 +866,7 @@ extern "C" int csm_backbone_step_ids(csm_engine_t* e, const int64_t* ids, const 
 }
 
 static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* rope_pos,
-                        float* last_h_out, float* c0_logits_out);
+                        float* last_h_out, float* c0_logits_out, float* all_h_out = nullptr);
 
 extern "C" int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, float* last_h_out,
                            float* c0_logits_out) {
@@ -899,8 +909,107 @@ static const void* tiled_of(const csm_engine* e, const void* W) {
   return it == e->tiled.end() ? nullptr : it->second;
 }
 
+// R = B * S rows (row b * S + s = position past + s of sequence b; e->p_row_seq / p_row_pos filled by the caller) through
+// every layer of a stack: residual stream in e->p_h [R][hidden], K/V appended to kc[l] / vc[l] ([B][n_kv][lmax][hd]
+// layouts of the engine caches).  On return *pending_out split-K partials of the LAST layer's down_proj wait in e->p_part
+// (stride *part_stride_out) for the caller's next rmsnorm launch to fold in.  Used by the context prefill (backbone, the
+// engine's own caches) and by the training forward's decoder pass (scratch caches, 32 positions per frame).
+static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc, int lmax, int B, int S, int past,
+                      const int* kv_start, const int32_t* rope_pos, bool allow_split, int* pending_out, size_t* part_stride_out) {
+  const size_t R = (size_t)B * S;
+  const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
+  const int wd = e->cfg.weight_dtype;
+  // bf16 / fp8 weights: RMSNorm, the flash attention and the SwiGLU epilogue hand their outputs to the next GEMM as
+  // exact bf16 planes (split once per element instead of once per column block of the consumer)
+  const bool pl = e->prefill_planes && e->p_pl_h && wd != CSM_DTYPE_F32 && H % 8 == 0 && F % 8 == 0 && (nq * hd) % 8 == 0;
+  // prefill_precision = bf16: ONE plane (activations rounded to nearest bf16 by the producer), flagged by a plane
+  // stride of 0; = exact: three planes, one stride apart
+  const bool one = pl && e->prefill_bf16;
+  const size_t ps_h = one ? 0 : R * (size_t)H, ps_att = one ? 0 : R * (size_t)(nq * hd), ps_act = one ? 0 : R * (size_t)F;
+  // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
+  // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
+  const bool can_split = allow_split && pl && e->prefill_splitk && e->p_part && R <= 4096;
+  int ks_o = can_split ? prefill_ksplit((int)R, H, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, H, F) : 1;
+  if ((one || e->gemm_wide_exact) && e->gemm_wide && can_split && H % 256 == 0 && !e->tiled.empty()) {
+    // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
+    // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands
+    const long t = (long)((R + 127) / 128) * (H / 256);
+    auto wide_split = [&](int K, int cur) {
+      if (t >= (one ? 320 : 192)) return 1;
+      const int ks = (int)((256 + t - 1) / t);
+      return (ks <= 4 && K % (256 * ks) == 0 && K / ks >= 1024 && t * ks >= 256) ? ks : cur;
+    };
+    ks_o = wide_split(nq * hd, ks_o);
+    ks_d = wide_split(F, ks_d);
+  }
+  const size_t part_stride = R * (size_t)H;
+  int pending = 0;   // splits waiting in p_part for the next RMSNorm
+  for (int l = 0; l < s.c.layers; ++l) {
+    const csm_layer_weights_t& w = s.layers[l];
+    LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln1, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H));
+    pending = 0;
+    GemmArgs g{};
+    if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
+    g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot;
+    LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
+    RopeArgs ra{};
+    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
+    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
+    ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
+    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    PrefillAttnArgs fa{};
+    fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.out = e->p_att;
+    if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
+    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, one && e->prefill_bf16_attn) : -2;
+    bool att_pl = pl && fr != -2;
+    if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
+      AttnArgs t{};
+      t.q = e->p_q; t.kcache = kc[l]; t.vcache = vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = lmax;
+      t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = kv_start; t.nsplit = 1; t.out = e->p_att;
+      fr = launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t);
+    }
+    LCK(fr);
+    GemmArgs o{};
+    if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot;
+    o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
+    if (att_pl && ks_o > 1) {
+      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, o));
+      pending = ks_o;
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
+    }
+    LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln2, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H));
+    pending = 0;
+    GemmArgs gu{};
+    if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot;
+    gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
+    LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
+    GemmArgs d{};
+    if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot;
+    d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
+    if (pl && ks_d > 1) {
+      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, d));
+      pending = ks_d;
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
+    }
+  }
+  *pending_out = pending;
+  *part_stride_out = part_stride;
+  return 0;
+}
+
 static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* rope_pos,
-                        float* last_h_out, float* c0_logits_out) {
+                        float* last_h_out, float* c0_logits_out, float* all_h_out) {
   if (!e || !e->bound || !ids) return fail(CSM_ERR_STATE, "weights not bound / null ids");
   if (B < 1 || B > e->cfg.max_batch || S < 1) return fail(CSM_ERR_ARG, "bad batch/sequence (%d, %d)", B, S);
   if (e->B && B != e->B) return fail(CSM_ERR_ARG, "batch %d does not match active batch %d (call csm_reset)", B, e->B);
@@ -916,89 +1025,13 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
   em.ids = ids; em.mask = mask; em.out = e->p_h;
   LCK(launch_embed(e->stream, emb_dtype(e), (int)R, em));
-  // bf16 / fp8 weights: RMSNorm, the flash attention and the SwiGLU epilogue hand their outputs to the next GEMM as
-  // exact bf16 planes (split once per element instead of once per column block of the consumer)
-  const bool pl = e->prefill_planes && e->p_pl_h && wd != CSM_DTYPE_F32 && Hb % 8 == 0 && F % 8 == 0 && (nq * hd) % 8 == 0;
-  // prefill_precision = bf16: ONE plane (activations rounded to nearest bf16 by the producer), flagged by a plane
-  // stride of 0; = exact: three planes, one stride apart
-  const bool one = pl && e->prefill_bf16;
-  const size_t ps_h = one ? 0 : R * (size_t)Hb, ps_att = one ? 0 : R * (size_t)(nq * hd), ps_act = one ? 0 : R * (size_t)F;
-  // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
-  // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
-  const bool can_split = pl && e->prefill_splitk && e->p_part && R <= 4096;
-  int ks_o = can_split ? prefill_ksplit((int)R, Hb, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, Hb, F) : 1;
-  if ((one || e->gemm_wide_exact) && e->gemm_wide && can_split && Hb % 256 == 0 && !e->tiled.empty()) {
-    // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
-    // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands
-    const long t = (long)((R + 127) / 128) * (Hb / 256);
-    auto wide_split = [&](int K, int cur) {
-      if (t >= (one ? 320 : 192)) return 1;
-      const int ks = (int)((256 + t - 1) / t);
-      return (ks <= 4 && K % (256 * ks) == 0 && K / ks >= 1024 && t * ks >= 256) ? ks : cur;
-    };
-    ks_o = wide_split(nq * hd, ks_o);
-    ks_d = wide_split(F, ks_d);
-  }
-  const size_t part_stride = R * (size_t)Hb;
-  int pending = 0;   // splits waiting in p_part for the next RMSNorm
-  for (int l = 0; l < s.c.layers; ++l) {
-    const csm_layer_weights_t& w = s.layers[l];
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln1, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
+  int pending = 0;
+  size_t part_stride = 0;
+  if (int r = stack_rows(e, s, s.kc.data(), s.vc.data(), s.lmax, B, S, e->h_len, e->d_kv_start, rope_pos, true, &pending, &part_stride)) return r;
+  if (all_h_out) {   // training forward: the final-normed hidden state of EVERY row (the last layer's partials fold in here)
+    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, s.final_norm, (int)R, Hb, s.c.rms_eps, all_h_out, Hb, nullptr, 0, 0, nullptr, 0,
                        pending > 1 ? e->p_part : nullptr, pending, part_stride, Hb));
     pending = 0;
-    GemmArgs g{};
-    if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
-    g.A = e->p_xn; g.lda = Hb; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = Hb; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot;
-    LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
-    RopeArgs ra{};
-    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
-    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
-    ra.qbuf = e->p_q; ra.kcache = s.kc[l]; ra.vcache = s.vc[l]; ra.lmax = s.lmax; ra.rope_pos = rope_pos;
-    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
-    PrefillAttnArgs fa{};
-    fa.q = e->p_q; fa.kcache = s.kc[l]; fa.vcache = s.vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = s.lmax;
-    fa.S = S; fa.past = e->h_len; fa.kv_start = e->d_kv_start; fa.out = e->p_att;
-    if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
-    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, one && e->prefill_bf16_attn) : -2;
-    bool att_pl = pl && fr != -2;
-    if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
-      AttnArgs t{};
-      t.q = e->p_q; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
-      t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = e->d_kv_start; t.nsplit = 1; t.out = e->p_att;
-      fr = launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t);
-    }
-    LCK(fr);
-    GemmArgs o{};
-    if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot;
-    o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = Hb; o.K = nq * hd; o.C = e->p_h; o.ldc = Hb;
-    if (att_pl && ks_o > 1) {
-      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
-      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, o));
-      pending = ks_o;
-    } else {
-      LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
-    }
-    LCK(launch_rmsnorm(e->stream, e->p_h, Hb, w.ln2, (int)R, Hb, s.c.rms_eps, e->p_xn, Hb, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, Hb));
-    pending = 0;
-    GemmArgs gu{};
-    if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot;
-    gu.A = e->p_xn; gu.lda = Hb; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = Hb; gu.C = e->p_act; gu.ldc = F;
-    LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
-    GemmArgs d{};
-    if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot;
-    d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = Hb; d.K = F; d.C = e->p_h; d.ldc = Hb;
-    if (pl && ks_d > 1) {
-      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
-      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, d));
-      pending = ks_d;
-    } else {
-      LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
-    }
   }
   // last position of every sequence: rows b*S + S-1
   const float* hl = e->p_h + (size_t)(S - 1) * Hb;
@@ -1032,6 +1065,122 @@ extern "C" int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logit
 // about `pf_sub_kb`; run e may be fetched once the bytes of runs whose consumer has not started yet, up to and including
 // e, fit the window (cyclically over consecutive frames).  Runs that could only be fetched after their own consumer has
 // started are left to the consumer.
+// ---- training forward, labels branch (reference modeling_csm.py:367-465) -------------------------------------------------
+// loss = CE(codebook-0 logits of position t, label of t+1) + CE(decoder logits of codebooks 1..C-1 over the frames whose C
+// audio labels are all present), both as the reference's nn.CrossEntropyLoss(ignore_index=-100) means.  FORWARD ONLY (no
+// backward pass): what a caller can do with it is evaluate / monitor the reference's training objective on MI355X.
+// The backbone pass is the context prefill (it fills the engine's KV cache like csm_prefill: call csm_reset first); the
+// decoder pass runs the labelled frames as sequences of C positions through the same prefill kernels on scratch caches.
+constexpr int LOSS_FRAMES = 256;   // labelled frames per decoder pass
+extern "C" int csm_forward_loss(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, const int64_t* labels, int B, int S,
+                                float* out3, float* last_h_out, float* c0_logits_out) {
+  if (!e || !e->bound || !ids || !labels || !out3) return fail(CSM_ERR_ARG, "null argument");
+  if (e->h_len != 0) return fail(CSM_ERR_STATE, "csm_forward_loss starts from an empty cache (csm_reset first)");
+  if (!e->w.proj_table) return fail(CSM_ERR_STATE, "projection table not built");
+  const int C = e->cfg.n_codebooks, V = e->cfg.audio_vocab, Hb = e->cfg.backbone.hidden, Hd = e->cfg.decoder.hidden;
+  const size_t R = (size_t)B * S;
+  const int P = C;   // decoder positions per frame that matter: 0 .. C-1 (the reference also runs position C, which nothing reads)
+  if (P > e->dec.lmax || P > e->dec.rope_positions) return fail(CSM_ERR_CAPACITY, "decoder cache shorter than %d positions", P);
+  const int FC = std::min<int>(LOSS_FRAMES, e->cfg.max_prefill_rows / P);
+  if (FC < 1) return fail(CSM_ERR_CAPACITY, "max_prefill_rows %d is below one decoder frame", e->cfg.max_prefill_rows);
+  int r;
+  // ---- scratch (first call) ----
+  if (!e->loss_head) {
+    const size_t maxR = (size_t)e->cfg.max_prefill_rows;
+    const size_t kvb = e->cfg.kv_dtype == 1 ? 2 : 4;
+    const size_t per = (size_t)FC * e->dec.c.n_kv * e->dec.lmax * e->dec.c.head_dim * kvb;
+    if ((r = dalloc(e, &e->loss_head, maxR * e->ld_head))) return r;
+    e->loss_head_rows = maxR;
+    for (int l = 0; l < e->dec.c.layers; ++l) {
+      char *k = nullptr, *v = nullptr;
+      if ((r = dalloc(e, &k, per)) || (r = dalloc(e, &v, per))) return r;
+      HIPCK(hipMemsetAsync(k, 0, per, e->stream));
+      HIPCK(hipMemsetAsync(v, 0, per, e->stream));
+      e->loss_kc.push_back(k); e->loss_vc.push_back(v);
+    }
+    e->loss_rows_n = std::max(maxR, (size_t)FC);
+    e->loss_lab_n = maxR + (size_t)(C - 1) * FC;
+    if ((r = dalloc(e, &e->loss_logits, (size_t)FC * ((V + 3) & ~3))) || (r = dalloc(e, &e->loss_rows, e->loss_rows_n)) ||
+        (r = dalloc(e, &e->loss_lab, e->loss_lab_n)) || (r = dalloc(e, &e->loss_idx, (size_t)2 * FC)) || (r = dalloc(e, &e->loss_acc, (size_t)4)))
+      return r;
+  }
+  if (R > e->loss_head_rows) return fail(CSM_ERR_CAPACITY, "B*S = %zu exceeds max_prefill_rows", R);
+  // ---- 1. backbone over the context; final-normed state of EVERY position ----
+  if ((r = prefill_impl(e, ids, mask, B, S, nullptr, last_h_out, c0_logits_out, e->p_xn))) return r;
+  // ---- 2. [projection ; codebook0_head] on every position (modeling_csm.py:361 and :407) ----
+  {
+    GemvArgs a{};
+    a.nt = 0;
+    a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = Hd + V; a.K = Hb; a.x = e->p_xn; a.ldx = Hb;
+    a.out = e->loss_head; a.ldo = e->ld_head;
+    if ((r = gemv_rows(e, (int)R, PRO_PLAIN, EPI_STORE, a))) return r;
+  }
+  // ---- 3. labels on the host: shifted codebook-0 targets, the list of fully labelled frames ----
+  std::vector<int64_t> lab(R * (size_t)(C + 1));
+  HIPCK(hipMemcpyAsync(lab.data(), labels, lab.size() * sizeof(int64_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  std::vector<int> lab0(R);
+  std::vector<int> fr_prev, fr_row;
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < S; ++t) {
+      const size_t row = (size_t)b * S + t;
+      const int64_t nx = t + 1 < S ? lab[(row + 1) * (C + 1)] : -100;
+      lab0[row] = (nx >= 0 && nx < V) ? (int)nx : -100;
+      bool all = true;
+      for (int c = 0; c < C; ++c) all = all && lab[row * (C + 1) + c] != -100;
+      if (all) { fr_prev.push_back((int)((size_t)b * S + (t + S - 1) % S)); fr_row.push_back((int)row); }
+    }
+  HIPCK(hipMemsetAsync(e->loss_acc, 0, 4 * sizeof(double), e->stream));
+  HIPCK(hipMemcpyAsync(e->loss_lab, lab0.data(), R * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  {
+    CeArgs ce{};
+    ce.logits = e->loss_head + Hd; ce.ld = e->ld_head; ce.V = V; ce.rows = (int)R; ce.labels = e->loss_lab; ce.row_loss = e->loss_rows;
+    LCK(launch_ce_rows(e->stream, ce));
+    LCK(launch_ce_reduce(e->stream, e->loss_rows, e->loss_lab, V, (int)R, e->loss_acc));
+  }
+  HIPCK(hipStreamSynchronize(e->stream));   // lab0 is re-used below
+  // ---- 4. decoder over the labelled frames, LOSS_FRAMES at a time ----
+  const int nf = (int)fr_row.size();
+  const int ldl = (V + 3) & ~3;
+  std::vector<int> idx(2 * (size_t)FC), labc((size_t)(C - 1) * FC);
+  for (int f0 = 0; f0 < nf; f0 += FC) {
+    const int fc = std::min(FC, nf - f0);
+    for (int i = 0; i < fc; ++i) { idx[i] = fr_prev[f0 + i]; idx[FC + i] = fr_row[f0 + i]; }
+    for (int c = 1; c < C; ++c)
+      for (int i = 0; i < fc; ++i) {
+        const int64_t v = lab[(size_t)fr_row[f0 + i] * (C + 1) + c];
+        labc[(size_t)(c - 1) * FC + i] = (v >= 0 && v < V) ? (int)v : -100;
+      }
+    HIPCK(hipMemcpyAsync(e->loss_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipMemcpyAsync(e->loss_lab, labc.data(), labc.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    DecInArgs di{};
+    di.head_rows = e->loss_head; di.ld_head = e->ld_head; di.Hd = Hd; di.P = P; di.prev_row = e->loss_idx; di.tok_row = e->loss_idx + FC;
+    di.ids = ids; di.C = C; di.V = V; di.proj_table = e->w.proj_table; di.out = e->p_h;
+    LCK(launch_dec_input(e->stream, fc, di));
+    LCK(launch_rows_iota(e->stream, e->p_row_seq, e->p_row_pos, fc * P, P, 0));
+    int pending = 0;
+    size_t part_stride = 0;
+    if ((r = stack_rows(e, e->dec, e->loss_kc.data(), e->loss_vc.data(), e->dec.lmax, fc, P, 0, nullptr, nullptr, false, &pending, &part_stride)))
+      return r;
+    for (int c = 1; c < C; ++c) {   // codebook c from position c of every frame (modeling_csm.py:447-463)
+      GemvArgs a{};
+      a.nt = 0;
+      a.W = (const char*)e->w.audio_head_t + (size_t)(c - 1) * V * Hd * w_esz(e);
+      a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(c - 1) * V : nullptr;
+      a.N = V; a.K = Hd; a.x = e->p_h + (size_t)c * Hd; a.ldx = P * Hd; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
+      a.out = e->loss_logits; a.ldo = ldl;
+      if ((r = gemv_rows(e, fc, PRO_NORM, EPI_STORE, a))) return r;
+      CeArgs ce{};
+      ce.logits = e->loss_logits; ce.ld = ldl; ce.V = V; ce.rows = fc; ce.labels = e->loss_lab + (size_t)(c - 1) * FC; ce.row_loss = e->loss_rows;
+      LCK(launch_ce_rows(e->stream, ce));
+      LCK(launch_ce_reduce(e->stream, e->loss_rows, ce.labels, V, fc, e->loss_acc + 2));
+    }
+    HIPCK(hipStreamSynchronize(e->stream));   // idx / labc are overwritten by the next chunk
+  }
+  LCK(launch_loss_finalize(e->stream, e->loss_acc, nf, out3));
+  return 0;
+}
+
 static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, GraphEntry& ent) {
   ent.n_launch = (int)geoms.size();
   if (geoms.empty()) return 0;

@@ -182,6 +182,25 @@ int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojAr
   return launch_attn_oproj_t<float, float>(st, a);
 }
 
+int launch_ce_rows(hipStream_t st, const CeArgs& a) {
+  if (a.rows < 1) return 0;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(a.rows), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+int launch_ce_reduce(hipStream_t st, const float* row_loss, const int* labels, int V, int rows, double* acc) {
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, labels, V, rows, acc);
+  return (int)hipGetLastError();
+}
+int launch_loss_finalize(hipStream_t st, const double* acc, int frames, float* out3) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, acc, frames, out3);
+  return (int)hipGetLastError();
+}
+int launch_dec_input(hipStream_t st, int frames, const DecInArgs& a) {
+  if (a.Hd % 4) return -1;
+  hipLaunchKernelGGL(dec_input_kernel, dim3(frames, a.P), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
   if (a.H % 8 != 0) return -1;
   if (a.C + 1 > 64) return -1;

@@ -617,3 +617,93 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   }
 }
 #endif  // CSM_ARGS_ONLY
+
+// ---------------------------------------------------------------------------------------------------
+// Training forward, labels branch (reference modeling_csm.py:367-465): cross-entropy over logits rows, the decoder
+// inputs of the labelled frames.  Forward only: the loss values of the reference, no backward pass.
+// ---------------------------------------------------------------------------------------------------
+struct CeArgs {
+  const float* logits;  // [rows][ld]
+  int ld, V, rows;
+  const int* labels;    // [rows]; < 0 = ignore_index (-100)
+  float* row_loss;      // [rows]: logsumexp(logits) - logits[label], 0 for ignored rows
+};
+struct DecInArgs {
+  const float* head_rows;   // [B*S][ld_head]: columns [0, Hd) = projection(final-normed backbone state) of every position
+  int ld_head, Hd, P;       // P = decoder positions per frame (32)
+  const int* prev_row;      // [frames] context row whose backbone state predicts the frame (t - 1, wrapping like the reference's index)
+  const int* tok_row;       // [frames] context row of the frame itself (its audio tokens are the inputs of positions 1..)
+  const int64_t* ids;       // [B*S][C+1]
+  int C, V;
+  const float* proj_table;  // [C*V][Hd] = projection(audio_embeddings)
+  float* out;               // [frames * P][Hd]
+};
+
+#ifndef CSM_ARGS_ONLY
+// one workgroup per row (nn.CrossEntropyLoss(ignore_index=-100) per element, modeling_csm.py:374-386, 458-463)
+__global__ __launch_bounds__(256) void ce_rows_kernel(CeArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int lab = a.labels[row];
+  if (lab < 0 || lab >= a.V) {   // ignored
+    if (tid == 0) a.row_loss[row] = 0.f;
+    return;
+  }
+  const float* lr = a.logits + (size_t)row * a.ld;
+  float mx = -INFINITY;
+  for (int i = tid; i < a.V; i += 256) mx = fmaxf(mx, lr[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int i = tid; i < a.V; i += 256) se += __expf(lr[i] - mx);
+  se = wave_sum(se);
+  if ((tid & 63) == 0) red[tid >> 6] = se;
+  __syncthreads();
+  if (tid == 0) a.row_loss[row] = (mx + logf((red[0] + red[1]) + (red[2] + red[3]))) - lr[lab];
+}
+
+// acc[0] += sum of the row losses, acc[1] += labelled rows: one workgroup, fixed order (deterministic), fp64 inside
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const int* labels, int V, int rows, double* acc) {
+  __shared__ double ss[256];
+  __shared__ double sc[256];
+  const int tid = threadIdx.x;
+  double s = 0.0, c = 0.0;
+  for (int i = tid; i < rows; i += 256) {
+    const int lab = labels[i];
+    if (lab >= 0 && lab < V) { s += (double)row_loss[i]; c += 1.0; }
+  }
+  ss[tid] = s; sc[tid] = c;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) {
+    if (tid < o) { ss[tid] += ss[tid + o]; sc[tid] += sc[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) { acc[0] += ss[0]; acc[1] += sc[0]; }
+}
+
+// out3 = (loss, backbone_loss, decoder_loss): means over the labelled elements (0 / 0 = NaN like torch for an all-ignored
+// backbone target; the decoder term is 0 when no frame is fully labelled, modeling_csm.py:464-465)
+__global__ void loss_finalize_kernel(const double* acc, int frames, float* out3) {
+  const float bl = (float)(acc[0] / acc[1]);
+  const float dl = frames > 0 ? (float)(acc[2] / acc[3]) : 0.f;
+  out3[0] = bl + dl; out3[1] = bl; out3[2] = dl;
+}
+
+// grid = (frames, P): decoder input rows (modeling_csm.py:399-440)
+__global__ __launch_bounds__(256) void dec_input_kernel(DecInArgs a) {
+  const int f = blockIdx.x, p = blockIdx.y;
+  const float* src;
+  if (p == 0) {
+    src = a.head_rows + (size_t)a.prev_row[f] * a.ld_head;
+  } else {
+    const int64_t tok = a.ids[(size_t)a.tok_row[f] * (a.C + 1) + (p - 1)];
+    src = a.proj_table + ((size_t)tok + (size_t)(p - 1) * a.V) * a.Hd;
+  }
+  float* dst = a.out + ((size_t)f * a.P + p) * a.Hd;
+  for (int i = threadIdx.x * 4; i < a.Hd; i += 1024) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+}
+#endif  // CSM_ARGS_ONLY
+

@@ -17,7 +17,7 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
@@ -28,7 +28,7 @@ EXPORTS = [
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
-    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length",
+    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss",
 ]
 
 
@@ -122,6 +122,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     lib.csm_read_zero_counts.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
     lib.csm_set_length.argtypes = [vp, i32, i32]
@@ -391,6 +392,27 @@ class Engine:
             self.length += n
         self.batch = B
         return lh, lg
+
+    def forward_loss(self, ids: torch.Tensor, mask: Optional[torch.Tensor], labels: torch.Tensor):
+        """The reference's training forward (modeling_csm.py:367-465), forward only: returns (losses [3] fp32 on the
+        device = loss, backbone_loss, decoder_loss; last_h [B,Hb]; c0_logits [B,V]).  Starts from an empty cache and
+        leaves the context prefilled; B*S must fit the prefill scratch (max_prefill_rows)."""
+        B, S = ids.shape[0], ids.shape[1]
+        if B * S > self.max_prefill_rows:
+            raise ValueError(f"B*S = {B * S} exceeds max_prefill_rows {self.max_prefill_rows}")
+        ids, m = self._prep_ids(ids, mask)
+        lab = labels.to(device=self.device, dtype=torch.int64).contiguous()
+        if lab.shape != ids.shape:
+            raise ValueError(f"labels {tuple(lab.shape)} must match input_ids {tuple(ids.shape)}")
+        out = torch.empty(3, dtype=torch.float32, device=self.device)
+        lh = torch.empty(B, self.Hb, dtype=torch.float32, device=self.device)
+        lg = torch.empty(B, self.V, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_forward_loss(self._h, _ptr(ids), _ptr(m), _ptr(lab), B, S, _ptr(out), _ptr(lh), _ptr(lg)))
+        self.sync()
+        self.length += S
+        self.batch = B
+        return out, lh, lg
 
     def step_ids(self, ids: torch.Tensor, mask: Optional[torch.Tensor], advance_frame: bool):
         B = ids.shape[0]

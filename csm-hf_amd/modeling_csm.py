@@ -12,7 +12,8 @@ Deviations from the reference, all deliberate (DESIGN.md "Deviations"):
   * left-padded rows mask their pads at every step, so a padded row equals its solo run (the reference
     forgets the pad mask on decode steps).
   * `past_key_values` is an opaque handle onto the engine-resident KV cache, not a `DynamicCache`.
-  * the training branch (`labels=`, :367-465) is out of scope and raises NotImplementedError.
+  * the training branch (`labels=`, :367-465) is built FORWARD ONLY: `forward(labels=...)` returns the reference's loss,
+    backbone_loss and decoder_loss (tensors without autograd history); there is no backward pass.
 """
 from __future__ import annotations
 
@@ -315,11 +316,11 @@ class CSMModel(nn.Module):
                 generate_frame=False, labels=None):
         """reference :292-482, inference branch.  `temperature/topk/generate_frame` accepted and ignored
         as in the reference."""
-        if labels is not None:
-            raise NotImplementedError("the training branch (labels=) is out of scope of csm_hf_amd")
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         use_cache = use_cache if use_cache is not None else self._using_kv_cache
         B, S = input_ids.shape[0], input_ids.shape[1]
+        if labels is not None:
+            return self._forward_loss(input_ids, attention_mask, labels, position_ids, past_key_values, use_cache, return_dict)
         if position_ids is not None and tuple(position_ids.shape) not in ((B, S), (1, S)):
             raise ValueError(f"position_ids must be [B, S] or [1, S], got {tuple(position_ids.shape)}")
         hf_layers = None if isinstance(past_key_values, CSMKVCache) else _hf_cache_layers(past_key_values)
@@ -363,6 +364,30 @@ class CSMModel(nn.Module):
             out = (last_h, c0)
             return out + (pkv,) if use_cache else out
         return CSMOutput(last_hidden_state=last_h, logits=c0, past_key_values=pkv)
+
+    def _forward_loss(self, input_ids, attention_mask, labels, position_ids, past_key_values, use_cache, return_dict):
+        """reference :367-465, forward only: loss = backbone_loss (codebook-0 cross-entropy, shifted by one position) +
+        decoder_loss (codebooks 1..31 over the frames whose 32 audio labels are all present).  The losses come back as
+        fp32 tensors WITHOUT autograd history -- this package has no backward pass; the call evaluates the reference's
+        training objective.  Like the reference's training batches: a fresh context (no past_key_values / position_ids)."""
+        if past_key_values is not None or position_ids is not None:
+            raise NotImplementedError("forward(labels=...) takes a fresh context: no past_key_values / position_ids")
+        B, S = input_ids.shape[0], input_ids.shape[1]
+        if tuple(labels.shape) != tuple(input_ids.shape):
+            raise ValueError(f"labels {tuple(labels.shape)} must match input_ids {tuple(input_ids.shape)}")
+        eng = self._ensure_engine(B, S + 1, 1, max(B * S, 32))
+        eng.reset()
+        self._epoch += 1
+        self._frame_pending = False
+        eng.set_kv_start(self._kv_starts(attention_mask, B, S))
+        losses, last_h, c0 = eng.forward_loss(input_ids, attention_mask, labels)
+        pkv = CSMKVCache(self, self._epoch, eng.length, B, False) if use_cache else None
+        last_h, c0 = self._out_dtype(last_h), self._out_dtype(c0)
+        loss, bl, dl = losses[0], losses[1], losses[2]
+        if not return_dict:
+            out = (loss, last_h, c0)
+            return out + (pkv,) if use_cache else out
+        return CSMOutput(last_hidden_state=last_h, logits=c0, past_key_values=pkv, loss=loss, backbone_loss=bl, decoder_loss=dl)
 
     @torch.no_grad()
     def generate_frame(self, input_ids, attention_mask, position_ids=None, temperature=1.0, topk=50,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 3
+#define CSM_ABI_VERSION 4
 
 enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
@@ -151,6 +151,14 @@ int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B,
  * which masks by cache index and rotates by position_ids */
 int csm_prefill_pos(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* position_ids,
                     float* last_h_out, float* c0_logits_out);
+/* ---- CSMModel.forward with labels (modeling_csm.py:367-465): the training objective, FORWARD ONLY.
+ * labels [B,S,C+1] int64 on the device, -100 = ignored.  out3 (device, 3 floats) = (loss, backbone_loss, decoder_loss):
+ * cross-entropy of the codebook-0 logits of position t against labels[:, t+1, 0], plus cross-entropy of the decoder's
+ * codebook 1..C-1 logits over the frames whose C audio labels are all present -- the reference's
+ * nn.CrossEntropyLoss(ignore_index=-100) means.  Starts from an empty cache (csm_reset) and leaves the context prefilled
+ * like csm_prefill does (last_h_out / c0_logits_out as there, nullable).  No backward pass is provided. */
+int csm_forward_loss(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, const int64_t* labels, int B, int S,
+                     float* out3, float* last_h_out, float* c0_logits_out);
 /* backbone KV cache <-> the HF layout of `past_key_values` (transformers DynamicCache: per layer keys / values
  * [B, n_kv, len, head_dim]; reference modeling_csm.py:355-358 returns it, :349 takes it back), fp32 on the device.
  * Export reads the resident batch; import + csm_set_length continue a context the caller built, forked or edited. */

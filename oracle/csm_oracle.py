@@ -245,6 +245,36 @@ def forward(sd, cfg, input_ids, attention_mask, cache: Optional[KVCache] = None,
 
 
 # --------------------------------------------------------------------------------------------------
+# reference CSMModel.forward, labels branch (modeling_csm.py:367-465): codebook-0 cross-entropy over all positions
+# (shifted by one) + decoder cross-entropy over the frames whose 32 audio labels are all present
+# --------------------------------------------------------------------------------------------------
+def forward_loss(sd, cfg, input_ids, attention_mask, labels):
+    """Returns (loss, backbone_loss, decoder_loss, last_hidden [B,H], c0_logits [B,V]) like the reference's training
+    forward does for `labels` [B,S,C+1] (-100 = ignored).  fp32 tensors, no autograd bookkeeping."""
+    C, V = cfg.audio_num_codebooks, cfg.audio_vocab_size
+    h, valid = embed_frames(sd, cfg, input_ids, attention_mask)
+    hb, _ = llama_forward(sd, "backbone", cfg.backbone_config, h, None, None, new_valid=valid)   # :345-354
+    c0_all = F.linear(hb, sd["codebook0_head.weight"])                                            # :361
+    # :373-386  predict label[t+1] from hidden[t]
+    backbone_loss = F.cross_entropy(c0_all[:, :-1, :].reshape(-1, V).float(), labels[:, 1:, 0].reshape(-1), ignore_index=-100)
+    audio_tokens, audio_labels = input_ids[:, :, :C], labels[:, :, :C]                            # :389-392
+    frames = (audio_labels != -100).all(dim=2).nonzero(as_tuple=False)                           # :395-396
+    if frames.numel() > 0:
+        b, t = frames[:, 0], frames[:, 1]
+        frame_hidden = hb[b, t - 1]                       # :402-404 (t = 0 wraps to the last position, as indexing does)
+        toks, labs = audio_tokens[b, t], audio_labels[b, t]
+        proj = sd["projection.weight"]
+        emb = F.embedding((toks + torch.arange(C) * V).view(-1), sd["audio_embeddings.weight"]).view(len(b), C, -1)   # :416-431
+        dec_in = torch.cat([F.linear(frame_hidden, proj).unsqueeze(1), F.linear(emb, proj)], dim=1)                    # :434-440
+        dh, _ = llama_forward(sd, "decoder", cfg.decoder_config, dec_in, None, None)              # :441-444, default causal
+        logits = torch.einsum("fcd,cdv->fcv", dh[:, 1:C, :], sd["audio_head"])                    # :447-454
+        decoder_loss = F.cross_entropy(logits.reshape(-1, V), labs[:, 1:].reshape(-1), ignore_index=-100)   # :458-463
+    else:
+        decoder_loss = torch.tensor(0.0)
+    return backbone_loss + decoder_loss, backbone_loss, decoder_loss, hb[:, -1, :], c0_all[:, -1, :]
+
+
+# --------------------------------------------------------------------------------------------------
 # reference CSMModel.generate_frame (modeling_csm.py:508-589)
 # --------------------------------------------------------------------------------------------------
 def generate_frame(sd, cfg, input_ids, attention_mask, temperature=1.0, topk=50, cache=None, use_cache=True,

@@ -3,7 +3,7 @@
 Runs only in the build container (needs /root/reference and `transformers`); the reference never
 travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
 
-    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise] [--frames2 200]
+    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss] [--frames2 200]
 
 What it does
   * imports /root/reference/modeling_csm.py unmodified;
@@ -312,9 +312,53 @@ def gen_processor():
     print("[golden] processor written", flush=True)
 
 
+def loss_inputs(cfg, batch, n_text, n_audio, seed):
+    """Context + labels in the layout the reference's processor produces for training (processor.py:330-378): labels
+    repeat the audio tokens of audio frames, text frames are -100; a few frames are dropped from the decoder loss (the
+    1/16 amortisation leaves most frames unlabelled: here ~1/3 kept), and one frame has a single codebook masked."""
+    ids, mask = synth_context(cfg, batch, n_text, n_audio, seed=seed)
+    C = cfg.audio_num_codebooks
+    labels = torch.full_like(ids, -100)
+    labels[:, n_text:, :C] = ids[:, n_text:, :C]
+    g = torch.Generator().manual_seed(seed)
+    drop = torch.rand(batch, n_audio, generator=g) > 0.34
+    drop[:, 0] = False                                   # the first audio frame stays (its predecessor is a text frame)
+    for b in range(batch):
+        for t in range(n_audio):
+            if drop[b, t]:
+                labels[b, n_text + t, 1:C] = -100        # codebook 0 stays labelled: it feeds the backbone loss
+    labels[batch - 1, n_text + 1, 5] = -100              # a frame with ONE missing codebook is not a decoder frame
+    return ids, mask, labels
+
+
+def gen_loss():
+    """Training forward (modeling_csm.py:367-465): loss / backbone_loss / decoder_loss of the reference itself."""
+    for name, cfg, dtype, shape in (("tiny", CSMConfig.tiny(), torch.float32, (2, 4, 10)),
+                                    ("csm1b", CSMConfig(), torch.bfloat16, (2, 6, 18))):
+        t0 = time.time()
+        if name == "tiny":
+            sd = synth_state_dict(cfg, seed=0, std=0.05)
+        else:
+            sd = synth_state_dict(cfg, seed=0, dtype=dtype, bf16_representable=True)
+        sd32 = {k: v.float() for k, v in sd.items()}
+        model = build_ref(cfg, sd32, torch.float32)      # fp32 arithmetic on the (bf16-representable) weights
+        ids, mask, labels = loss_inputs(cfg, *shape, seed=41)
+        with torch.no_grad():
+            out = model(input_ids=ids, attention_mask=mask, labels=labels, return_dict=True)
+        o = O.forward_loss(sd32, cfg, ids, mask, labels)
+        assert abs(float(o[0]) - float(out.loss)) < 2e-5 * abs(float(out.loss)), (o[0], out.loss)
+        assert abs(float(o[1]) - float(out.backbone_loss)) < 2e-5 and abs(float(o[2]) - float(out.decoder_loss)) < 2e-5
+        np.savez_compressed(os.path.join(GOLD, f"{name}_loss.npz"), input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                            labels=labels.numpy(), loss=np.float32(out.loss), backbone_loss=np.float32(out.backbone_loss),
+                            decoder_loss=np.float32(out.decoder_loss), last_h=out.last_hidden_state.float().numpy(),
+                            c0_logits=out.logits.float().numpy())
+        print(f"[golden] {name}_loss written: loss {float(out.loss):.6f} = {float(out.backbone_loss):.6f} + "
+              f"{float(out.decoder_loss):.6f}  ({time.time() - t0:.1f}s)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise")
+    ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss")
     ap.add_argument("--frames2", type=int, default=200)
     a = ap.parse_args()
     which = set(a.only.split(","))
@@ -327,6 +371,8 @@ def main():
         gen_processor()
     if which & {"cfg1", "prefill512", "cfg2", "b4", "b4noise"}:
         gen_1b(which, a.frames2)
+    if "loss" in which:
+        gen_loss()
 
 
 if __name__ == "__main__":

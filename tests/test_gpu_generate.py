@@ -136,7 +136,7 @@ def test_tiny_api_generate_frame_forward_and_errors():
         cm = torch.zeros(2, 1, 33, dtype=mask.dtype, device=DEV)
         cm[:, :, :32] = 1
     assert torch.equal(torch.stack(got, 1).cpu(), want)
-    # forward(): hidden/logits vs oracle; tuple return; stale cache handle; labels unsupported
+    # forward(): hidden/logits vs oracle; tuple return; stale cache handle; mis-shaped labels
     o = m.forward(ids.to(DEV), mask.to(DEV), use_cache=True)
     lh, lg, _ = O.forward(sd, cfg, ids, mask)
     torch.testing.assert_close(o.last_hidden_state.cpu(), lh, atol=2e-4, rtol=0)
@@ -145,8 +145,8 @@ def test_tiny_api_generate_frame_forward_and_errors():
     assert isinstance(t, tuple) and len(t) == 3
     with pytest.raises(ValueError):
         m.forward(cur, cm, past_key_values=pkv)            # handle from an older engine state
-    with pytest.raises(NotImplementedError):
-        m.forward(ids.to(DEV), mask.to(DEV), labels=ids.to(DEV))
+    with pytest.raises(ValueError):
+        m.forward(ids.to(DEV), mask.to(DEV), labels=ids[:, :2].to(DEV))        # labels must match input_ids
     with pytest.raises(RuntimeError):
         m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=1, topk=cfg.audio_vocab_size + 1)
     assert m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=0).shape == (2, 0, 32)

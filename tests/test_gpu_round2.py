@@ -350,6 +350,59 @@ def test_decoder_attention_and_o_proj_as_one_launch(wdtype, kvdtype):
     m._drop_engine()
 
 
+@pytest.mark.parametrize("name", ["tiny", "csm1b"])
+def test_training_forward_loss_vs_reference(name):
+    """SURVEY.md section 8 row f-3, forward only: `forward(labels=...)` returns the reference's loss / backbone_loss /
+    decoder_loss (modeling_csm.py:367-465) -- against the values the reference itself produced for the committed inputs
+    (fp32 arithmetic on the same weights).  Tolerance 2e-4 relative: fp32 summation order over ~2 000-way softmaxes."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_loss.npz"))
+    if name == "tiny":
+        cfg = CSMConfig.tiny()
+        sd = synth_state_dict(cfg, seed=0, std=0.05)
+    else:
+        cfg = CSMConfig()
+        sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    ids, mask, labels = (torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
+    out = m.forward(ids, mask, labels=labels, return_dict=True)
+    for k in ("loss", "backbone_loss", "decoder_loss"):
+        got, want = float(getattr(out, k)), float(g[k])
+        assert abs(got - want) < 2e-4 * abs(want), (k, got, want)
+    assert not out.loss.requires_grad
+    lh = out.last_hidden_state.float().cpu()
+    assert float((lh - torch.from_numpy(g["last_h"])).norm() / torch.from_numpy(g["last_h"]).norm()) < (1e-4 if name == "tiny" else 5e-3)
+    tup = m.forward(ids, mask, labels=labels, return_dict=False, use_cache=False)
+    assert len(tup) == 3 and abs(float(tup[0]) - float(g["loss"])) < 2e-4 * float(g["loss"])
+    # no fully labelled frame: decoder term 0, backbone term unchanged
+    lab2 = labels.clone()
+    lab2[:, :, 1] = -100
+    o2 = m.forward(ids, mask, labels=lab2, return_dict=True)
+    assert float(o2.decoder_loss) == 0.0 and abs(float(o2.backbone_loss) - float(g["backbone_loss"])) < 2e-4 * float(g["backbone_loss"])
+    # the context is left prefilled: a later frame continues from it
+    S = ids.shape[1]
+    o3 = m.forward(ids[:, :S - 1], mask[:, :S - 1], labels=labels[:, :S - 1], use_cache=True, return_dict=True)
+    assert o3.past_key_values.get_seq_length() == S - 1
+    cont = m.forward(ids[:, S - 1:], mask[:, S - 1:], past_key_values=o3.past_key_values, use_cache=True, return_dict=True)
+    full = m.forward(ids, mask, use_cache=True, return_dict=True)
+    a, b = cont.last_hidden_state.float(), full.last_hidden_state.float()     # model dtype (bf16 for csm-1b): one rounding apart at most
+    assert float((a - b).norm() / b.norm()) < (1e-4 if name == "tiny" else 1e-2)
+    if name == "tiny":
+        # more labelled frames than one decoder pass takes (256): 3 x 120 frames run as two passes -- against the oracle
+        sd32 = {k: v.float().cpu() for k, v in sd.items()}
+        ids3, mask3 = synth_context(cfg, 3, 8, 120, seed=77)
+        lab3 = torch.full_like(ids3, -100)
+        lab3[:, 8:, :32] = ids3[:, 8:, :32]
+        lab3[1, 50, 7] = -100
+        want = O.forward_loss(sd32, cfg, ids3, mask3, lab3)
+        o4 = m.forward(ids3.to(DEV), mask3.to(DEV), labels=lab3.to(DEV), return_dict=True)
+        for got, w in zip((o4.loss, o4.backbone_loss, o4.decoder_loss), want[:3]):
+            assert abs(float(got) - float(w)) < 2e-4 * abs(float(w)), (float(got), float(w))
+    m._drop_engine()
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)

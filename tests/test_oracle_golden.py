@@ -111,3 +111,22 @@ def test_oracle_csm1b_cfg1_fp32_bit_exact(gold):
     np.testing.assert_allclose(tr["last_h"].numpy(), g["last_h"], atol=1e-4, rtol=0)
     tv = torch.topk(tr["logits"], 4, dim=-1)[0].numpy()
     np.testing.assert_allclose(tv, g["top_vals"], atol=1e-4, rtol=0)
+
+
+def test_oracle_training_forward_loss_vs_reference(gold):
+    """reference modeling_csm.py:367-465 (labels branch): the oracle's restatement against the losses the reference itself
+    returned for the committed inputs (tiny config; the csm-1b fixture is checked when the oracle was pinned and on the GPU)."""
+    g = gold("tiny_loss")
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    ids, mask, labels = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels"))
+    loss, bl, dl, last_h, c0 = O.forward_loss(sd, cfg, ids, mask, labels)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert abs(float(bl) - float(g["backbone_loss"])) < 1e-4 and abs(float(dl) - float(g["decoder_loss"])) < 1e-4
+    torch.testing.assert_close(last_h, torch.from_numpy(g["last_h"]), atol=2e-5, rtol=0)
+    # no fully labelled frame -> the decoder term is 0 (:464-465); every label ignored -> NaN like torch's mean over nothing
+    lab2 = labels.clone()
+    lab2[:, :, 1] = -100
+    _, bl2, dl2, _, _ = O.forward_loss(sd, cfg, ids, mask, lab2)
+    assert float(dl2) == 0.0 and abs(float(bl2) - float(bl)) < 1e-6
+
