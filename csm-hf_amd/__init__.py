@@ -4,5 +4,6 @@ compute: hand-written HIP kernels for gfx950 behind the C-ABI in `include/csm_hi
 from .configuration_csm import CSMConfig, LlamaSubConfig  # noqa: F401
 from .modeling_csm import CSMModel, CSMOutput, CSMKVCache, sample_topk  # noqa: F401
 from .processor import CSMProcessor  # noqa: F401
+from .serving import ContinuousBatcher  # noqa: F401
 
-__all__ = ["CSMConfig", "LlamaSubConfig", "CSMModel", "CSMOutput", "CSMKVCache", "sample_topk", "CSMProcessor"]
+__all__ = ["CSMConfig", "LlamaSubConfig", "CSMModel", "CSMOutput", "CSMKVCache", "sample_topk", "CSMProcessor", "ContinuousBatcher"]

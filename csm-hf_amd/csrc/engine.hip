@@ -1065,6 +1065,44 @@ extern "C" int csm_get_state(csm_engine_t* e, float* last_h_out, float* c0_logit
 // about `pf_sub_kb`; run e may be fetched once the bytes of runs whose consumer has not started yet, up to and including
 // e, fit the window (cyclically over consecutive frames).  Runs that could only be fetched after their own consumer has
 // started are left to the consumer.
+// ---- continuous batching (SURVEY f-4; no reference counterpart): a NEW utterance takes over batch row `row` of a running
+// batch.  Its S context frames are prefilled right-aligned against the batch's current length L (cache positions
+// L - S .. L - 1 of that row, kv_start[row] = L - S: exactly the layout of a left-padded row, which the reference positions
+// the same way -- RoPE is relative, `tiny_padded`), the row's head output is replaced, its stop flag cleared; the other
+// rows, the captured frame-step graphs and the frame counter are untouched.  Call between two csm_generate /
+// csm_decode_frame + csm_backbone_step pairs.  The row's frames from the current frame index on belong to the new utterance.
+extern "C" int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, const uint8_t* mask, int S) {
+  if (!e || !e->bound || !ids) return fail(CSM_ERR_ARG, "null argument");
+  if (!e->ready || e->B < 1) return fail(CSM_ERR_STATE, "no running batch (csm_prefill first)");
+  if (row < 0 || row >= e->B) return fail(CSM_ERR_ARG, "row %d outside the running batch of %d", row, e->B);
+  if (S < 1 || S > e->h_len) return fail(CSM_ERR_CAPACITY, "a joining context (%d frames) cannot be longer than the batch's current length (%d)", S, e->h_len);
+  if (S > e->cfg.max_prefill_rows) return fail(CSM_ERR_CAPACITY, "context %d exceeds max_prefill_rows %d", S, e->cfg.max_prefill_rows);
+  Stack& s = e->bb;
+  const int Hb = s.c.hidden, past = e->h_len - S;
+  const size_t kvb = e->cfg.kv_dtype == 1 ? 2 : 4;
+  const size_t slot = (size_t)s.c.n_kv * s.lmax * s.c.head_dim * kvb;
+  std::vector<void*> kc(s.c.layers), vc(s.c.layers);
+  for (int l = 0; l < s.c.layers; ++l) { kc[l] = (char*)s.kc[l] + (size_t)row * slot; vc[l] = (char*)s.vc[l] + (size_t)row * slot; }
+  LCK(launch_set_int(e->stream, e->d_kv_start + row, past));
+  if (e->d_row_done) LCK(launch_set_int(e->stream, e->d_row_done + row, 0));
+  LCK(launch_rows_iota(e->stream, e->p_row_seq, e->p_row_pos, S, S, past));
+  EmbedArgs em{};
+  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
+  em.ids = ids; em.mask = mask; em.out = e->p_h;
+  LCK(launch_embed(e->stream, emb_dtype(e), S, em));
+  int pending = 0;
+  size_t part_stride = 0;
+  if (int r = stack_rows(e, s, kc.data(), vc.data(), s.lmax, 1, S, past, e->d_kv_start + row, nullptr, true, &pending, &part_stride)) return r;
+  const float* hl = e->p_h + (size_t)(S - 1) * Hb;
+  LCK(launch_rmsnorm(e->stream, hl, Hb, s.final_norm, 1, Hb, s.c.rms_eps, e->last_h + (size_t)row * Hb, Hb, nullptr, 0, 0, nullptr, 0,
+                     pending > 1 ? e->p_part + (size_t)(S - 1) * Hb : nullptr, pending, part_stride, Hb));
+  GemvArgs a{};
+  a.nt = e->nt_backbone;
+  a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;
+  a.x = hl; a.ldx = Hb; a.ln = s.final_norm; a.eps = s.c.rms_eps; a.out = e->head_out + (size_t)row * e->ld_head; a.ldo = e->ld_head;
+  return gemv_rows(e, 1, PRO_NORM, EPI_STORE, a);
+}
+
 // ---- training forward, labels branch (reference modeling_csm.py:367-465) -------------------------------------------------
 // loss = CE(codebook-0 logits of position t, label of t+1) + CE(decoder logits of codebooks 1..C-1 over the frames whose C
 // audio labels are all present), both as the reference's nn.CrossEntropyLoss(ignore_index=-100) means.  FORWARD ONLY (no

@@ -28,7 +28,7 @@ EXPORTS = [
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
-    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss",
+    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
 ]
 
 
@@ -123,6 +123,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_read_zero_counts.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.csm_prefill_slot.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
     lib.csm_set_length.argtypes = [vp, i32, i32]
@@ -392,6 +393,18 @@ class Engine:
             self.length += n
         self.batch = B
         return lh, lg
+
+    def prefill_slot(self, row: int, ids: torch.Tensor, mask: Optional[torch.Tensor]):
+        """Continuous batching: a new utterance (ids/mask [S,C+1] or [1,S,C+1]) takes over batch row `row` of the running
+        batch; its context is placed right-aligned against the current length (S <= self.length)."""
+        if ids.dim() == 2:
+            ids = ids.unsqueeze(0)
+            mask = None if mask is None else mask.unsqueeze(0)
+        S = ids.shape[1]
+        ids, m = self._prep_ids(ids, mask)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_prefill_slot(self._h, int(row), _ptr(ids), _ptr(m), S))
+        self.sync()
 
     def forward_loss(self, ids: torch.Tensor, mask: Optional[torch.Tensor], labels: torch.Tensor):
         """The reference's training forward (modeling_csm.py:367-465), forward only: returns (losses [3] fp32 on the

@@ -1,0 +1,113 @@
+"""Continuous batching of utterances into one fixed-shape running batch.
+
+No reference counterpart: the reference's `generate` (modeling_csm.py:591-702) runs one batch to completion and stops
+when ALL rows emit an all-zero frame in the same step (:662).  Here a batch of `batch_size` rows keeps replaying the
+captured frame-step graph; a row whose utterance has finished (all-zero frame, or its frame budget) is handed to the
+next queued utterance through `csm_prefill_slot`: the new context is prefilled right-aligned against the batch's
+current length (the layout of a left-padded row, which the reference positions the same way), the other rows never
+notice.  Finished rows that find no successor are frozen by the per-row stop (they emit zeros).
+
+Limits (by construction of the shared-length cache): a joining context cannot be longer than the batch's current
+length; it waits in the queue until the batch has grown that far (or starts the next batch).
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Dict, Optional
+
+import torch
+
+
+class ContinuousBatcher:
+    def __init__(self, model, batch_size: int, temperature: float = 1.0, topk: int = 50, max_new_frames: int = 100,
+                 check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None):
+        if batch_size < 1:
+            raise ValueError("batch_size must be positive")
+        self.model = model
+        self.B = int(batch_size)
+        self.temperature, self.topk = float(temperature), int(topk)
+        self.default_budget = int(max_new_frames)
+        self.check_every = max(1, int(check_every))
+        self.seed = seed
+        self.initial_frames = initial_frames   # frames of cache room reserved up front (default: every queued budget, <= 4096)
+        self._queue = deque()
+        self._next_id = 0
+        self.joined_mid_batch = 0      # utterances that took over a row of a running batch (statistics)
+
+    def submit(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: Optional[int] = None) -> int:
+        """input_ids / attention_mask `[T, 33]` (or `[1, T, 33]`) of ONE utterance; returns its request id."""
+        if input_ids.dim() == 3:
+            input_ids, attention_mask = input_ids[0], attention_mask[0]
+        if input_ids.dim() != 2 or input_ids.shape != attention_mask.shape:
+            raise ValueError("one utterance: input_ids and attention_mask of shape [T, C+1]")
+        rid = self._next_id
+        self._next_id += 1
+        self._queue.append((rid, input_ids.cpu(), attention_mask.cpu(), int(max_new_frames or self.default_budget)))
+        return rid
+
+    # ------------------------------------------------------------------------------------------------------------
+    def run(self) -> Dict[int, torch.Tensor]:
+        """Generates every queued utterance; returns {request id: LongTensor [n, 32]} (frames before the all-zero
+        frame, at most the request's budget) on the CPU."""
+        results: Dict[int, torch.Tensor] = {}
+        while self._queue:
+            self._run_batch(results)
+        return results
+
+    def _run_batch(self, results):
+        m, B = self.model, self.B
+        C = m.config.audio_num_codebooks
+        first = [self._queue.popleft() for _ in range(min(B, len(self._queue)))]
+        T0 = max(r[1].shape[0] for r in first)
+        ids = torch.zeros(B, T0, C + 1, dtype=torch.long)
+        mask = torch.zeros(B, T0, C + 1, dtype=first[0][2].dtype)
+        rows = []                                   # per row: None (idle) or [rid, budget, list of frames]
+        for b in range(B):
+            rid, ri, rm, budget = first[b] if b < len(first) else first[0]
+            T = ri.shape[0]
+            ids[b, T0 - T:], mask[b, T0 - T:] = ri, rm                 # left padding
+            rows.append([rid, budget, []] if b < len(first) else None)
+        k = self.check_every
+        # room for every queued budget up front where that is cheap; beyond it the engine is re-homed on the fly
+        horizon = min(4096, sum(r[3] for r in first) + sum(r[3] for r in self._queue) + 2 * k)
+        if self.initial_frames is not None:
+            horizon = int(self.initial_frames)
+        eng = m._ensure_engine(B, T0 + max(8 * k, horizon) + 1, max(4 * k, 32), B * T0)
+        eng.reset()
+        m._epoch += 1
+        m._frame_pending = False
+        eng.set_kv_start(m._kv_starts(mask, B, T0))
+        eng.prefill(ids, mask, want_outputs=False)
+        s = eng.sampling(temperature=self.temperature, topk=self.topk, seed=m._next_seed() if self.seed is None else int(self.seed),
+                         row_offset=m.row_offset, per_row_stop=True)
+        while any(r is not None for r in rows):
+            if eng.frames + k > eng.max_frames:
+                eng.rewind_frames()                 # every frame so far has been read out
+            if eng.length + k + 1 > eng.max_len:
+                eng = m._ensure_engine(B, eng.length + k + 1, max(4 * k, 32), 1, cont=True)   # re-homed, never restarted
+            f0 = eng.frames
+            eng.generate(s, k, m.use_graph)
+            toks = eng.read_frames(f0, k).cpu()
+            for b, r in enumerate(rows):
+                if r is None:
+                    continue
+                done = False
+                for i in range(k):
+                    if bool((toks[b, i] == 0).all()) or len(r[2]) >= r[1]:
+                        done = True
+                        break
+                    r[2].append(toks[b, i])
+                if done or len(r[2]) >= r[1]:
+                    results[r[0]] = torch.stack(r[2]) if r[2] else torch.zeros(0, C, dtype=torch.long)
+                    rows[b] = self._join(eng, b)
+        m._epoch += 1
+
+    def _join(self, eng, row):
+        """first queued utterance whose context fits under the batch's current length takes over `row`"""
+        for j, (rid, ri, rm, budget) in enumerate(self._queue):
+            if ri.shape[0] <= eng.length:
+                del self._queue[j]
+                eng.prefill_slot(row, ri, rm)
+                self.joined_mid_batch += 1
+                return [rid, budget, []]
+        return None

@@ -151,6 +151,11 @@ int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B,
  * which masks by cache index and rotates by position_ids */
 int csm_prefill_pos(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* position_ids,
                     float* last_h_out, float* c0_logits_out);
+/* ---- continuous batching (no reference counterpart): a new utterance takes over batch row
+ * `row` of the running batch between two frame-steps.  ids [S][C+1] / mask [S][C+1] on the device; S <= the batch's
+ * current length (the context is placed right-aligned, like a left-padded row of the reference).  The row's frames from
+ * the current frame index on belong to the new utterance; other rows are untouched. */
+int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, const uint8_t* mask, int S);
 /* ---- CSMModel.forward with labels (modeling_csm.py:367-465): the training objective, FORWARD ONLY.
  * labels [B,S,C+1] int64 on the device, -100 = ignored.  out3 (device, 3 floats) = (loss, backbone_loss, decoder_loss):
  * cross-entropy of the codebook-0 logits of position t against labels[:, t+1, 0], plus cross-entropy of the decoder's

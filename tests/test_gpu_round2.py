@@ -403,6 +403,46 @@ def test_training_forward_loss_vs_reference(name):
     m._drop_engine()
 
 
+def test_continuous_batching_rows_equal_solo_runs():
+    """SURVEY.md section 8 row f-4: utterances of different lengths and budgets flow through a running batch of 2 rows;
+    a finished row is taken over by the next queued utterance (csm_prefill_slot: context right-aligned against the
+    batch's length, like a left-padded row).  Every utterance's greedy frames equal its SOLO run through the oracle."""
+    from csm_hf_amd import ContinuousBatcher
+    cfg, sd, m = tiny_model()
+    reqs = []
+    for i, (nt, na, budget) in enumerate([(3, 6, 5), (2, 4, 11), (2, 5, 4), (1, 4, 7), (3, 5, 6), (2, 9, 3)]):
+        ids, mask = synth_context(cfg, 1, nt, na, seed=100 + i)
+        reqs.append((ids[0], mask[0], budget))
+    cb = ContinuousBatcher(m, batch_size=2, temperature=1.0, topk=1, check_every=3)
+    rid = [cb.submit(i, k, max_new_frames=b) for i, k, b in reqs]
+    out = cb.run()
+    assert sorted(out) == sorted(rid) and cb.joined_mid_batch >= 3
+    for r, (ids, mask, budget) in zip(rid, reqs):
+        want = O.generate(sd, cfg, ids[None], mask[None], max_new_frames=budget, topk=1, stop_on_all_zeros=False)[0]
+        assert out[r].shape == (budget, 32), (r, out[r].shape)
+        assert torch.equal(out[r], want), f"request {r}"
+    # a second run on the same batcher (new batch, queue drained before) and a batch wider than the queue
+    cb2 = ContinuousBatcher(m, batch_size=4, topk=1, check_every=4)
+    r0 = cb2.submit(reqs[0][0], reqs[0][1], max_new_frames=5)
+    got = cb2.run()
+    assert torch.equal(got[r0], out[rid[0]])
+    # the batch outgrows its cache while running: the live state is re-homed into a larger engine (csm_kv_copy), a row is
+    # taken over after the move, results unchanged
+    m._drop_engine()
+    cb3 = ContinuousBatcher(m, batch_size=2, topk=1, check_every=5, initial_frames=8)
+    long_budget = 135                                   # 9-frame context + 135 frames > the tiny model's 128-position cache
+    ra = cb3.submit(reqs[0][0], reqs[0][1], max_new_frames=long_budget)
+    rb = cb3.submit(reqs[1][0], reqs[1][1], max_new_frames=4)
+    rc = cb3.submit(reqs[2][0], reqs[2][1], max_new_frames=4)
+    got3 = cb3.run()
+    assert m._engine.max_len > 128 and cb3.joined_mid_batch == 1
+    want_a = O.generate(sd, cfg, reqs[0][0][None], reqs[0][1][None], max_new_frames=long_budget, topk=1, stop_on_all_zeros=False)[0]
+    assert torch.equal(got3[ra], want_a) and torch.equal(got3[rb], out[rid[1]][:4]) and torch.equal(got3[rc], out[rid[2]][:4])
+    with pytest.raises(ValueError):
+        m._engine.prefill_slot(0, reqs[5][0][None].repeat(1, 40, 1)[0], None)      # longer than the batch's current length
+    m._drop_engine()
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Continuous batching (csm_hf_amd.serving.ContinuousBatcher) against static batches on csm-1b: N utterances with
+512-frame contexts... kept short here: contexts of 64-128 frames, frame budgets 20-200, batch of 16 rows.
+usage: python tools/serve_bench.py [n_utterances] [batch]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from csm_hf_amd import CSMConfig, CSMModel, ContinuousBatcher  # noqa: E402
+from csm_hf_amd.synth import synth_state_dict, synth_context  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+dev = torch.device("cuda:0")
+cfg = CSMConfig()
+sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=dev, bf16_representable=True)
+m = CSMModel(cfg)
+m.load_state_dict(sd)
+del sd
+g = torch.Generator().manual_seed(3)
+reqs = []
+for i in range(N):
+    T = int(torch.randint(64, 129, (1,), generator=g))
+    budget = int(torch.randint(20, 201, (1,), generator=g))
+    ids, mask = synth_context(cfg, 1, T // 4, T - T // 4, seed=500 + i)
+    reqs.append((ids[0], mask[0], budget))
+total = sum(r[2] for r in reqs)
+for label in ("warm-up", "continuous"):
+    cb = ContinuousBatcher(m, batch_size=B, topk=1, check_every=8)
+    for ids, mask, budget in (reqs[:B] if label == "warm-up" else reqs):
+        cb.submit(ids, mask, max_new_frames=budget if label != "warm-up" else 16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = cb.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if label != "warm-up":
+        assert sum(v.shape[0] for v in out.values()) == total
+        print(f"continuous batching : {N} utterances, {total} frames, batch {B}: {dt:.2f} s = {total / dt:.0f} useful frames/s "
+              f"({cb.joined_mid_batch} utterances joined a running batch)", flush=True)
+# static batches (the reference's rule: a batch runs until its longest row is done), same rows per batch, FIFO order
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+steps = 0
+for b0 in range(0, N, B):
+    chunk = reqs[b0:b0 + B]
+    T0 = max(r[0].shape[0] for r in chunk)
+    ids = torch.zeros(len(chunk), T0, 33, dtype=torch.long)
+    mask = torch.zeros(len(chunk), T0, 33, dtype=chunk[0][1].dtype)
+    for i, (ri, rm, _) in enumerate(chunk):
+        ids[i, T0 - ri.shape[0]:], mask[i, T0 - ri.shape[0]:] = ri, rm
+    n = max(r[2] for r in chunk)
+    m.generate(ids.to(dev), mask.to(dev), max_new_frames=n, topk=1, stop_on_all_zeros=False)
+    steps += n
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"static batches      : same utterances, {steps} frame-steps of {B} rows: {dt:.2f} s = {total / dt:.0f} useful frames/s", flush=True)
