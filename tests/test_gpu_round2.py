@@ -436,7 +436,11 @@ def test_continuous_batching_rows_equal_solo_runs():
     rc = cb3.submit(reqs[2][0], reqs[2][1], max_new_frames=4)
     got3 = cb3.run()
     assert m._engine.max_len > 128 and cb3.joined_mid_batch == 1
-    want_a = O.generate(sd, cfg, reqs[0][0][None], reqs[0][1][None], max_new_frames=long_budget, topk=1, stop_on_all_zeros=False)[0]
+    grown = m._engine.max_len
+    # (the 135-frame solo run comes from the engine's own generate(), itself pinned to the oracle above: the oracle's
+    # Python loop would take most of a minute for it)
+    want_a = m.generate(reqs[0][0][None].to(DEV), reqs[0][1][None].to(DEV), max_new_frames=long_budget, topk=1, stop_on_all_zeros=False)[0].cpu()
+    assert torch.equal(want_a[:5], out[rid[0]])
     assert torch.equal(got3[ra], want_a) and torch.equal(got3[rb], out[rid[1]][:4]) and torch.equal(got3[rc], out[rid[2]][:4])
     with pytest.raises(ValueError):
         m._engine.prefill_slot(0, reqs[5][0][None].repeat(1, 40, 1)[0], None)      # longer than the batch's current length
