@@ -144,7 +144,8 @@ struct csm_engine {
   int h_len = 0, h_frame = 0;
   bool ready = false;   // head_out holds valid c0 logits
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
-  int fuse_attn_oproj = 1;   // M = 1 decoder: attention + o_proj as one launch (attn_oproj.h)
+  int fuse_attn_oproj = 1;   // decoder attention + o_proj as one launch (attn_oproj.h): bit 0 single sequence (B = 1: 3.28 -> 3.16 ms),
+                             // bit 1 batched rows (measured SLOWER at B = 16, 5.58 vs 5.09 ms: off)
   int fuse_dec_attn = 0;  // measured (round 1): separate 2-workgroup attention + register-path o_proj is 4 % faster per frame
   int use_mfma = 1;
   int flash_prefill = 1;
@@ -656,12 +657,21 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   o.nt = nt_small;
   o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
   int ao = -2;
-  if (M == 1 && e->fuse_attn_oproj && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
+  if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
     // single sequence, short cache: one launch for SDPA + o_proj (heads in parallel on the waves of each o_proj workgroup)
     AttnOprojArgs f{};
     f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
     f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h;
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
+    if (ao != -2) LCK(ao);
+  }
+  if (ao == -2 && M >= 2 && (e->fuse_attn_oproj & 2) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
+    // batched decode, short cache: per batch row the same fusion (attn_oproj_rows_kernel); planes epilogue like o_proj's
+    AttnOprojArgs f{};
+    f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
+    f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h; f.ldo = ldh;
+    if (planes) { f.oplanes = e->pl_h; f.oln = w.ln2; f.oss = e->pl_ss; f.oss_ld = PL_SS_LD; }
+    ao = launch_attn_oproj_rows(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, M, f);
     if (ao != -2) LCK(ao);
   }
   if (ao != -2) {
