@@ -28,6 +28,7 @@ struct AttnOprojArgs {
   const float* wscale;   // per-row scale (fp8 weights), nullable
   int N;
   float* out;            // residual stream [N], updated in place (batched form: [rows][ldo])
+  int beside_streamer;   // host-side: refuse (-2) when a workgroup of this launch does not fit beside a resident streamer wave
   // batched form (attn_oproj_rows_kernel, 2 <= rows <= 64): sequence = row; the updated residual row also leaves as
   // MFMA B-operand planes for the gate/up launch (x * oln in fragment order, 16 rows per group) + per-16-column sums of x^2
   int ldo;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(512) void attn_oproj_rows_kernel(AttnOprojArgs a) {
   }
 }
 #endif  // CSM_ATTN_OPROJ_KERNEL
-// returns -2 when the shape is not covered (head_dim not 64 / 128, n_q not 2 / 4 / 8, N % 32, cache longer than 32 positions)
+// returns -2 (caller runs the two-launch form) when the shape is not covered (head_dim not 64 / 128, n_q not 2 / 4 / 8, N % 32, cache longer than 32 positions)
 int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojArgs& a);
 // batched form: rows sequences (row = sequence); -2 when not covered (rows outside 2..64, N % 64, n_q not 2 / 4 / 8)
 int launch_attn_oproj_rows(hipStream_t st, int wdtype, int kvdtype, int rows, const AttnOprojArgs& a);

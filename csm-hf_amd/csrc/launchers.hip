@@ -161,6 +161,15 @@ static int launch_attn_oproj_t(hipStream_t st, const AttnOprojArgs& a) {
   const int K = a.n_q * a.hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * a.n_q / tpr;
   const dim3 grid(a.N / rows), block(64 * a.n_q);
   const size_t lds = ((size_t)2 * a.n_q * a.hd + (size_t)a.n_q * 32) * sizeof(float);
+  const void* fn = a.hd == 64 ? (const void*)attn_oproj_kernel<KT, WT, 64> : (const void*)attn_oproj_kernel<KT, WT, 128>;
+  if (a.beside_streamer) {
+    // the weight streamer keeps one 72-register wave on every SIMD: a workgroup of this launch (n_q / 4 waves per SIMD)
+    // must fit beside it, or the chain would stall until the streamer gives up (registers are allocated in blocks of 8)
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -2;
+    const int alloc = (fa.numRegs + 7) & ~7, per_simd = (a.n_q + 3) / 4;
+    if (per_simd * alloc + ((PF_STREAMER_VGPRS + 7) & ~7) > 512) return -2;
+  }
   if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 64>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 128>), grid, block, lds, st, a);
   return (int)hipGetLastError();
