@@ -464,6 +464,51 @@ def test_batched_attention_o_proj_option_keeps_parity():
     m._drop_engine()
 
 
+@pytest.mark.parametrize("wdtype", [torch.float32, torch.bfloat16])
+def test_other_model_shapes_vs_oracle(wdtype):
+    """The kernels are templated on head_dim / heads per kv-head / K chunks; the csm-1b and `tiny` shapes exercise one
+    point each.  A third shape -- backbone 8 q / 2 kv heads of 64, hidden 512; decoder 8 q / 4 kv heads of 64 (head_dim 64
+    in the fused attention + o_proj launch, 2 q-heads per kv-head), ffn 1024 -- against the oracle: greedy frames for one
+    sequence and for a left-padded batch of 3, prefill hidden state, the bf16-activation prefill mode."""
+    _ROPE = dict(rope_type="llama3", factor=32.0, high_freq_factor=4.0, low_freq_factor=1.0, original_max_position_embeddings=8192)
+    cfg = CSMConfig.tiny(backbone_config=dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+                                              num_key_value_heads=2, rope_scaling=dict(_ROPE)),
+                         decoder_config=dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+                                             num_key_value_heads=4, rope_scaling=dict(_ROPE)))
+    assert cfg.backbone_config.head_dim == 64 and cfg.decoder_config.head_dim == 64
+    sd = synth_state_dict(cfg, seed=2, std=0.05, dtype=wdtype, bf16_representable=wdtype != torch.float32)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    ids, mask = synth_context(cfg, 3, 4, 9, seed=8)
+    tr = {}
+    want1 = O.generate(sd32, cfg, ids[:1], mask[:1], max_new_frames=5, topk=1, stop_on_all_zeros=False, trace=tr)
+    tv = torch.topk(tr["logits"], 2, -1)[0]
+    assert float((tv[..., 0] - tv[..., 1]).min()) > 1e-4            # no near-tie in the oracle's stream: tokens must match
+    got1 = m.generate(ids[:1].to(DEV), mask[:1].to(DEV), max_new_frames=5, topk=1, stop_on_all_zeros=False).cpu()
+    assert torch.equal(got1, want1)
+    ids_p, mask_p = ids.clone(), mask.clone()
+    ids_p[2, :3] = 0
+    mask_p[2, :3] = 0
+    got3 = m.generate(ids_p.to(DEV), mask_p.to(DEV), max_new_frames=4, topk=1, stop_on_all_zeros=False).cpu()
+    for b in range(3):
+        cut = 3 if b == 2 else 0
+        w = O.generate(sd32, cfg, ids[b:b + 1, cut:], mask[b:b + 1, cut:], max_new_frames=4, topk=1, stop_on_all_zeros=False)
+        assert torch.equal(got3[b:b + 1], w), f"row {b}"
+    lh, lg, _ = O.forward(sd32, cfg, ids, mask)
+    o = m.forward(ids.to(DEV), mask.to(DEV), use_cache=True)
+    eh = m._engine.get_state()[0].cpu()
+    assert float((eh - lh).norm() / lh.norm()) < 1e-4
+    if wdtype != torch.float32:
+        m.prefill_precision = "bf16"
+        m.forward(ids.to(DEV), mask.to(DEV), use_cache=True)
+        eb = m._engine.get_state()[0].cpu()
+        m.prefill_precision = "exact"
+        assert 1e-6 < float((eb - lh).norm() / lh.norm()) < 3e-2
+    m._drop_engine()
+
+
 def _run_bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
