@@ -180,6 +180,8 @@ struct ApStage<float> {
     for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(vsrc + 4 * i);
   }
   __device__ __forceinline__ uint2 kword(int i) const { return make_uint2(ap_pack2(k[i][0], k[i][1]), ap_pack2(k[i][2], k[i][3])); }
+  __device__ __forceinline__ float kval(int i, int e) const { return k[i][e]; }   // exact mode: the fp32 value itself
+  __device__ __forceinline__ float vval(int d) const { return v[d >> 2][d & 3]; }   // V[key][16c + d]
   // bf16 bits of V[key][16c + 2q] (low half) and V[key][16c + 2q + 1] (high half)
   __device__ __forceinline__ uint32_t vpair(int q) const { return ap_pack2(v[q >> 1][(2 * q) & 3], v[q >> 1][(2 * q + 1) & 3]); }
 };
@@ -200,6 +202,8 @@ struct ApStage<bf16_t> {
   }
   __device__ __forceinline__ uint2 kword(int i) const { return k[i]; }
   __device__ __forceinline__ uint32_t vpair(int q) const { return v[q >> 2][q & 3]; }
+  __device__ __forceinline__ float kval(int, int) const { return 0.f; }   // (one-plane cache: never split)
+  __device__ __forceinline__ float vval(int) const { return 0.f; }
 };
 
 __device__ __forceinline__ float ap_max3(float a, float b, float c) {   // no NaN canonicalisation round trips
@@ -353,8 +357,219 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
     }
   }
 }
+
+// ---- exact mode on the bf16 matrix pipe ------------------------------------------------------------------------------
+// The fp32 flash kernel above pays 64 matrix clocks per 32x32x2 product; the bf16 pipe is 16 times faster per flop.  Here
+// every fp32 operand is split EXACTLY into three bf16 pieces by truncation (x = hi + mid + lo, 8 + 8 + 8 mantissa bits:
+// what the exact prefill GEMM does with its activations) and a product a.b is evaluated as the six piece products whose
+// weight is >= 2^-16 relative (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi -- small terms first; the three dropped terms
+// are below 2^-24, the fp32 rounding unit), each exact in the fp32 accumulator.  Scores, statistics and the output stay
+// fp32: the result carries fp32 summation-order error only, like the fp32-MFMA kernel, at 96 bf16 MFMAs (3 072 matrix
+// clocks) per 64-key tile and head instead of 128 fp32 MFMAs (8 192).  Q is split once, K / V while they are staged to
+// LDS (a bf16 cache is its own hi piece: one plane), P per tile in registers.  Same tiling, layouts and lazy rescale as
+// attn_prefill_bf16_kernel.
+__device__ __forceinline__ void ap_split3(const float* x, ap_bf16x8& hi, ap_bf16x8& mid, ap_bf16x8& lo) {   // 8 values
+  uint32_t* ph = reinterpret_cast<uint32_t*>(&hi);
+  uint32_t* pm = reinterpret_cast<uint32_t*>(&mid);
+  uint32_t* pl = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float v0 = x[2 * p], v1 = x[2 * p + 1];
+    const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+    const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(m0), s1 = r1 - __uint_as_float(m1);
+    ph[p] = (h0 >> 16) | h1;
+    pm[p] = (m0 >> 16) | m1;
+    pl[p] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+}
+// the three pieces of one value as bf16 bit patterns
+__device__ __forceinline__ void ap_split1(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const uint32_t hb = __float_as_uint(v) & 0xffff0000u;
+  const float r = v - __uint_as_float(hb);
+  const uint32_t mb = __float_as_uint(r) & 0xffff0000u;
+  const float t = r - __uint_as_float(mb);
+  h = hb >> 16; m = mb >> 16; l = __float_as_uint(t) >> 16;
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void attn_prefill_x3_kernel(PrefillAttnArgs a) {
+  constexpr int HD = 64, LDK = 72;
+  constexpr int NPK = sizeof(KT) == 4 ? 3 : 1;   // planes of K / V (a bf16 cache is exact in one)
+  extern __shared__ __attribute__((aligned(16))) bf16_t xs[];   // Ks[NPK][64 * LDK] | Vt[NPK][64 * LDK]
+  auto Ks = [&](int p) { return xs + (size_t)p * 64 * LDK; };
+  auto Vt = [&](int p) { return xs + (size_t)(NPK + p) * 64 * LDK; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = a.n_q / a.n_kv;
+  const int qt = gridDim.x - 1 - blockIdx.x;
+  const int j = blockIdx.y, b = blockIdx.z;
+  const int s0 = qt * 32;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool head_live = wave < G;
+  const int h = j * G + (head_live ? wave : 0);
+  const int kv_lo = a.kv_start ? a.kv_start[b] : 0;
+  const int s_last = min(a.S - 1, s0 + 31);
+  const int kmax = a.past + s_last;
+  const int s = s0 + li;
+  const bool row_live = s < a.S && head_live;
+  const int row_lo = kv_lo;
+  const unsigned row_span = row_live && a.past + s >= kv_lo ? (unsigned)(a.past + s - kv_lo) : 0u;
+  const bool row_any = row_live && a.past + s >= kv_lo;
+  const bool tile_full = s0 + 31 < a.S && G == 4;
+
+  ap_bf16x8 qf[3][4];   // three pieces of Q[row][16t + 8lh .. +7]
+  {
+    const float* qrow = a.q + ((size_t)b * a.S + (s < a.S ? s : a.S - 1)) * a.n_q * HD + (size_t)h * HD + 8 * lh;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = row_live ? qrow[16 * t + i] : 0.f;
+      ap_split3(x, qf[0][t], qf[1][t], qf[2][t]);
+    }
+  }
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+
+  f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);
+  float m_run = -INFINITY, l_run = 0.f;
+  constexpr float L2E = 1.4426950408889634f, SLACK = 8.f;
+
+  ApStage<KT> st;
+  int kt0 = kv_lo & ~63;
+  st.load(kc, vc, a.lmax, kt0, tid);
+  const int vkey = tid & 63;
+  const int voff = ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;   // in 32-bit words
+  const uint32_t vsel = (vkey & 1) ? 0x03020706u : 0x05040100u;
+  for (; kt0 <= kmax; kt0 += 64) {
+    // ---- registers -> LDS, split into pieces on the way ---------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int off = (idx & 63) * LDK + (idx >> 6) * 4;
+      if (NPK == 1) {
+        *reinterpret_cast<uint2*>(Ks(0) + off) = st.kword(i);
+      } else {
+        uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ap_split1(st.kval(i, e), hh[e], mm[e], ll[e]);
+        *reinterpret_cast<uint2*>(Ks(0) + off) = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
+        *reinterpret_cast<uint2*>(Ks(1) + off) = make_uint2(mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16));
+        *reinterpret_cast<uint2*>(Ks(2) + off) = make_uint2(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t mine[3];
+      if (NPK == 1) {
+        mine[0] = st.vpair(q);
+      } else {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        ap_split1(st.vval(2 * q), a0, a1, a2);
+        ap_split1(st.vval(2 * q + 1), b0, b1, b2);
+        mine[0] = a0 | (b0 << 16); mine[1] = a1 | (b1 << 16); mine[2] = a2 | (b2 << 16);
+      }
+#pragma unroll
+      for (int p = 0; p < NPK; ++p) {
+        const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[p], 0xB1, 0xf, 0xf, true);   // lane ^ 1
+        reinterpret_cast<uint32_t*>(Vt(p))[voff + q * LDK] = __builtin_amdgcn_perm(theirs, mine[p], vsel);
+      }
+    }
+    __syncthreads();
+    if (kt0 + 64 <= kmax) st.load(kc, vc, a.lmax, kt0 + 64, tid);
+    // ---- S^T = K Q^T: piece products, small terms first ---------------------------------------------------------
+    f32x16 sc0 = (f32x16)(0.f), sc1 = (f32x16)(0.f);
+    // (K piece, Q piece): with a one-plane cache only K's hi piece exists
+    constexpr int NT = NPK == 3 ? 6 : 3;
+    constexpr int KP[6] = {2, 0, 1, 1, 0, 0}, QP[6] = {0, 2, 1, 0, 1, 0};   // lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+    constexpr int QP1[3] = {2, 1, 0};                                       // hi_K . (lo, mid, hi)_Q
+#pragma unroll
+    for (int term = 0; term < NT; ++term) {
+      const int kp = NPK == 3 ? KP[term] : 0, qp = NPK == 3 ? QP[term] : QP1[term];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const ap_bf16x8 k0 = *reinterpret_cast<const ap_bf16x8*>(Ks(kp) + li * LDK + 16 * t + 8 * lh);
+        const ap_bf16x8 k1 = *reinterpret_cast<const ap_bf16x8*>(Ks(kp) + (32 + li) * LDK + 16 * t + 8 * lh);
+        sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[qp][t], sc0, 0, 0, 0);
+        sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[qp][t], sc1, 0, 0, 0);
+      }
+    }
+    const bool interior = tile_full && kt0 >= kv_lo && kt0 + 63 <= a.past + s0;
+    if (!interior) {
+      const int base = kt0 + 4 * lh - row_lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = base + (r & 3) + 8 * (r >> 2);
+        sc0[r] = (row_any && (unsigned)rel <= row_span) ? sc0[r] : -INFINITY;
+        sc1[r] = (row_any && (unsigned)(rel + 32) <= row_span) ? sc1[r] : -INFINITY;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = ap_max3(mx, sc0[r], sc1[r]);
+    mx = xor32_max(mx) * L2E;
+    const bool move = mx > m_run + SLACK;
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {
+      const float m_new = move ? mx : m_run;
+      const float alpha = (move && m_run > -INFINITY) ? exp2f(m_run - m_new) : 1.f;
+      m_run = m_new;
+      l_run *= alpha;
+      o0 *= alpha;
+      o1 *= alpha;
+    }
+    const float neg_m = m_run > -INFINITY ? -m_run : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc0[r] = exp2f(fmaf(sc0[r], L2E, neg_m));   // the library exp2 (the fp32 kernel's accuracy class), not the raw instruction
+      sc1[r] = exp2f(fmaf(sc1[r], L2E, neg_m));
+      sum += sc0[r] + sc1[r];
+    }
+    l_run += xor32_sum(sum);
+    // ---- O^T += V^T P^T: piece products, small terms first ---------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x16& sc = (u < 2) ? sc0 : sc1;
+      const int r0 = 8 * (u & 1);
+      float pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pv[i] = sc[r0 + i];
+      ap_bf16x8 pp[3];
+      ap_split3(pv, pp[0], pp[1], pp[2]);
+#pragma unroll
+      for (int term = 0; term < NT; ++term) {
+        const int vp = NPK == 3 ? KP[term] : 0, ppi = NPK == 3 ? QP[term] : QP1[term];
+        const ap_bf16x8 v0 = *reinterpret_cast<const ap_bf16x8*>(Vt(vp) + li * LDK + (2 * u + lh) * 8);
+        const ap_bf16x8 v1 = *reinterpret_cast<const ap_bf16x8*>(Vt(vp) + (32 + li) * LDK + (2 * u + lh) * 8);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pp[ppi], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pp[ppi], o1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!row_live) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  float* dst = a.out + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int d = 8 * r4 + 4 * lh;
+    f32x4 v0, v1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v0[i] = o0[4 * r4 + i] * inv; v1[i] = o1[4 * r4 + i] * inv; }
+    if (a.oplanes) {
+      bf16_t* pd = a.oplanes + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
+      store_rowplanes4(pd + d, a.plane_stride, v0);
+      store_rowplanes4(pd + 32 + d, a.plane_stride, v1);
+    } else {
+      *reinterpret_cast<f32x4*>(dst + d) = v0;
+      *reinterpret_cast<f32x4*>(dst + 32 + d) = v1;
+    }
+  }
+}
 #endif  // CSM_ATTN_PREFILL_KERNELS
 
 // returns -2 when the shape is not covered (head_dim != 64 or more than 4 q-heads per kv-head)
 // bf16_math: Q / K / V / P rounded to bf16 on the bf16 matrix pipe (prefill_precision = bf16) instead of exact fp32
+// bf16_math: 1 = Q / K / V / P rounded to bf16 (prefill_precision = bf16); 2 = exact, three-piece products on the bf16 pipe
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);

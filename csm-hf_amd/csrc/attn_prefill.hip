@@ -7,6 +7,12 @@
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math) {
   if (hd != 64 || a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 4 || a.S < 1) return -2;
   const dim3 grid((a.S + 31) / 32, a.n_kv, B);
+  if (bf16_math == 2) {   // exact on the bf16 pipe: K / V as three pieces in LDS (fp32 cache) or one (bf16 cache)
+    const size_t lds = (size_t)(kvdtype == 1 ? 2 : 6) * 64 * 72 * sizeof(bf16_t);
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_x3_kernel<bf16_t>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((attn_prefill_x3_kernel<float>), grid, dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+  }
   if (bf16_math) {
     if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);

@@ -138,6 +138,7 @@ struct csm_engine {
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
+  int prefill_x3_attn = 1;     // exact mode: context attention as three-piece products on the bf16 matrix pipe (0 = fp32 MFMA)
   int prefill_bf16_attn = 1;   // with prefill_bf16: the context attention on the bf16 matrix pipe too (0 = keep the fp32-MFMA flash kernel)
   // host mirrors
   int B = 0;
@@ -500,6 +501,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
+  else if (!strcmp(name, "prefill_x3_attn")) e->prefill_x3_attn = value;
   else if (!strcmp(name, "gemm_wide")) e->gemm_wide = value;
   else if (!strcmp(name, "gemm_wide_depth")) e->gemm_wide_depth = value;
   else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
@@ -974,7 +976,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
     fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
-    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, one && e->prefill_bf16_attn) : -2;
+    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, (one && e->prefill_bf16_attn) ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     bool att_pl = pl && fr != -2;
     if (fr == -2) {   // shapes the matrix-core kernel does not cover: one workgroup per (row, kv-head)
       AttnArgs t{};
