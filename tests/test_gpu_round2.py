@@ -400,6 +400,16 @@ def test_training_forward_loss_vs_reference(name):
         o4 = m.forward(ids3.to(DEV), mask3.to(DEV), labels=lab3.to(DEV), return_dict=True)
         for got, w in zip((o4.loss, o4.backbone_loss, o4.decoder_loss), want[:3]):
             assert abs(float(got) - float(w)) < 2e-4 * abs(float(w)), (float(got), float(w))
+        # a left-padded batch (the processor pads on the left, processor.py:340-360): pad frames are masked, their labels ignored
+        ids5, mask5 = synth_context(cfg, 2, 3, 12, seed=78)
+        lab5 = torch.full_like(ids5, -100)
+        lab5[:, 3:, :32] = ids5[:, 3:, :32]
+        ids5[1, :4], mask5[1, :4], lab5[1, :4] = 0, 0, -100
+        lab5[1, 4:7] = -100                                     # the row's own text frames now sit at 4..6
+        want5 = O.forward_loss(sd32, cfg, ids5, mask5, lab5)
+        o5 = m.forward(ids5.to(DEV), mask5.to(DEV), labels=lab5.to(DEV), return_dict=True)
+        for got, w in zip((o5.loss, o5.backbone_loss, o5.decoder_loss), want5[:3]):
+            assert abs(float(got) - float(w)) < 2e-4 * abs(float(w)), (float(got), float(w))
     m._drop_engine()
 
 
