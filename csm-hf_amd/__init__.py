@@ -5,5 +5,6 @@ from .configuration_csm import CSMConfig, LlamaSubConfig  # noqa: F401
 from .modeling_csm import CSMModel, CSMOutput, CSMKVCache, sample_topk  # noqa: F401
 from .processor import CSMProcessor  # noqa: F401
 from .serving import ContinuousBatcher  # noqa: F401
+from .mimi import MimiDecoder, MimiDecodeConfig  # noqa: F401
 
-__all__ = ["CSMConfig", "LlamaSubConfig", "CSMModel", "CSMOutput", "CSMKVCache", "sample_topk", "CSMProcessor", "ContinuousBatcher"]
+__all__ = ["CSMConfig", "LlamaSubConfig", "CSMModel", "CSMOutput", "CSMKVCache", "sample_topk", "CSMProcessor", "ContinuousBatcher", "MimiDecoder", "MimiDecodeConfig"]

@@ -56,6 +56,11 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// other translation units of the library (mimi.hip) report through the same thread-local message
+int csm_set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
 #define HIPCK(x)                                                                              \
   do {                                                                                        \
     hipError_t _e = (x);                                                                      \

@@ -1,0 +1,150 @@
+// Mimi decode: element-wise / gather / attention kernels around the exact-fp32 MFMA GEMM
+// (gemm.h: gemm_f32mfma_kernel), which carries every convolution and linear of the codec's decode path.
+// Replaces `audio_tokenizer.decode(codes)` of the reference's call site (/root/reference/README.md:114-118; codec =
+// third-party moshi==0.2.2, architecture as in transformers 5.15 models/mimi/modeling_mimi.py, cited per kernel).
+// Activations are channels-last ([time][channels], fp32): a causal convolution's k shifted input rows are then ONE contiguous
+// operand row of K = k * C_in, so conv1d = GEMM with lda = C_in < K over a buffer that starts with k - 1 zero rows, and a
+// stride-r transposed convolution (kernel 2r) is one GEMM with K = 2 C_in and N = r * C_out whose output row q holds the r
+// output positions r q .. r q + r - 1.
+#pragma once
+#include "common.h"
+
+#ifdef CSM_MIMI_KERNELS
+// split RVQ decode (modeling_mimi.py:1004-1007, 1070-1082, 1128-1139): out[t][0:D] = sum of the semantic codebooks' rows,
+// out[t][D:2D] = sum of the acoustic codebooks' rows (the two 1x1 output projections follow as one GEMM with K = 2 D)
+__global__ __launch_bounds__(256) void mimi_rvq_gather_kernel(const int64_t* codes, const float* embed, int n_q, int n_sem, int csize,
+                                                              int D, int T, float* out) {
+  const int t = blockIdx.x;
+  for (int d = threadIdx.x; d < 2 * D; d += 256) {
+    const int acoustic = d >= D, dd = acoustic ? d - D : d;
+    float s = 0.f;
+    for (int k = acoustic ? n_sem : 0; k < (acoustic ? n_q : n_sem); ++k) {
+      const int64_t c = codes[(size_t)k * T + t];
+      s += embed[((size_t)k * csize + c) * D + dd];
+    }
+    out[(size_t)t * 2 * D + d] = s;
+  }
+}
+
+// depthwise transposed convolution, kernel 2 s, stride s, causal trim (modeling_mimi.py:399-405, MimiModel.upsample):
+// out[s q + p][c] = x[q][c] w[c][p] + x[q - 1][c] w[c][p + s]
+__global__ __launch_bounds__(256) void mimi_upsample_kernel(const float* x, const float* w, int L, int C, int s, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)L * s * C) return;
+  const int c = (int)(i % C);
+  const size_t lo = i / C;
+  const int q = (int)(lo / s), p = (int)(lo % s);
+  float v = x[(size_t)q * C + c] * w[(size_t)c * 2 * s + p];
+  if (q > 0) v += x[(size_t)(q - 1) * C + c] * w[(size_t)c * 2 * s + p + s];
+  out[i] = v;
+}
+
+// nn.LayerNorm with bias (modeling_mimi.py:737-738): one workgroup per row
+__global__ __launch_bounds__(256) void mimi_layernorm_kernel(const float* x, const float* w, const float* b, int C, float eps, float* out) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * C;
+  float s = 0.f;
+  for (int i = tid; i < C; i += 256) s += xr[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
+  __syncthreads();
+  float v = 0.f;
+  for (int i = tid; i < C; i += 256) { const float d = xr[i] - mean; v += d * d; }
+  v = wave_sum(v);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)C + eps);
+  for (int i = tid; i < C; i += 256) out[(size_t)row * C + i] = (xr[i] - mean) * rstd * w[i] + b[i];
+}
+
+// rotary embedding, default rope, rotate_half convention (modeling_mimi.py:524-600), in place on the q and k parts of a
+// [L][3 A] projection buffer; position = row
+__global__ __launch_bounds__(256) void mimi_rope_kernel(float* qkv, int L, int heads, int hd, float theta) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int half = hd / 2, A = heads * hd;
+  if (i >= (size_t)L * 2 * heads * half) return;
+  const int f = (int)(i % half);
+  const size_t r = i / half;
+  const int h = (int)(r % (2 * heads));      // q heads, then k heads
+  const int pos = (int)(r / (2 * heads));
+  float* p = qkv + (size_t)pos * 3 * A + (size_t)h * hd;
+  const float ang = (float)pos * powf(theta, -2.f * (float)f / (float)hd);
+  const float c = cosf(ang), s = sinf(ang);
+  const float a = p[f], b = p[f + half];
+  p[f] = a * c - b * s;
+  p[f + half] = b * c + a * s;
+}
+
+// causal sliding-window attention (modeling_mimi.py:687-726, create_sliding_window_causal_mask): query i sees keys
+// max(0, i - window + 1) .. i.  grid = (L, heads), 64 threads (head_dim <= 64 * 2), fp32 softmax.
+__global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, int L, int heads, int hd, int window, float* out) {
+  extern __shared__ float sc[];   // [window]
+  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int A = heads * hd;
+  const int j0 = max(0, i - window + 1), n = i - j0 + 1;
+  const float* q = qkv + (size_t)i * 3 * A + (size_t)h * hd;
+  const float scale = rsqrtf((float)hd);
+  float mx = -INFINITY;
+  for (int j = tid; j < n; j += 64) {
+    const float* k = qkv + (size_t)(j0 + j) * 3 * A + A + (size_t)h * hd;
+    float s = 0.f;
+    for (int d = 0; d < hd; ++d) s = fmaf(q[d], k[d], s);
+    s *= scale;
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = tid; j < n; j += 64) { const float p = expf(sc[j] - mx); sc[j] = p; se += p; }
+  se = wave_sum(se);
+  __syncthreads();
+  const float inv = 1.f / se;
+  for (int d = tid; d < hd; d += 64) {
+    float o = 0.f;
+    for (int j = 0; j < n; ++j) o = fmaf(sc[j], qkv[(size_t)(j0 + j) * 3 * A + 2 * A + (size_t)h * hd + d], o);
+    out[(size_t)i * A + (size_t)h * hd + d] = o * inv;
+  }
+}
+
+// x[r][c] += scale[c] * y[r][c]   (MimiLayerScale + residual, modeling_mimi.py:506-507, 765, 771)
+__global__ __launch_bounds__(256) void mimi_scale_add_kernel(float* x, const float* y, const float* scale, size_t n, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] += scale[i % C] * y[i];
+}
+// exact (erf) GELU in place (ACT2FN["gelu"], modeling_mimi.py:606)
+__global__ __launch_bounds__(256) void mimi_gelu_kernel(float* x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float v = x[i]; x[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+}
+// out[r][c] = act(src[r * lds + c] + bias[c % nb] (+ res[r][c])), c < C: takes a GEMM result with padded columns to its
+// exact-width channels-last buffer; act: 0 none, 1 ELU (nn.ELU, alpha 1)
+__global__ __launch_bounds__(256) void mimi_bias_act_kernel(const float* src, int lds, const float* bias, int nb, const float* res, int C,
+                                                            size_t rows, int act, float* out, int ldo) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const size_t r = i / C;
+  const int c = (int)(i % C);
+  float v = src[r * lds + c] + (bias ? bias[c % nb] : 0.f);
+  if (res) v += res[r * C + c];
+  if (act == 1) v = v > 0.f ? v : expm1f(v);
+  out[r * ldo + c] = v;
+}
+// dst[r][c] = ELU(src[r][c]) (or a plain copy): the padded input buffer of the next convolution
+__global__ __launch_bounds__(256) void mimi_elu_copy_kernel(const float* src, float* dst, size_t n, int elu) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float v = src[i]; dst[i] = (elu && v <= 0.f) ? expm1f(v) : v; }
+}
+// last convolution, one output channel (modeling_mimi.py:955): audio[l] = b + sum_j sum_c w[j * C + c] * xa[(l + j) * C + c]
+// over the ELU'd, front-padded input xa (k - 1 zero rows first)
+__global__ __launch_bounds__(256) void mimi_last_conv_kernel(const float* xa, const float* w, const float* b, int C, int k, size_t L, float* audio) {
+  const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (l >= L) return;
+  const float* p = xa + l * C;
+  float s = b[0];
+  for (int i = 0; i < k * C; ++i) s = fmaf(w[i], p[i], s);
+  audio[l] = s;
+}
+#endif  // CSM_MIMI_KERNELS

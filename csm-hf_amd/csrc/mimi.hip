@@ -1,0 +1,201 @@
+// Mimi decode behind the C ABI (include/csm_hip.h: csm_mimi_*): the orchestration of one decode call.
+#define CSM_MIMI_KERNELS 1
+#define CSM_ARGS_ONLY 1   // gemm.h: argument structs and launch_gemm only (the kernels live in launchers.hip)
+#include "../../include/csm_hip.h"
+#include "gemm.h"
+#include "mimi.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+int csm_set_error(int code, const char* msg);   // engine.hip: stores the message csm_last_error() returns
+
+static int mfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return csm_set_error(code, buf);
+}
+#define MHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return mfail((int)e_, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#define MLCK(x) do { int r_ = (x); if (r_) return r_ < 0 ? mfail(CSM_ERR_ARG, "launch refused (%d): %s", r_, #x) : mfail(r_, "%s: %s", #x, hipGetErrorString((hipError_t)r_)); } while (0)
+
+struct csm_mimi {
+  csm_mimi_config_t c{};
+  csm_mimi_weights_t w{};
+  bool bound = false;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  // scratch for ONE sequence (sequences of a batch are decoded one after the other)
+  float *q2 = nullptr, *e0 = nullptr, *x = nullptr, *hn = nullptr, *qkv = nullptr, *ao = nullptr, *tmp = nullptr, *ff = nullptr;
+  float *bufa = nullptr, *bufb = nullptr, *pad = nullptr, *scr = nullptr;
+  size_t big = 0;   // floats in each of bufa / bufb / pad / scr
+};
+constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
+
+static inline int pad128(int n) { return (n + 127) & ~127; }
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+template <typename T>
+static int malloc_f(csm_mimi* m, T** p, size_t n) {
+  void* q = nullptr;
+  if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) return mfail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) failed", n * sizeof(T));
+  m->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
+  if (!cfg || !out) return mfail(CSM_ERR_ARG, "null argument");
+  if (cfg->abi_version != CSM_ABI_VERSION) return mfail(CSM_ERR_ARG, "ABI version mismatch");
+  const csm_mimi_config_t& c = *cfg;
+  if (c.layers > CSM_MIMI_MAX_LAYERS || c.n_ratios > CSM_MIMI_MAX_RATIOS || c.n_ratios < 1) return mfail(CSM_ERR_ARG, "too many layers / ratios");
+  if (c.kernel_size - 1 > PADR || c.res_kernel_size - 1 > PADR || c.last_kernel_size - 1 > PADR) return mfail(CSM_ERR_ARG, "kernel sizes above %d", PADR + 1);
+  const int A = c.heads * c.head_dim;
+  // GEMM shape rules (gemm.h: N % 128 == 0 is met by padding the weights' rows, K % 32 == 0 must hold as is)
+  int ch = c.num_filters << c.n_ratios;
+  bool ok = c.hidden % 128 == 0 && (2 * c.codebook_dim) % 32 == 0 && (3 * A) % 128 == 0 && A % 32 == 0 && c.ffn % 128 == 0 &&
+            (c.kernel_size * c.hidden) % 32 == 0 && ch % 128 == 0 && c.head_dim % 2 == 0 && c.window >= 1;
+  for (int i = 0; i < c.n_ratios && ok; ++i) {
+    const int co = ch / 2, hid = co / c.compress;
+    ok = (2 * ch) % 32 == 0 && (c.ratios[i] * co) % 128 == 0 && (c.res_kernel_size * co) % 32 == 0 && hid % 32 == 0 && co % 4 == 0;
+    ch = co;
+  }
+  if (!ok) return mfail(CSM_ERR_ARG, "shape outside the GEMM path's rules (N %% 128, K %% 32)");
+  csm_mimi* m = new csm_mimi();
+  m->c = c;
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return mfail(CSM_ERR_STATE, "stream creation failed"); }
+  const size_t T = (size_t)c.max_frames, L1 = T * c.up_stride;
+  size_t Lf = L1;
+  size_t big = (L1 + PADR) * (size_t)std::max(c.hidden, c.num_filters << c.n_ratios);
+  ch = c.num_filters << c.n_ratios;
+  for (int i = 0; i < c.n_ratios; ++i) {
+    const int co = ch / 2, hid = co / c.compress;
+    big = std::max(big, (Lf + PADR) * (size_t)ch);                       // padded input of the transposed conv
+    big = std::max(big, Lf * (size_t)(c.ratios[i] * co));                // its GEMM result
+    Lf *= c.ratios[i];
+    big = std::max(big, (Lf + PADR) * (size_t)co);
+    big = std::max(big, Lf * (size_t)std::max(pad128(hid), pad128(co)));
+    ch = co;
+  }
+  m->big = big;
+  int r = 0;
+  if ((r = malloc_f(m, &m->q2, T * 2 * c.codebook_dim)) || (r = malloc_f(m, &m->e0, T * c.hidden)) || (r = malloc_f(m, &m->x, L1 * c.hidden)) ||
+      (r = malloc_f(m, &m->hn, L1 * c.hidden)) || (r = malloc_f(m, &m->qkv, L1 * 3 * A)) || (r = malloc_f(m, &m->ao, L1 * A)) ||
+      (r = malloc_f(m, &m->tmp, L1 * c.hidden)) || (r = malloc_f(m, &m->ff, L1 * c.ffn)) || (r = malloc_f(m, &m->bufa, big)) ||
+      (r = malloc_f(m, &m->bufb, big)) || (r = malloc_f(m, &m->pad, big)) || (r = malloc_f(m, &m->scr, big))) {
+    for (void* p : m->allocs) hipFree(p);
+    hipStreamDestroy(m->stream);
+    delete m;
+    return r;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int csm_mimi_destroy(csm_mimi_t* m) {
+  if (!m) return 0;
+  hipStreamSynchronize(m->stream);
+  for (void* p : m->allocs) hipFree(p);
+  hipStreamDestroy(m->stream);
+  delete m;
+  return 0;
+}
+
+extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w) {
+  if (!m || !w) return mfail(CSM_ERR_ARG, "null argument");
+  if (!w->embed || !w->out_proj || !w->upsample || !w->conv0_w || !w->conv0_b || !w->last_w || !w->last_b) return mfail(CSM_ERR_ARG, "null weight");
+  m->w = *w;
+  m->bound = true;
+  return 0;
+}
+
+// C[R][N] = A (rows of K floats, lda apart) @ W[N][K]^T, fp32 weights, exact-fp32 MFMA
+static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+  return launch_gemm(m->stream, CSM_DTYPE_F32, GEPI_STORE, g);
+}
+
+// causal conv1d, stride 1, dilation 1 (MimiConv1d, modeling_mimi.py:327-347): xin = exact-width channels-last input
+// [L][Cin]; elu: apply nn.ELU to the input first; result (+ bias, + res, act) to out [L][Cout] (row stride ldo)
+static int conv1d(csm_mimi* m, const float* xin, size_t L, int Cin, int k, int elu, const float* Wp, int Cout, const float* bias,
+                  const float* res, int act, float* out, int ldo) {
+  hipStream_t st = m->stream;
+  MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * Cin * sizeof(float), st));
+  hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * Cin)), dim3(256), 0, st, xin, m->pad + (size_t)PADR * Cin, L * Cin, elu);
+  const int Np = pad128(Cout);
+  MLCK(gemm(m, m->pad + (size_t)(PADR - (k - 1)) * Cin, Cin, Wp, Np, k * Cin, L, m->scr, Np));
+  hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * Cout)), dim3(256), 0, st, m->scr, Np, bias, Cout, res, Cout, L, act, out, ldo);
+  const hipError_t le = hipGetLastError();
+  return le != hipSuccess ? mfail((int)le, "conv1d launch failed: %s", hipGetErrorString(le)) : 0;
+}
+
+extern "C" int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* audio) {
+  if (!m || !m->bound || !codes || !audio) return mfail(CSM_ERR_ARG, "null argument / weights not bound");
+  const csm_mimi_config_t& c = m->c;
+  if (B < 1 || T < 1 || T > c.max_frames) return mfail(CSM_ERR_CAPACITY, "T = %d outside 1..max_frames %d", T, c.max_frames);
+  hipStream_t st = m->stream;
+  const int H = c.hidden, D = c.codebook_dim, A = c.heads * c.head_dim, F = c.ffn;
+  size_t spf = (size_t)c.up_stride;
+  for (int i = 0; i < c.n_ratios; ++i) spf *= c.ratios[i];
+  for (int b = 0; b < B; ++b) {
+    const int64_t* cb = codes + (size_t)b * c.n_q * T;
+    // ---- split RVQ decode + the two 1x1 output projections (one GEMM, K = 2 D) ----
+    hipLaunchKernelGGL(mimi_rvq_gather_kernel, dim3(T), dim3(256), 0, st, cb, m->w.embed, c.n_q, c.n_sem, c.codebook_size, D, T, m->q2);
+    MLCK(gemm(m, m->q2, 2 * D, m->w.out_proj, H, 2 * D, T, m->e0, H));
+    // ---- upsample to the transformer's rate ----
+    const size_t L1 = (size_t)T * c.up_stride;
+    hipLaunchKernelGGL(mimi_upsample_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->e0, m->w.upsample, T, H, c.up_stride, m->x);
+    // ---- transformer ----
+    for (int l = 0; l < c.layers; ++l) {
+      hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln1_w[l], m->w.ln1_b[l], H, c.norm_eps, m->hn);
+      MLCK(gemm(m, m->hn, H, m->w.wqkv[l], 3 * A, H, L1, m->qkv, 3 * A));
+      hipLaunchKernelGGL(mimi_rope_kernel, dim3(nblk(L1 * 2 * c.heads * (c.head_dim / 2))), dim3(256), 0, st, m->qkv, (int)L1, c.heads, c.head_dim, c.rope_theta);
+      hipLaunchKernelGGL(mimi_attn_kernel, dim3((unsigned)L1, c.heads), dim3(64), (size_t)c.window * sizeof(float), st, m->qkv, (int)L1, c.heads,
+                         c.head_dim, c.window, m->ao);
+      MLCK(gemm(m, m->ao, A, m->w.wo[l], H, A, L1, m->tmp, H));
+      hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls1[l], L1 * H, H);
+      hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln2_w[l], m->w.ln2_b[l], H, c.norm_eps, m->hn);
+      MLCK(gemm(m, m->hn, H, m->w.w1[l], F, H, L1, m->ff, F));
+      hipLaunchKernelGGL(mimi_gelu_kernel, dim3(nblk(L1 * F)), dim3(256), 0, st, m->ff, L1 * F);
+      MLCK(gemm(m, m->ff, F, m->w.w2[l], H, F, L1, m->tmp, H));
+      hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls2[l], L1 * H, H);
+    }
+    // ---- SEANet decoder ----
+    int ch = c.num_filters << c.n_ratios;
+    size_t L = L1;
+    float *cur = m->bufa, *nxt = m->bufb;
+    if (int r = conv1d(m, m->x, L, H, c.kernel_size, 0, m->w.conv0_w, ch, m->w.conv0_b, nullptr, 0, cur, ch)) return r;
+    for (int i = 0; i < c.n_ratios; ++i) {
+      const int rr = c.ratios[i], co = ch / 2, hid = co / c.compress;
+      // ELU -> transposed conv (kernel 2 r, stride r, causal trim): one GEMM, K = 2 C_in, N = r C_out, output row q = positions r q ..
+      MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * ch * sizeof(float), st));
+      hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cur, m->pad + (size_t)PADR * ch, L * ch, 1);
+      MLCK(gemm(m, m->pad + (size_t)(PADR - 1) * ch, ch, m->w.up_w[i], rr * co, 2 * ch, L, m->scr, rr * co));
+      hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * rr * co)), dim3(256), 0, st, m->scr, rr * co, m->w.up_b[i], co, nullptr, rr * co, L, 0, nxt, rr * co);
+      L *= rr;
+      std::swap(cur, nxt);   // cur = [L][co]
+      // residual block: x + conv1(ELU(conv3(ELU(x))))
+      float* hb = nxt;       // [L][hid]
+      if (int r = conv1d(m, cur, L, co, c.res_kernel_size, 1, m->w.res1_w[i], hid, m->w.res1_b[i], nullptr, 1, hb, hid)) return r;
+      {
+        const int Np = pad128(co);
+        MLCK(gemm(m, hb, hid, m->w.res2_w[i], Np, hid, L, m->scr, Np));
+        hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * co)), dim3(256), 0, st, m->scr, Np, m->w.res2_b[i], co, cur, co, L, 0, cur, co);
+      }
+      ch = co;
+    }
+    // ---- ELU, last convolution to one channel ----
+    MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * ch * sizeof(float), st));
+    hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cur, m->pad + (size_t)PADR * ch, L * ch, 1);
+    hipLaunchKernelGGL(mimi_last_conv_kernel, dim3(nblk(L)), dim3(256), 0, st, m->pad + (size_t)(PADR - (c.last_kernel_size - 1)) * ch, m->w.last_w,
+                       m->w.last_b, ch, c.last_kernel_size, L, audio + (size_t)b * T * spf);
+    MHIP(hipGetLastError());
+  }
+  MHIP(hipStreamSynchronize(st));
+  return 0;
+}

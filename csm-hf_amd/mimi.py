@@ -1,0 +1,292 @@
+"""Mimi decode on MI355X: the step right after the generation path.
+
+The reference turns generated codes into audio with `audio_tokenizer.decode(gen_frames.permute(0, 2, 1))`
+(/root/reference/README.md:114-118), where `audio_tokenizer` is the Mimi codec of the third-party package `moshi==0.2.2`
+(/root/reference/requirements.txt:6, loaded at README.md:58-60 / train.py:363-365).  That package is not in the image;
+its published architecture is also implemented by `transformers.models.mimi.modeling_mimi.MimiModel` (pinned here:
+transformers 5.15), whose `decode()` is what this module mirrors (API, checkpoint key layout `kyutai/mimi`) and what the
+parity fixtures are generated with (`oracle/make_golden_mimi.py`).
+
+Decode path (modeling_mimi.py:1388-1406): split residual VQ decode (1 semantic + 31 acoustic codebooks, 256-d, 1x1 output
+projections to 512) -> depthwise transposed conv upsample 12.5 -> 25 Hz -> 8-layer transformer (LayerNorm, RoPE, causal
+sliding window 250, GELU MLP, layer scale) -> SEANet decoder (causal conv k=7, four [ELU, transposed conv x8 / x6 / x5 / x4,
+residual block], ELU, conv k=3) -> 24 kHz waveform, 1920 samples per frame.
+
+Everything runs in fp32 on the device through `libcsm_hip.so` (`csm_mimi_*`, include/csm_hip.h): every convolution and linear
+is one launch of the exact-fp32 MFMA GEMM (activations are kept channels-last, so a causal convolution's k shifted rows are
+one contiguous K = k * C_in operand row, and a stride-r transposed convolution is one GEMM with N = r * C_out); the small
+element-wise steps have their own kernels (csrc/mimi.h).  torch is used to repack the weights once and to hold buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class MimiDecodeConfig:
+    """The fields of transformers.MimiConfig the decode path reads (defaults = kyutai/mimi)."""
+    num_quantizers: int = 32
+    num_semantic_quantizers: int = 1
+    codebook_size: int = 2048
+    codebook_dim: int = 256
+    hidden_size: int = 512
+    num_hidden_layers: int = 8
+    num_attention_heads: int = 8
+    head_dim: int = 64
+    intermediate_size: int = 2048
+    sliding_window: int = 250
+    rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    upsampling_ratios: List[int] = field(default_factory=lambda: [8, 6, 5, 4])
+    num_filters: int = 64
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    compress: int = 2
+    upsample_stride: int = 2          # encodec frame rate 25 Hz / codec frame rate 12.5 Hz
+
+    @property
+    def samples_per_frame(self) -> int:
+        return self.upsample_stride * math.prod(self.upsampling_ratios)
+
+    @classmethod
+    def tiny(cls) -> "MimiDecodeConfig":
+        """Small shape for unit tests: same structure, GEMM-friendly sizes (multiples of 32 / 128)."""
+        return cls(num_quantizers=4, codebook_size=64, codebook_dim=32, hidden_size=128, num_hidden_layers=2,
+                   num_attention_heads=2, head_dim=64, intermediate_size=256, sliding_window=6,
+                   upsampling_ratios=[4, 2], num_filters=64)
+
+
+def mimi_state_dict_spec(cfg: MimiDecodeConfig):
+    """(key, shape, kind) of every tensor the decode path reads, in the `kyutai/mimi` (transformers) key layout."""
+    H, D = cfg.hidden_size, cfg.codebook_dim
+    for name, n in (("semantic", cfg.num_semantic_quantizers), ("acoustic", cfg.num_quantizers - cfg.num_semantic_quantizers)):
+        p = f"quantizer.{name}_residual_vector_quantizer"
+        for i in range(n):
+            yield f"{p}.layers.{i}.codebook.embed_sum", (cfg.codebook_size, D), "embed"
+            yield f"{p}.layers.{i}.codebook.cluster_usage", (cfg.codebook_size,), "usage"
+        yield f"{p}.output_proj.weight", (H, D, 1), "conv"
+    yield "upsample.conv.weight", (H, 1, 2 * cfg.upsample_stride), "conv"
+    A = cfg.num_attention_heads * cfg.head_dim
+    for l in range(cfg.num_hidden_layers):
+        p = f"decoder_transformer.layers.{l}"
+        for n_, shp in (("self_attn.q_proj", (A, H)), ("self_attn.k_proj", (A, H)), ("self_attn.v_proj", (A, H)),
+                        ("self_attn.o_proj", (H, A)), ("mlp.fc1", (cfg.intermediate_size, H)), ("mlp.fc2", (H, cfg.intermediate_size))):
+            yield f"{p}.{n_}.weight", shp, "linear"
+        for n_ in ("input_layernorm", "post_attention_layernorm"):
+            yield f"{p}.{n_}.weight", (H,), "norm"
+            yield f"{p}.{n_}.bias", (H,), "bias"
+        yield f"{p}.self_attn_layer_scale.scale", (H,), "scale"
+        yield f"{p}.mlp_layer_scale.scale", (H,), "scale"
+    ch = cfg.num_filters * 2 ** len(cfg.upsampling_ratios)
+    yield "decoder.layers.0.conv.weight", (ch, H, cfg.kernel_size), "conv"
+    yield "decoder.layers.0.conv.bias", (ch,), "bias"
+    idx = 1
+    for r in cfg.upsampling_ratios:
+        yield f"decoder.layers.{idx + 1}.conv.weight", (ch, ch // 2, 2 * r), "convT"      # [C_in, C_out, k]
+        yield f"decoder.layers.{idx + 1}.conv.bias", (ch // 2,), "bias"
+        hid = ch // 2 // cfg.compress
+        yield f"decoder.layers.{idx + 2}.block.1.conv.weight", (hid, ch // 2, cfg.residual_kernel_size), "conv"
+        yield f"decoder.layers.{idx + 2}.block.1.conv.bias", (hid,), "bias"
+        yield f"decoder.layers.{idx + 2}.block.3.conv.weight", (ch // 2, hid, 1), "conv"
+        yield f"decoder.layers.{idx + 2}.block.3.conv.bias", (ch // 2,), "bias"
+        ch //= 2
+        idx += 3
+    yield f"decoder.layers.{idx + 1}.conv.weight", (1, ch, cfg.last_kernel_size), "conv"
+    yield f"decoder.layers.{idx + 1}.conv.bias", (1,), "bias"
+
+
+def synth_mimi_state_dict(cfg: MimiDecodeConfig, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic decode-path checkpoint (hash-based like csm_hf_amd.synth: identical on every machine)."""
+    from .synth import synth_tensor, hash_uniform
+    sd = {}
+    for key, shape, kind in mimi_state_dict_spec(cfg):
+        if kind == "usage":
+            sd[key] = hash_uniform("mimi:" + key, shape[0], seed, device) * 0.5 + 1.0          # in (0.5, 1.5)
+        elif kind == "norm":
+            sd[key] = synth_tensor("mimi:" + key, shape, 0.05, seed, device, mean=1.0)
+        elif kind == "bias":
+            sd[key] = synth_tensor("mimi:" + key, shape, 0.02, seed, device)
+        elif kind == "scale":
+            sd[key] = synth_tensor("mimi:" + key, shape, 0.05, seed, device, mean=0.3)
+        elif kind == "embed":
+            sd[key] = synth_tensor("mimi:" + key, shape, 0.5, seed, device)
+        else:   # conv [C_out, C_in, k], convT [C_in, C_out, k], linear [N, K]: keep activations O(1) through the stack
+            fan = shape[1] * (shape[2] if len(shape) == 3 else 1)
+            if kind == "convT":
+                fan = shape[0] * 2                                                          # two taps reach an output
+            sd[key] = synth_tensor("mimi:" + key, shape, 1.0 / math.sqrt(max(fan, 1)), seed, device)
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the device path: ctypes binding of csm_mimi_* (include/csm_hip.h) and the one-time weight repacking
+# ---------------------------------------------------------------------------------------------------------------------
+_MAX_LAYERS, _MAX_RATIOS = 16, 8
+
+
+class _MimiCfg(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("n_q", C.c_int32), ("n_sem", C.c_int32), ("codebook_size", C.c_int32),
+                ("codebook_dim", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+                ("head_dim", C.c_int32), ("ffn", C.c_int32), ("window", C.c_int32), ("rope_theta", C.c_float),
+                ("norm_eps", C.c_float), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * _MAX_RATIOS),
+                ("num_filters", C.c_int32), ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32),
+                ("res_kernel_size", C.c_int32), ("compress", C.c_int32), ("up_stride", C.c_int32), ("max_frames", C.c_int32)]
+
+
+_PL, _PR = C.c_void_p * _MAX_LAYERS, C.c_void_p * _MAX_RATIOS
+
+
+class _MimiWeights(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("out_proj", C.c_void_p), ("upsample", C.c_void_p),
+                ("ln1_w", _PL), ("ln1_b", _PL), ("wqkv", _PL), ("wo", _PL), ("ls1", _PL), ("ln2_w", _PL), ("ln2_b", _PL),
+                ("w1", _PL), ("w2", _PL), ("ls2", _PL), ("conv0_w", C.c_void_p), ("conv0_b", C.c_void_p),
+                ("up_w", _PR), ("up_b", _PR), ("res1_w", _PR), ("res1_b", _PR), ("res2_w", _PR), ("res2_b", _PR),
+                ("last_w", C.c_void_p), ("last_b", C.c_void_p)]
+
+
+def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    n = (w.shape[0] + mult - 1) // mult * mult
+    if n == w.shape[0]:
+        return w.contiguous()
+    out = torch.zeros(n, w.shape[1], dtype=w.dtype, device=w.device)
+    out[: w.shape[0]] = w
+    return out
+
+
+def _conv_as_gemm(w: torch.Tensor) -> torch.Tensor:
+    """conv1d weight [C_out, C_in, k] -> [pad128(C_out), k * C_in] with W'[co][j * C_in + ci] = w[co][ci][j]: the operand
+    row of output position l is the k consecutive channels-last input rows l - (k - 1) .. l."""
+    return _pad_rows(w.permute(0, 2, 1).reshape(w.shape[0], -1))
+
+
+def _convtr_as_gemm(w: torch.Tensor, r: int) -> torch.Tensor:
+    """conv_transpose1d weight [C_in, C_out, 2r], stride r, causal trim: [r * C_out, 2 * C_in], row s * C_out + co =
+    [w[:, co, s + r] | w[:, co, s]] against the operand row [x[q - 1] ; x[q]] -> output position r q + s."""
+    ci, co, k = w.shape
+    assert k == 2 * r
+    rows = [torch.cat([w[:, :, s + r].t(), w[:, :, s].t()], dim=1) for s in range(r)]        # each [C_out, 2 C_in]
+    return torch.cat(rows, dim=0).contiguous()
+
+
+def pack_mimi_weights(cfg: MimiDecodeConfig, sd: Dict[str, torch.Tensor], device) -> Dict[str, object]:
+    """HF-layout (`kyutai/mimi`) decode-path tensors -> the fp32 device tensors csm_mimi_weights_t points at."""
+    f = lambda k: sd[k].to(device=device, dtype=torch.float32)
+    out: Dict[str, object] = {}
+    emb, proj = [], []
+    for name, n in (("semantic", cfg.num_semantic_quantizers), ("acoustic", cfg.num_quantizers - cfg.num_semantic_quantizers)):
+        p = f"quantizer.{name}_residual_vector_quantizer"
+        for i in range(n):
+            emb.append(f(f"{p}.layers.{i}.codebook.embed_sum") / f(f"{p}.layers.{i}.codebook.cluster_usage").clamp(min=1e-5)[:, None])
+        proj.append(f(f"{p}.output_proj.weight")[:, :, 0])
+    out["embed"] = torch.stack(emb).contiguous()
+    out["out_proj"] = torch.cat(proj, dim=1).contiguous()
+    out["upsample"] = f("upsample.conv.weight")[:, 0, :].contiguous()
+    for key in ("ln1_w", "ln1_b", "wqkv", "wo", "ls1", "ln2_w", "ln2_b", "w1", "w2", "ls2"):
+        out[key] = []
+    for l in range(cfg.num_hidden_layers):
+        p = f"decoder_transformer.layers.{l}"
+        out["ln1_w"].append(f(f"{p}.input_layernorm.weight").contiguous())
+        out["ln1_b"].append(f(f"{p}.input_layernorm.bias").contiguous())
+        out["wqkv"].append(torch.cat([f(f"{p}.self_attn.{n}_proj.weight") for n in "qkv"], dim=0).contiguous())
+        out["wo"].append(f(f"{p}.self_attn.o_proj.weight").contiguous())
+        out["ls1"].append(f(f"{p}.self_attn_layer_scale.scale").contiguous())
+        out["ln2_w"].append(f(f"{p}.post_attention_layernorm.weight").contiguous())
+        out["ln2_b"].append(f(f"{p}.post_attention_layernorm.bias").contiguous())
+        out["w1"].append(f(f"{p}.mlp.fc1.weight").contiguous())
+        out["w2"].append(f(f"{p}.mlp.fc2.weight").contiguous())
+        out["ls2"].append(f(f"{p}.mlp_layer_scale.scale").contiguous())
+    out["conv0_w"] = _conv_as_gemm(f("decoder.layers.0.conv.weight"))
+    out["conv0_b"] = f("decoder.layers.0.conv.bias").contiguous()
+    for key in ("up_w", "up_b", "res1_w", "res1_b", "res2_w", "res2_b"):
+        out[key] = []
+    idx = 1
+    for r in cfg.upsampling_ratios:
+        out["up_w"].append(_convtr_as_gemm(f(f"decoder.layers.{idx + 1}.conv.weight"), r))
+        out["up_b"].append(f(f"decoder.layers.{idx + 1}.conv.bias").contiguous())
+        out["res1_w"].append(_conv_as_gemm(f(f"decoder.layers.{idx + 2}.block.1.conv.weight")))
+        out["res1_b"].append(f(f"decoder.layers.{idx + 2}.block.1.conv.bias").contiguous())
+        out["res2_w"].append(_conv_as_gemm(f(f"decoder.layers.{idx + 2}.block.3.conv.weight")))
+        out["res2_b"].append(f(f"decoder.layers.{idx + 2}.block.3.conv.bias").contiguous())
+        idx += 3
+    lw = f(f"decoder.layers.{idx + 1}.conv.weight")                      # [1, C, k]
+    out["last_w"] = lw[0].t().reshape(-1).contiguous()                    # w'[j * C + c]
+    out["last_b"] = f(f"decoder.layers.{idx + 1}.conv.bias").contiguous()
+    return out
+
+
+class MimiDecoder:
+    """`decode(audio_codes [B, n_q, T]) -> waveform [B, 1, T * samples_per_frame]` like transformers' MimiModel.decode /
+    the reference's `audio_tokenizer.decode` (README.md:114-118: `audio_tokenizer.decode(gen_frames.permute(0, 2, 1))`).
+    `state_dict`: the decode-path tensors in the `kyutai/mimi` key layout (see mimi_state_dict_spec)."""
+
+    def __init__(self, cfg: MimiDecodeConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", max_frames: int = 512):
+        from .engine import load_library, ABI_VERSION, _ck
+        self.cfg, self.device = cfg, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MimiDecoder runs on an AMD GPU only: csm_hf_amd has no CPU path")
+        self.lib = load_library()
+        self._ck = _ck
+        self.lib.csm_mimi_create.argtypes = [C.POINTER(_MimiCfg), C.POINTER(C.c_void_p)]
+        self.lib.csm_mimi_destroy.argtypes = [C.c_void_p]
+        self.lib.csm_mimi_bind_weights.argtypes = [C.c_void_p, C.POINTER(_MimiWeights)]
+        self.lib.csm_mimi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if cfg.num_hidden_layers > _MAX_LAYERS or len(cfg.upsampling_ratios) > _MAX_RATIOS:
+            raise ValueError("too many transformer layers / upsampling ratios for csm_mimi_config_t")
+        c = _MimiCfg(abi_version=ABI_VERSION, n_q=cfg.num_quantizers, n_sem=cfg.num_semantic_quantizers,
+                     codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim, hidden=cfg.hidden_size,
+                     layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads, head_dim=cfg.head_dim, ffn=cfg.intermediate_size,
+                     window=cfg.sliding_window, rope_theta=cfg.rope_theta, norm_eps=cfg.norm_eps, n_ratios=len(cfg.upsampling_ratios),
+                     num_filters=cfg.num_filters, kernel_size=cfg.kernel_size, last_kernel_size=cfg.last_kernel_size,
+                     res_kernel_size=cfg.residual_kernel_size, compress=cfg.compress, up_stride=cfg.upsample_stride,
+                     max_frames=int(max_frames))
+        for i, r in enumerate(cfg.upsampling_ratios):
+            c.ratios[i] = int(r)
+        self.max_frames = int(max_frames)
+        with torch.cuda.device(self.device):
+            h = C.c_void_p()
+            _ck(self.lib, self.lib.csm_mimi_create(C.byref(c), C.byref(h)))
+            self._h = h
+            self.packed = pack_mimi_weights(cfg, state_dict, self.device)          # keeps the tensors alive
+            w = _MimiWeights()
+            for name, _ in _MimiWeights._fields_:
+                v = self.packed[name]
+                if isinstance(v, list):
+                    arr = getattr(w, name)
+                    for i, t in enumerate(v):
+                        arr[i] = t.data_ptr()
+                else:
+                    setattr(w, name, v.data_ptr())
+            torch.cuda.synchronize(self.device)
+            _ck(self.lib, self.lib.csm_mimi_bind_weights(self._h, C.byref(w)))
+
+    def decode(self, audio_codes: torch.Tensor) -> torch.Tensor:
+        if audio_codes.dim() != 3 or audio_codes.shape[1] != self.cfg.num_quantizers:
+            raise ValueError(f"audio_codes must be [B, {self.cfg.num_quantizers}, T], got {tuple(audio_codes.shape)}")
+        B, _, T = audio_codes.shape
+        if T < 1 or T > self.max_frames:
+            raise ValueError(f"T = {T} outside 1..{self.max_frames} (max_frames)")
+        if int(audio_codes.min()) < 0 or int(audio_codes.max()) >= self.cfg.codebook_size:
+            raise ValueError("audio codes outside the codebook")
+        codes = audio_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(B, 1, T * self.cfg.samples_per_frame, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib, self.lib.csm_mimi_decode(self._h, codes.data_ptr(), B, T, out.data_ptr()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.csm_mimi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

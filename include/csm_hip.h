@@ -151,6 +151,51 @@ int csm_prefill(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B,
  * which masks by cache index and rotates by position_ids */
 int csm_prefill_pos(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, int B, int S, const int32_t* position_ids,
                     float* last_h_out, float* c0_logits_out);
+/* ---- Mimi decode: `audio_tokenizer.decode(gen_frames.permute(0, 2, 1))`, the step right
+ * after the generation path (/root/reference/README.md:58-60, 114-118; train.py:363-365).  The codec is the third-party
+ * package moshi==0.2.2 (absent from the reference tree and from the image); its decode path is restated from the published
+ * architecture as implemented by transformers 5.15 models/mimi/modeling_mimi.py:1388-1455 (MimiModel.decode), which the
+ * parity fixtures are generated with.  fp32 throughout.  Weights are repacked by the host (csm-hf_amd/mimi.py:
+ * pack_mimi_weights documents every layout). */
+#define CSM_MIMI_MAX_LAYERS 16
+#define CSM_MIMI_MAX_RATIOS 8
+typedef struct csm_mimi csm_mimi_t;
+typedef struct {
+  int32_t abi_version;
+  int32_t n_q, n_sem, codebook_size, codebook_dim;        /* split residual VQ: n_sem semantic + (n_q - n_sem) acoustic codebooks */
+  int32_t hidden, layers, heads, head_dim, ffn, window;   /* decoder transformer; window = sliding attention window */
+  float rope_theta, norm_eps;
+  int32_t n_ratios, ratios[CSM_MIMI_MAX_RATIOS];          /* SEANet upsampling ratios, in decode order */
+  int32_t num_filters, kernel_size, last_kernel_size, res_kernel_size, compress, up_stride;
+  int32_t max_frames;                                     /* capacity: codec frames per sequence */
+} csm_mimi_config_t;
+typedef struct {                                          /* fp32 device pointers */
+  const float* embed;      /* [n_q][codebook_size][codebook_dim] = embed_sum / clamp(cluster_usage, 1e-5) */
+  const float* out_proj;   /* [hidden][2 * codebook_dim] = [semantic output_proj | acoustic output_proj] */
+  const float* upsample;   /* [hidden][2 * up_stride] depthwise taps */
+  const float* ln1_w[CSM_MIMI_MAX_LAYERS]; const float* ln1_b[CSM_MIMI_MAX_LAYERS];
+  const float* wqkv[CSM_MIMI_MAX_LAYERS];  /* [3 * heads * head_dim][hidden] = [q_proj; k_proj; v_proj] */
+  const float* wo[CSM_MIMI_MAX_LAYERS];    /* [hidden][heads * head_dim] */
+  const float* ls1[CSM_MIMI_MAX_LAYERS];
+  const float* ln2_w[CSM_MIMI_MAX_LAYERS]; const float* ln2_b[CSM_MIMI_MAX_LAYERS];
+  const float* w1[CSM_MIMI_MAX_LAYERS];    /* [ffn][hidden] */
+  const float* w2[CSM_MIMI_MAX_LAYERS];    /* [hidden][ffn] */
+  const float* ls2[CSM_MIMI_MAX_LAYERS];
+  const float* conv0_w; const float* conv0_b;   /* [C0][k * hidden]: W'[co][j * C_in + ci] = w[co][ci][j];  [C0] */
+  const float* up_w[CSM_MIMI_MAX_RATIOS];       /* [r * C_out][2 * C_in]: row s * C_out + co = [w[:, co, s + r] | w[:, co, s]] */
+  const float* up_b[CSM_MIMI_MAX_RATIOS];       /* [C_out] */
+  const float* res1_w[CSM_MIMI_MAX_RATIOS];     /* [pad128(hid)][k * C_out] (rows beyond hid zero), layout as conv0_w */
+  const float* res1_b[CSM_MIMI_MAX_RATIOS];     /* [hid] */
+  const float* res2_w[CSM_MIMI_MAX_RATIOS];     /* [pad128(C_out)][hid] */
+  const float* res2_b[CSM_MIMI_MAX_RATIOS];     /* [C_out] */
+  const float* last_w; const float* last_b;     /* [k * C]: w'[j * C + c] = w[0][c][j];  [1] */
+} csm_mimi_weights_t;
+int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out);
+int csm_mimi_destroy(csm_mimi_t* m);
+int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w);   /* borrowed pointers */
+/* codes [B][n_q][T] int64 (device) -> audio [B][T * samples_per_frame] fp32 (device); samples_per_frame = up_stride * prod(ratios) */
+int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* audio);
+
 /* ---- continuous batching (no reference counterpart): a new utterance takes over batch row
  * `row` of the running batch between two frame-steps.  ids [S][C+1] / mask [S][C+1] on the device; S <= the batch's
  * current length (the context is placed right-aligned, like a left-padded row of the reference).  The row's frames from
