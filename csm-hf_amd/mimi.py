@@ -220,6 +220,52 @@ def pack_mimi_weights(cfg: MimiDecodeConfig, sd: Dict[str, torch.Tensor], device
     return out
 
 
+def load_mimi_checkpoint(path: str):
+    """(MimiDecodeConfig, decode-path state dict) from a `kyutai/mimi`-layout directory (`config.json` +
+    `model.safetensors`, what `transformers.MimiModel.save_pretrained` writes).  Weight-normalised convolutions stored as
+    `...conv.parametrizations.weight.original0/1` (g, v) are folded to plain weights (w = g * v / ||v||, norm over all
+    dimensions but the first, torch.nn.utils.parametrizations.weight_norm's default)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    hf = json.load(open(os.path.join(path, "config.json")))
+    cfg = MimiDecodeConfig()
+    for mine, theirs in (("num_quantizers", "num_quantizers"), ("num_semantic_quantizers", "num_semantic_quantizers"),
+                         ("codebook_size", "codebook_size"), ("codebook_dim", "codebook_dim"), ("hidden_size", "hidden_size"),
+                         ("num_hidden_layers", "num_hidden_layers"), ("num_attention_heads", "num_attention_heads"),
+                         ("head_dim", "head_dim"), ("intermediate_size", "intermediate_size"), ("sliding_window", "sliding_window"),
+                         ("norm_eps", "norm_eps"), ("upsampling_ratios", "upsampling_ratios"), ("num_filters", "num_filters"),
+                         ("kernel_size", "kernel_size"), ("last_kernel_size", "last_kernel_size"),
+                         ("residual_kernel_size", "residual_kernel_size"), ("compress", "compress")):
+        if hf.get(theirs) is not None:
+            setattr(cfg, mine, hf[theirs])
+    rp = hf.get("rope_parameters") or {}
+    cfg.rope_theta = float(rp.get("rope_theta", hf.get("rope_theta", cfg.rope_theta)))
+    if hf.get("frame_rate") and hf.get("sampling_rate"):
+        total = round(hf["sampling_rate"] / hf["frame_rate"])
+        cfg.upsample_stride = total // math.prod(cfg.upsampling_ratios)
+    for flag, want in (("use_causal_conv", True), ("use_conv_shortcut", False), ("num_residual_layers", 1), ("trim_right_ratio", 1.0)):
+        if hf.get(flag, want) != want:
+            raise ValueError(f"Mimi config {flag}={hf[flag]!r} is outside what the device path implements ({want!r})")
+    if hf.get("num_key_value_heads", cfg.num_attention_heads) != cfg.num_attention_heads:
+        raise ValueError("grouped-query attention in the Mimi transformer is not implemented")
+    raw = load_file(os.path.join(path, "model.safetensors"))
+    sd = {}
+    for key, shape, _ in mimi_state_dict_spec(cfg):
+        if key in raw:
+            t = raw[key]
+        elif key.endswith("conv.weight") and key[:-len("weight")] + "parametrizations.weight.original1" in raw:
+            base = key[:-len("weight")] + "parametrizations.weight.original"
+            g, v = raw[base + "0"].float(), raw[base + "1"].float()
+            t = g * v / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+        else:
+            raise KeyError(f"{key} missing from the checkpoint")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{key}: shape {tuple(t.shape)} != {tuple(shape)}")
+        sd[key] = t.float()
+    return cfg, sd
+
+
 class MimiDecoder:
     """`decode(audio_codes [B, n_q, T]) -> waveform [B, 1, T * samples_per_frame]` like transformers' MimiModel.decode /
     the reference's `audio_tokenizer.decode` (README.md:114-118: `audio_tokenizer.decode(gen_frames.permute(0, 2, 1))`).
@@ -264,6 +310,11 @@ class MimiDecoder:
                     setattr(w, name, v.data_ptr())
             torch.cuda.synchronize(self.device)
             _ck(self.lib, self.lib.csm_mimi_bind_weights(self._h, C.byref(w)))
+
+    @classmethod
+    def from_pretrained(cls, path: str, device="cuda:0", max_frames: int = 512) -> "MimiDecoder":
+        cfg, sd = load_mimi_checkpoint(path)
+        return cls(cfg, sd, device, max_frames)
 
     def decode(self, audio_codes: torch.Tensor) -> torch.Tensor:
         if audio_codes.dim() != 3 or audio_codes.shape[1] != self.cfg.num_quantizers:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from csm_hf_amd.mimi import MimiDecodeConfig, synth_mimi_state_dict, mimi_state_dict_spec
+from csm_hf_amd.mimi import MimiDecodeConfig, synth_mimi_state_dict, mimi_state_dict_spec, load_mimi_checkpoint
 from oracle import mimi_oracle as MO
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -38,6 +38,39 @@ def test_oracle_vs_transformers_golden(name):
         assert torch.equal(out[..., :keep], out2[..., :keep]) and not torch.equal(out, out2)
 
 
+def test_checkpoint_directory_round_trip(tmp_path):
+    """`kyutai/mimi`-layout directory (config.json + model.safetensors, as transformers writes it) -> config + decode-path
+    tensors; a weight-normalised convolution (g, v) is folded to the plain weight."""
+    import json
+    from safetensors.torch import save_file
+    cfg = MimiDecodeConfig.tiny()
+    sd = synth_mimi_state_dict(cfg, seed=0)
+    hf = dict(num_quantizers=cfg.num_quantizers, num_semantic_quantizers=1, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+              hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+              num_key_value_heads=cfg.num_attention_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+              sliding_window=cfg.sliding_window, norm_eps=cfg.norm_eps, upsampling_ratios=cfg.upsampling_ratios, num_filters=cfg.num_filters,
+              kernel_size=7, last_kernel_size=3, residual_kernel_size=3, compress=2, rope_parameters={"rope_theta": 10000.0, "rope_type": "default"},
+              frame_rate=12.5, sampling_rate=12.5 * cfg.samples_per_frame, use_causal_conv=True, model_type="mimi")
+    stored = dict(sd)
+    k = "decoder.layers.0.conv.weight"
+    w = stored.pop(k)
+    v = w * 3.0                                             # any direction tensor; g restores the norm
+    stored["decoder.layers.0.conv.parametrizations.weight.original1"] = v
+    stored["decoder.layers.0.conv.parametrizations.weight.original0"] = w.flatten(1).norm(dim=1).view(-1, 1, 1)
+    stored["encoder.layers.0.conv.weight"] = torch.zeros(4, 1, 7)          # an encode-side tensor: ignored
+    os.makedirs(tmp_path, exist_ok=True)
+    json.dump(hf, open(os.path.join(tmp_path, "config.json"), "w"))
+    save_file({a: b.contiguous() for a, b in stored.items()}, os.path.join(tmp_path, "model.safetensors"))
+    cfg2, sd2 = load_mimi_checkpoint(str(tmp_path))
+    assert cfg2 == cfg and set(sd2) == set(sd)
+    for a in sd:
+        torch.testing.assert_close(sd2[a], sd[a], atol=1e-6, rtol=1e-6)
+    hf["use_conv_shortcut"] = True
+    json.dump(hf, open(os.path.join(tmp_path, "config.json"), "w"))
+    with pytest.raises(ValueError):
+        load_mimi_checkpoint(str(tmp_path))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny", "full"])
 def test_hip_decode_vs_transformers_golden_and_oracle(name):
@@ -58,6 +91,20 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
         want = MO.decode(sd, cfg, c)
         got = dec.decode(c.to("cuda:0")).cpu()
         assert rel_max(got, want) < 1e-4, (B, T)
+    if name == "full":
+        # the reference's pipeline end to end (README.md:100-118): generate frames, hand them to the codec as [B, 32, n]
+        from csm_hf_amd import CSMConfig, CSMModel
+        from csm_hf_amd.synth import synth_state_dict, synth_context
+        ccfg = CSMConfig.tiny()
+        m = CSMModel(ccfg)
+        m.load_state_dict(synth_state_dict(ccfg, seed=0, std=0.05))
+        m = m.to("cuda:0").eval()
+        ids, mask = synth_context(ccfg, 2, 3, 5, seed=1)
+        frames = m.generate(ids.to("cuda:0"), mask.to("cuda:0"), max_new_frames=4, topk=1, stop_on_all_zeros=False)
+        wav = dec.decode(frames.permute(0, 2, 1))
+        assert wav.shape == (2, 1, 4 * 1920) and bool(torch.isfinite(wav).all())
+        assert rel_max(wav.cpu(), MO.decode(sd, cfg, frames.permute(0, 2, 1).cpu())) < 1e-4
+        m._drop_engine()
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, cfg.num_quantizers, 65, dtype=torch.long))          # beyond max_frames
     with pytest.raises(ValueError):
