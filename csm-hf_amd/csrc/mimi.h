@@ -81,20 +81,29 @@ __global__ __launch_bounds__(256) void mimi_rope_kernel(float* qkv, int L, int h
 // causal sliding-window attention (modeling_mimi.py:687-726, create_sliding_window_causal_mask): query i sees keys
 // max(0, i - window + 1) .. i.  grid = (L, heads), 64 threads (head_dim <= 64 * 2), fp32 softmax.
 __global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, int L, int heads, int hd, int window, float* out) {
-  extern __shared__ float sc[];   // [window]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // q[hd] | scores[window]
+  float* qs = sm;
+  float* sc = sm + hd;
   const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
   const int A = heads * hd;
   const int j0 = max(0, i - window + 1), n = i - j0 + 1;
   const float* q = qkv + (size_t)i * 3 * A + (size_t)h * hd;
   const float scale = rsqrtf((float)hd);
+  for (int d = tid; d < hd; d += 64) qs[d] = q[d] * scale;
+  __syncthreads();
   float mx = -INFINITY;
-  for (int j = tid; j < n; j += 64) {
+  for (int j = tid; j < n; j += 64) {   // one key per thread and round: its hd-wide row by 16-byte loads against q in LDS
     const float* k = qkv + (size_t)(j0 + j) * 3 * A + A + (size_t)h * hd;
-    float s = 0.f;
-    for (int d = 0; d < hd; ++d) s = fmaf(q[d], k[d], s);
-    s *= scale;
-    sc[j] = s;
-    mx = fmaxf(mx, s);
+    float s0 = 0.f, s1 = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + d), k1 = *reinterpret_cast<const f32x4*>(k + d + 4);
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + d), q1 = *reinterpret_cast<const f32x4*>(qs + d + 4);
+      s0 += (k0[0] * q0[0] + k0[1] * q0[1]) + (k0[2] * q0[2] + k0[3] * q0[3]);
+      s1 += (k1[0] * q1[0] + k1[1] * q1[1]) + (k1[2] * q1[2] + k1[3] * q1[3]);
+    }
+    const float sv = s0 + s1;
+    sc[j] = sv;
+    mx = fmaxf(mx, sv);
   }
   mx = wave_max(mx);
   float se = 0.f;
@@ -103,9 +112,15 @@ __global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, int L, 
   __syncthreads();
   const float inv = 1.f / se;
   for (int d = tid; d < hd; d += 64) {
-    float o = 0.f;
-    for (int j = 0; j < n; ++j) o = fmaf(sc[j], qkv[(size_t)(j0 + j) * 3 * A + 2 * A + (size_t)h * hd + d], o);
-    out[(size_t)i * A + (size_t)h * hd + d] = o * inv;
+    float o0 = 0.f, o1 = 0.f;
+    const float* v = qkv + (size_t)j0 * 3 * A + 2 * A + (size_t)h * hd + d;
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+      o0 = fmaf(sc[j], v[(size_t)j * 3 * A], o0);
+      o1 = fmaf(sc[j + 1], v[(size_t)(j + 1) * 3 * A], o1);
+    }
+    if (j < n) o0 = fmaf(sc[j], v[(size_t)j * 3 * A], o0);
+    out[(size_t)i * A + (size_t)h * hd + d] = (o0 + o1) * inv;
   }
 }
 
@@ -140,11 +155,28 @@ __global__ __launch_bounds__(256) void mimi_elu_copy_kernel(const float* src, fl
 // last convolution, one output channel (modeling_mimi.py:955): audio[l] = b + sum_j sum_c w[j * C + c] * xa[(l + j) * C + c]
 // over the ELU'd, front-padded input xa (k - 1 zero rows first)
 __global__ __launch_bounds__(256) void mimi_last_conv_kernel(const float* xa, const float* w, const float* b, int C, int k, size_t L, float* audio) {
-  const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (l >= L) return;
-  const float* p = xa + l * C;
-  float s = b[0];
-  for (int i = 0; i < k * C; ++i) s = fmaf(w[i], p[i], s);
-  audio[l] = s;
+  // a wave takes 16 consecutive outputs; its lanes walk the contiguous k * C operand row of each (coalesced), the weights
+  // stay in registers (k * C <= 64 * 4) or are re-read from L1 otherwise
+  const int lane = threadIdx.x & 63;
+  const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = k * C;
+  float wr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) wr[u] = lane + 64 * u < K ? w[lane + 64 * u] : 0.f;
+  const float bias = b[0];
+  for (int o = 0; o < 16; ++o) {
+    const size_t l = wv * 16 + o;
+    if (l >= L) return;
+    const float* p = xa + l * C;
+    float s = 0.f;
+    if (K <= 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lane + 64 * u < K) s = fmaf(wr[u], p[lane + 64 * u], s);
+    } else {
+      for (int i = lane; i < K; i += 64) s = fmaf(w[i], p[i], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) audio[l] = s + bias;
+  }
 }
 #endif  // CSM_MIMI_KERNELS

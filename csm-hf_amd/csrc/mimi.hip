@@ -155,7 +155,7 @@ extern "C" int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T
       hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln1_w[l], m->w.ln1_b[l], H, c.norm_eps, m->hn);
       MLCK(gemm(m, m->hn, H, m->w.wqkv[l], 3 * A, H, L1, m->qkv, 3 * A));
       hipLaunchKernelGGL(mimi_rope_kernel, dim3(nblk(L1 * 2 * c.heads * (c.head_dim / 2))), dim3(256), 0, st, m->qkv, (int)L1, c.heads, c.head_dim, c.rope_theta);
-      hipLaunchKernelGGL(mimi_attn_kernel, dim3((unsigned)L1, c.heads), dim3(64), (size_t)c.window * sizeof(float), st, m->qkv, (int)L1, c.heads,
+      hipLaunchKernelGGL(mimi_attn_kernel, dim3((unsigned)L1, c.heads), dim3(64), (size_t)(c.head_dim + c.window) * sizeof(float), st, m->qkv, (int)L1, c.heads,
                          c.head_dim, c.window, m->ao);
       MLCK(gemm(m, m->ao, A, m->w.wo[l], H, A, L1, m->tmp, H));
       hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls1[l], L1 * H, H);
@@ -192,7 +192,7 @@ extern "C" int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T
     // ---- ELU, last convolution to one channel ----
     MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * ch * sizeof(float), st));
     hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cur, m->pad + (size_t)PADR * ch, L * ch, 1);
-    hipLaunchKernelGGL(mimi_last_conv_kernel, dim3(nblk(L)), dim3(256), 0, st, m->pad + (size_t)(PADR - (c.last_kernel_size - 1)) * ch, m->w.last_w,
+    hipLaunchKernelGGL(mimi_last_conv_kernel, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, st, m->pad + (size_t)(PADR - (c.last_kernel_size - 1)) * ch, m->w.last_w,
                        m->w.last_b, ch, c.last_kernel_size, L, audio + (size_t)b * T * spf);
     MHIP(hipGetLastError());
   }
