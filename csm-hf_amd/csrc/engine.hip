@@ -309,15 +309,19 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->ids_stage, (size_t)B * (C + 1))) || (r = dalloc(e, &e->mask_stage, (size_t)B * (C + 1))))
     return r;
   const size_t R = cfg->max_prefill_rows;
-  if ((r = dalloc(e, &e->p_h, R * Hb)) || (r = dalloc(e, &e->p_xn, R * Hb)) ||
-      (r = dalloc(e, &e->p_qkv, R * e->bb.nqkv())) || (r = dalloc(e, &e->p_q, R * nqb)) ||
-      (r = dalloc(e, &e->p_att, R * nqb)) || (r = dalloc(e, &e->p_act, R * cfg->backbone.ffn)) ||
+  // the prefill scratch serves BOTH stacks (stack_rows: backbone context; decoder pass of the training forward), so every
+  // buffer takes the wider of the two shapes (the tiny test model's decoder QKV, 512 wide, is wider than its backbone's 384)
+  const size_t Hm_ = std::max(Hb, Hd), qkvm = std::max(e->bb.nqkv(), e->dec.nqkv()), nqm = std::max(nqb, nqd);
+  const size_t ffm = std::max(cfg->backbone.ffn, cfg->decoder.ffn);
+  if ((r = dalloc(e, &e->p_h, R * Hm_)) || (r = dalloc(e, &e->p_xn, R * Hm_)) ||
+      (r = dalloc(e, &e->p_qkv, R * qkvm)) || (r = dalloc(e, &e->p_q, R * nqm)) ||
+      (r = dalloc(e, &e->p_att, R * nqm)) || (r = dalloc(e, &e->p_act, R * ffm)) ||
       (r = dalloc(e, &e->p_row_seq, R)) || (r = dalloc(e, &e->p_row_pos, R)))
     return r;
   if (cfg->weight_dtype != CSM_DTYPE_F32) {
-    const size_t Km = std::max((size_t)Hb, (size_t)nqb);
-    if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * cfg->backbone.ffn))) return r;
-    if (R <= 4096 && (r = dalloc(e, &e->p_part, 4 * R * Hb))) return r;   // only small prefills are short of workgroups
+    const size_t Km = std::max(Hm_, nqm);
+    if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * ffm))) return r;
+    if (R <= 4096 && (r = dalloc(e, &e->p_part, 4 * R * Hm_))) return r;   // only small prefills are short of workgroups
   }
   if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
