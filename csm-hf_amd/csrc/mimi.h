@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void mimi_rvq_gather_kernel(const int64_t* cod
 
 // depthwise transposed convolution, kernel 2 s, stride s, causal trim (modeling_mimi.py:399-405, MimiModel.upsample):
 // out[s q + p][c] = x[q][c] w[c][p] + x[q - 1][c] w[c][p + s]
-__global__ __launch_bounds__(256) void mimi_upsample_kernel(const float* x, const float* w, int L, int C, int s, float* out) {
+__global__ __launch_bounds__(256) void mimi_upsample_kernel(const float* x, const float* w, int L, int C, int s, const float* prev, float* out) {
+  // prev (nullable): the row before x[0] (streaming: the last frame of the previous call)
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)L * s * C) return;
   const int c = (int)(i % C);
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void mimi_upsample_kernel(const float* x, cons
   const int q = (int)(lo / s), p = (int)(lo % s);
   float v = x[(size_t)q * C + c] * w[(size_t)c * 2 * s + p];
   if (q > 0) v += x[(size_t)(q - 1) * C + c] * w[(size_t)c * 2 * s + p + s];
+  else if (prev) v += prev[c] * w[(size_t)c * 2 * s + p + s];
   out[i] = v;
 }
 
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(256) void mimi_layernorm_kernel(const float* x, con
 }
 
 // rotary embedding, default rope, rotate_half convention (modeling_mimi.py:524-600), in place on the q and k parts of a
-// [L][3 A] projection buffer; position = row
-__global__ __launch_bounds__(256) void mimi_rope_kernel(float* qkv, int L, int heads, int hd, float theta) {
+// [L][3 A] projection buffer; position = pos0 + row (pos0 > 0 when a stream continues)
+__global__ __launch_bounds__(256) void mimi_rope_kernel(float* qkv, int L, int heads, int hd, float theta, int pos0) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int half = hd / 2, A = heads * hd;
   if (i >= (size_t)L * 2 * heads * half) return;
@@ -71,29 +73,45 @@ __global__ __launch_bounds__(256) void mimi_rope_kernel(float* qkv, int L, int h
   const int h = (int)(r % (2 * heads));      // q heads, then k heads
   const int pos = (int)(r / (2 * heads));
   float* p = qkv + (size_t)pos * 3 * A + (size_t)h * hd;
-  const float ang = (float)pos * powf(theta, -2.f * (float)f / (float)hd);
+  const float ang = (float)(pos0 + pos) * powf(theta, -2.f * (float)f / (float)hd);
   const float c = cosf(ang), s = sinf(ang);
   const float a = p[f], b = p[f + half];
   p[f] = a * c - b * s;
   p[f + half] = b * c + a * s;
 }
 
-// causal sliding-window attention (modeling_mimi.py:687-726, create_sliding_window_causal_mask): query i sees keys
-// max(0, i - window + 1) .. i.  grid = (L, heads), 64 threads (head_dim <= 64 * 2), fp32 softmax.
-__global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, int L, int heads, int hd, int window, float* out) {
+// the rotated K and the V rows of the new positions appended to the layer's history [rows][2 A] (K | V)
+__global__ __launch_bounds__(256) void mimi_kv_append_kernel(const float* qkv, float* hist, size_t L, int A) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * 2 * A) return;
+  const size_t r = i / (2 * A);
+  const int c = (int)(i % (2 * A));
+  hist[i] = qkv[r * 3 * A + A + c];
+}
+// rows [from, from + n) of src to the front of dst (the part of the history the next call can still see)
+__global__ __launch_bounds__(256) void mimi_rows_copy_kernel(const float* src, float* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// causal sliding-window attention (modeling_mimi.py:687-726, create_sliding_window_causal_mask): the query at history
+// index nh + i sees the keys max(0, nh + i - window + 1) .. nh + i of hist [nh + L][2 A] (nh = positions kept from earlier
+// calls of a stream, 0 otherwise).  grid = (L, heads), 64 threads, fp32 softmax.
+__global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, const float* hist, int nh, int heads, int hd, int window, float* out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // q[hd] | scores[window]
   float* qs = sm;
   float* sc = sm + hd;
   const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
   const int A = heads * hd;
-  const int j0 = max(0, i - window + 1), n = i - j0 + 1;
+  const int hi = nh + i;
+  const int j0 = max(0, hi - window + 1), n = hi - j0 + 1;
   const float* q = qkv + (size_t)i * 3 * A + (size_t)h * hd;
   const float scale = rsqrtf((float)hd);
   for (int d = tid; d < hd; d += 64) qs[d] = q[d] * scale;
   __syncthreads();
   float mx = -INFINITY;
   for (int j = tid; j < n; j += 64) {   // one key per thread and round: its hd-wide row by 16-byte loads against q in LDS
-    const float* k = qkv + (size_t)(j0 + j) * 3 * A + A + (size_t)h * hd;
+    const float* k = hist + (size_t)(j0 + j) * 2 * A + (size_t)h * hd;
     float s0 = 0.f, s1 = 0.f;
     for (int d = 0; d < hd; d += 8) {
       const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + d), k1 = *reinterpret_cast<const f32x4*>(k + d + 4);
@@ -113,13 +131,13 @@ __global__ __launch_bounds__(64) void mimi_attn_kernel(const float* qkv, int L, 
   const float inv = 1.f / se;
   for (int d = tid; d < hd; d += 64) {
     float o0 = 0.f, o1 = 0.f;
-    const float* v = qkv + (size_t)j0 * 3 * A + 2 * A + (size_t)h * hd + d;
+    const float* v = hist + (size_t)j0 * 2 * A + A + (size_t)h * hd + d;
     int j = 0;
     for (; j + 1 < n; j += 2) {
-      o0 = fmaf(sc[j], v[(size_t)j * 3 * A], o0);
-      o1 = fmaf(sc[j + 1], v[(size_t)(j + 1) * 3 * A], o1);
+      o0 = fmaf(sc[j], v[(size_t)j * 2 * A], o0);
+      o1 = fmaf(sc[j + 1], v[(size_t)(j + 1) * 2 * A], o1);
     }
-    if (j < n) o0 = fmaf(sc[j], v[(size_t)j * 3 * A], o0);
+    if (j < n) o0 = fmaf(sc[j], v[(size_t)j * 2 * A], o0);
     out[(size_t)i * A + (size_t)h * hd + d] = (o0 + o1) * inv;
   }
 }

@@ -33,6 +33,13 @@ struct csm_mimi {
   float *q2 = nullptr, *e0 = nullptr, *x = nullptr, *hn = nullptr, *qkv = nullptr, *ao = nullptr, *tmp = nullptr, *ff = nullptr;
   float *bufa = nullptr, *bufb = nullptr, *pad = nullptr, *scr = nullptr;
   size_t big = 0;   // floats in each of bufa / bufb / pad / scr
+  // K/V history of the transformer, per layer, ping-pong: [window - 1 + max positions per call][2 A]
+  std::vector<float*> hist[2];
+  // streaming state (csm_mimi_stream_*): frames decoded so far, history rows kept, the frame before the next call's first,
+  // and the last PADR input rows of every convolution (conv0, then per stage: transposed conv, residual conv; last conv)
+  int s_frames = 0, s_nh = 0, s_cur = 0;
+  float* s_up_prev = nullptr;
+  std::vector<float*> s_conv;
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
 
@@ -92,6 +99,31 @@ extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
     delete m;
     return r;
   }
+  {
+    const size_t hrows = (size_t)(c.window - 1) + L1;
+    int chs = c.num_filters << c.n_ratios;
+    std::vector<int> cins{c.hidden};
+    for (int i = 0; i < c.n_ratios; ++i) { cins.push_back(chs); cins.push_back(chs / 2); chs /= 2; }
+    cins.push_back(chs);
+    for (int l = 0; l < c.layers && !r; ++l)
+      for (int pp = 0; pp < 2 && !r; ++pp) {
+        float* h = nullptr;
+        r = malloc_f(m, &h, hrows * 2 * A);
+        m->hist[pp].push_back(h);
+      }
+    if (!r) r = malloc_f(m, &m->s_up_prev, (size_t)c.hidden);
+    for (size_t i = 0; i < cins.size() && !r; ++i) {
+      float* q = nullptr;
+      r = malloc_f(m, &q, (size_t)PADR * cins[i]);
+      m->s_conv.push_back(q);
+    }
+    if (r) {
+      for (void* p : m->allocs) hipFree(p);
+      hipStreamDestroy(m->stream);
+      delete m;
+      return r;
+    }
+  }
   *out = m;
   return 0;
 }
@@ -122,11 +154,26 @@ static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int
 
 // causal conv1d, stride 1, dilation 1 (MimiConv1d, modeling_mimi.py:327-347): xin = exact-width channels-last input
 // [L][Cin]; elu: apply nn.ELU to the input first; result (+ bias, + res, act) to out [L][Cout] (row stride ldo)
+// the PADR rows in front of a convolution's input: zeros, or (streaming) the last PADR input rows of the previous call
+static int pad_in(csm_mimi* m, const float* cache, int Cin) {
+  if (cache) MHIP(hipMemcpyAsync(m->pad, cache, (size_t)PADR * Cin * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+  else MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * Cin * sizeof(float), m->stream));
+  return 0;
+}
+// (streaming) keep the last PADR rows of the PADR + L rows now in m->pad for the next call
+static int pad_out(csm_mimi* m, float* cache, int Cin, size_t L) {
+  if (cache) MHIP(hipMemcpyAsync(cache, m->pad + L * Cin, (size_t)PADR * Cin * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+  return 0;
+}
+
+// causal conv1d, stride 1, dilation 1 (MimiConv1d, modeling_mimi.py:327-347): xin = exact-width channels-last input
+// [L][Cin]; elu: apply nn.ELU to the input first; result (+ bias, + res, act) to out [L][Cout] (row stride ldo)
 static int conv1d(csm_mimi* m, const float* xin, size_t L, int Cin, int k, int elu, const float* Wp, int Cout, const float* bias,
-                  const float* res, int act, float* out, int ldo) {
+                  const float* res, int act, float* out, int ldo, float* cache) {
   hipStream_t st = m->stream;
-  MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * Cin * sizeof(float), st));
+  if (int r = pad_in(m, cache, Cin)) return r;
   hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * Cin)), dim3(256), 0, st, xin, m->pad + (size_t)PADR * Cin, L * Cin, elu);
+  if (int r = pad_out(m, cache, Cin, L)) return r;
   const int Np = pad128(Cout);
   MLCK(gemm(m, m->pad + (size_t)(PADR - (k - 1)) * Cin, Cin, Wp, Np, k * Cin, L, m->scr, Np));
   hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * Cout)), dim3(256), 0, st, m->scr, Np, bias, Cout, res, Cout, L, act, out, ldo);
@@ -134,68 +181,118 @@ static int conv1d(csm_mimi* m, const float* xin, size_t L, int Cin, int k, int e
   return le != hipSuccess ? mfail((int)le, "conv1d launch failed: %s", hipGetErrorString(le)) : 0;
 }
 
+// one sequence: T frames of codes [n_q][T] -> T * samples_per_frame samples.  streaming: continue the handle's stream
+// (history of the transformer, left context of every convolution, positions) instead of starting from silence
+static int decode_one(csm_mimi* m, const int64_t* cb, int T, float* audio, bool streaming) {
+  const csm_mimi_config_t& c = m->c;
+  hipStream_t st = m->stream;
+  const int H = c.hidden, D = c.codebook_dim, A = c.heads * c.head_dim, F = c.ffn;
+  const int nh = streaming ? m->s_nh : 0;
+  const int pos0 = streaming ? m->s_frames * c.up_stride : 0;
+  int ci = 0;   // convolution cache index
+  auto cache = [&]() -> float* { float* q = streaming ? m->s_conv[ci] : nullptr; ++ci; return q; };
+  // ---- split RVQ decode + the two 1x1 output projections (one GEMM, K = 2 D) ----
+  hipLaunchKernelGGL(mimi_rvq_gather_kernel, dim3(T), dim3(256), 0, st, cb, m->w.embed, c.n_q, c.n_sem, c.codebook_size, D, T, m->q2);
+  MLCK(gemm(m, m->q2, 2 * D, m->w.out_proj, H, 2 * D, T, m->e0, H));
+  // ---- upsample to the transformer's rate ----
+  const size_t L1 = (size_t)T * c.up_stride;
+  hipLaunchKernelGGL(mimi_upsample_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->e0, m->w.upsample, T, H, c.up_stride,
+                     (streaming && m->s_frames > 0) ? m->s_up_prev : nullptr, m->x);
+  if (streaming) MHIP(hipMemcpyAsync(m->s_up_prev, m->e0 + (size_t)(T - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- transformer ----
+  const int keep = std::min<int>(c.window - 1, nh + (int)L1);   // history rows the next call can still see
+  const int cur = streaming ? m->s_cur : 0;
+  for (int l = 0; l < c.layers; ++l) {
+    float* hist = m->hist[cur][l];
+    hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln1_w[l], m->w.ln1_b[l], H, c.norm_eps, m->hn);
+    MLCK(gemm(m, m->hn, H, m->w.wqkv[l], 3 * A, H, L1, m->qkv, 3 * A));
+    hipLaunchKernelGGL(mimi_rope_kernel, dim3(nblk(L1 * 2 * c.heads * (c.head_dim / 2))), dim3(256), 0, st, m->qkv, (int)L1, c.heads, c.head_dim, c.rope_theta, pos0);
+    hipLaunchKernelGGL(mimi_kv_append_kernel, dim3(nblk(L1 * 2 * A)), dim3(256), 0, st, m->qkv, hist + (size_t)nh * 2 * A, L1, A);
+    hipLaunchKernelGGL(mimi_attn_kernel, dim3((unsigned)L1, c.heads), dim3(64), (size_t)(c.head_dim + c.window) * sizeof(float), st, m->qkv, hist, nh,
+                       c.heads, c.head_dim, c.window, m->ao);
+    if (streaming && keep > 0)
+      hipLaunchKernelGGL(mimi_rows_copy_kernel, dim3(nblk((size_t)keep * 2 * A)), dim3(256), 0, st, hist + (size_t)(nh + L1 - keep) * 2 * A,
+                         m->hist[cur ^ 1][l], (size_t)keep * 2 * A);
+    MLCK(gemm(m, m->ao, A, m->w.wo[l], H, A, L1, m->tmp, H));
+    hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls1[l], L1 * H, H);
+    hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln2_w[l], m->w.ln2_b[l], H, c.norm_eps, m->hn);
+    MLCK(gemm(m, m->hn, H, m->w.w1[l], F, H, L1, m->ff, F));
+    hipLaunchKernelGGL(mimi_gelu_kernel, dim3(nblk(L1 * F)), dim3(256), 0, st, m->ff, L1 * F);
+    MLCK(gemm(m, m->ff, F, m->w.w2[l], H, F, L1, m->tmp, H));
+    hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls2[l], L1 * H, H);
+  }
+  // ---- SEANet decoder ----
+  int ch = c.num_filters << c.n_ratios;
+  size_t L = L1;
+  float *cbuf = m->bufa, *nxt = m->bufb;
+  if (int r = conv1d(m, m->x, L, H, c.kernel_size, 0, m->w.conv0_w, ch, m->w.conv0_b, nullptr, 0, cbuf, ch, cache())) return r;
+  for (int i = 0; i < c.n_ratios; ++i) {
+    const int rr = c.ratios[i], co = ch / 2, hid = co / c.compress;
+    // ELU -> transposed conv (kernel 2 r, stride r, causal trim): one GEMM, K = 2 C_in, N = r C_out, output row q = positions r q ..
+    float* cc = cache();
+    if (int r = pad_in(m, cc, ch)) return r;
+    hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cbuf, m->pad + (size_t)PADR * ch, L * ch, 1);
+    if (int r = pad_out(m, cc, ch, L)) return r;
+    MLCK(gemm(m, m->pad + (size_t)(PADR - 1) * ch, ch, m->w.up_w[i], rr * co, 2 * ch, L, m->scr, rr * co));
+    hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * rr * co)), dim3(256), 0, st, m->scr, rr * co, m->w.up_b[i], co, nullptr, rr * co, L, 0, nxt, rr * co);
+    L *= rr;
+    std::swap(cbuf, nxt);   // cbuf = [L][co]
+    // residual block: x + conv1(ELU(conv3(ELU(x))))
+    float* hb = nxt;        // [L][hid]
+    if (int r = conv1d(m, cbuf, L, co, c.res_kernel_size, 1, m->w.res1_w[i], hid, m->w.res1_b[i], nullptr, 1, hb, hid, cache())) return r;
+    {
+      const int Np = pad128(co);
+      MLCK(gemm(m, hb, hid, m->w.res2_w[i], Np, hid, L, m->scr, Np));
+      hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * co)), dim3(256), 0, st, m->scr, Np, m->w.res2_b[i], co, cbuf, co, L, 0, cbuf, co);
+    }
+    ch = co;
+  }
+  // ---- ELU, last convolution to one channel ----
+  float* cc = cache();
+  if (int r = pad_in(m, cc, ch)) return r;
+  hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cbuf, m->pad + (size_t)PADR * ch, L * ch, 1);
+  if (int r = pad_out(m, cc, ch, L)) return r;
+  hipLaunchKernelGGL(mimi_last_conv_kernel, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, st, m->pad + (size_t)(PADR - (c.last_kernel_size - 1)) * ch, m->w.last_w,
+                     m->w.last_b, ch, c.last_kernel_size, L, audio);
+  MHIP(hipGetLastError());
+  if (streaming) {
+    m->s_frames += T;
+    m->s_nh = keep;
+    m->s_cur ^= 1;
+  }
+  return 0;
+}
+
 extern "C" int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* audio) {
   if (!m || !m->bound || !codes || !audio) return mfail(CSM_ERR_ARG, "null argument / weights not bound");
   const csm_mimi_config_t& c = m->c;
   if (B < 1 || T < 1 || T > c.max_frames) return mfail(CSM_ERR_CAPACITY, "T = %d outside 1..max_frames %d", T, c.max_frames);
-  hipStream_t st = m->stream;
-  const int H = c.hidden, D = c.codebook_dim, A = c.heads * c.head_dim, F = c.ffn;
   size_t spf = (size_t)c.up_stride;
   for (int i = 0; i < c.n_ratios; ++i) spf *= c.ratios[i];
-  for (int b = 0; b < B; ++b) {
-    const int64_t* cb = codes + (size_t)b * c.n_q * T;
-    // ---- split RVQ decode + the two 1x1 output projections (one GEMM, K = 2 D) ----
-    hipLaunchKernelGGL(mimi_rvq_gather_kernel, dim3(T), dim3(256), 0, st, cb, m->w.embed, c.n_q, c.n_sem, c.codebook_size, D, T, m->q2);
-    MLCK(gemm(m, m->q2, 2 * D, m->w.out_proj, H, 2 * D, T, m->e0, H));
-    // ---- upsample to the transformer's rate ----
-    const size_t L1 = (size_t)T * c.up_stride;
-    hipLaunchKernelGGL(mimi_upsample_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->e0, m->w.upsample, T, H, c.up_stride, m->x);
-    // ---- transformer ----
-    for (int l = 0; l < c.layers; ++l) {
-      hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln1_w[l], m->w.ln1_b[l], H, c.norm_eps, m->hn);
-      MLCK(gemm(m, m->hn, H, m->w.wqkv[l], 3 * A, H, L1, m->qkv, 3 * A));
-      hipLaunchKernelGGL(mimi_rope_kernel, dim3(nblk(L1 * 2 * c.heads * (c.head_dim / 2))), dim3(256), 0, st, m->qkv, (int)L1, c.heads, c.head_dim, c.rope_theta);
-      hipLaunchKernelGGL(mimi_attn_kernel, dim3((unsigned)L1, c.heads), dim3(64), (size_t)(c.head_dim + c.window) * sizeof(float), st, m->qkv, (int)L1, c.heads,
-                         c.head_dim, c.window, m->ao);
-      MLCK(gemm(m, m->ao, A, m->w.wo[l], H, A, L1, m->tmp, H));
-      hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls1[l], L1 * H, H);
-      hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)L1), dim3(256), 0, st, m->x, m->w.ln2_w[l], m->w.ln2_b[l], H, c.norm_eps, m->hn);
-      MLCK(gemm(m, m->hn, H, m->w.w1[l], F, H, L1, m->ff, F));
-      hipLaunchKernelGGL(mimi_gelu_kernel, dim3(nblk(L1 * F)), dim3(256), 0, st, m->ff, L1 * F);
-      MLCK(gemm(m, m->ff, F, m->w.w2[l], H, F, L1, m->tmp, H));
-      hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(L1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls2[l], L1 * H, H);
-    }
-    // ---- SEANet decoder ----
-    int ch = c.num_filters << c.n_ratios;
-    size_t L = L1;
-    float *cur = m->bufa, *nxt = m->bufb;
-    if (int r = conv1d(m, m->x, L, H, c.kernel_size, 0, m->w.conv0_w, ch, m->w.conv0_b, nullptr, 0, cur, ch)) return r;
-    for (int i = 0; i < c.n_ratios; ++i) {
-      const int rr = c.ratios[i], co = ch / 2, hid = co / c.compress;
-      // ELU -> transposed conv (kernel 2 r, stride r, causal trim): one GEMM, K = 2 C_in, N = r C_out, output row q = positions r q ..
-      MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * ch * sizeof(float), st));
-      hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cur, m->pad + (size_t)PADR * ch, L * ch, 1);
-      MLCK(gemm(m, m->pad + (size_t)(PADR - 1) * ch, ch, m->w.up_w[i], rr * co, 2 * ch, L, m->scr, rr * co));
-      hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * rr * co)), dim3(256), 0, st, m->scr, rr * co, m->w.up_b[i], co, nullptr, rr * co, L, 0, nxt, rr * co);
-      L *= rr;
-      std::swap(cur, nxt);   // cur = [L][co]
-      // residual block: x + conv1(ELU(conv3(ELU(x))))
-      float* hb = nxt;       // [L][hid]
-      if (int r = conv1d(m, cur, L, co, c.res_kernel_size, 1, m->w.res1_w[i], hid, m->w.res1_b[i], nullptr, 1, hb, hid)) return r;
-      {
-        const int Np = pad128(co);
-        MLCK(gemm(m, hb, hid, m->w.res2_w[i], Np, hid, L, m->scr, Np));
-        hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk(L * co)), dim3(256), 0, st, m->scr, Np, m->w.res2_b[i], co, cur, co, L, 0, cur, co);
-      }
-      ch = co;
-    }
-    // ---- ELU, last convolution to one channel ----
-    MHIP(hipMemsetAsync(m->pad, 0, (size_t)PADR * ch * sizeof(float), st));
-    hipLaunchKernelGGL(mimi_elu_copy_kernel, dim3(nblk(L * ch)), dim3(256), 0, st, cur, m->pad + (size_t)PADR * ch, L * ch, 1);
-    hipLaunchKernelGGL(mimi_last_conv_kernel, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, st, m->pad + (size_t)(PADR - (c.last_kernel_size - 1)) * ch, m->w.last_w,
-                       m->w.last_b, ch, c.last_kernel_size, L, audio + (size_t)b * T * spf);
-    MHIP(hipGetLastError());
-  }
-  MHIP(hipStreamSynchronize(st));
+  for (int b = 0; b < B; ++b)
+    if (int r = decode_one(m, codes + (size_t)b * c.n_q * T, T, audio + (size_t)b * T * spf, false)) return r;
+  MHIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// ---- streaming decode (modeling_mimi.py:1388-1406 with decoder_past_key_values, MimiConv1dPaddingCache :73-166): one
+// sequence decoded a few frames at a time; the concatenated output equals one decode of the whole sequence ----
+extern "C" int csm_mimi_stream_reset(csm_mimi_t* m) {
+  if (!m) return mfail(CSM_ERR_ARG, "null argument");
+  m->s_frames = m->s_nh = m->s_cur = 0;
+  MHIP(hipMemsetAsync(m->s_up_prev, 0, (size_t)m->c.hidden * sizeof(float), m->stream));
+  int chs = m->c.num_filters << m->c.n_ratios;
+  std::vector<int> cins{m->c.hidden};
+  for (int i = 0; i < m->c.n_ratios; ++i) { cins.push_back(chs); cins.push_back(chs / 2); chs /= 2; }
+  cins.push_back(chs);
+  for (size_t i = 0; i < cins.size(); ++i) MHIP(hipMemsetAsync(m->s_conv[i], 0, (size_t)PADR * cins[i] * sizeof(float), m->stream));
+  MHIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+extern "C" int csm_mimi_stream_decode(csm_mimi_t* m, const int64_t* codes, int T, float* audio) {
+  if (!m || !m->bound || !codes || !audio) return mfail(CSM_ERR_ARG, "null argument / weights not bound");
+  if (T < 1 || T > m->c.max_frames) return mfail(CSM_ERR_CAPACITY, "T = %d outside 1..max_frames %d", T, m->c.max_frames);
+  if (int r = decode_one(m, codes, T, audio, true)) return r;
+  MHIP(hipStreamSynchronize(m->stream));
   return 0;
 }

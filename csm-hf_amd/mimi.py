@@ -282,6 +282,8 @@ class MimiDecoder:
         self.lib.csm_mimi_destroy.argtypes = [C.c_void_p]
         self.lib.csm_mimi_bind_weights.argtypes = [C.c_void_p, C.POINTER(_MimiWeights)]
         self.lib.csm_mimi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.csm_mimi_stream_reset.argtypes = [C.c_void_p]
+        self.lib.csm_mimi_stream_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         if cfg.num_hidden_layers > _MAX_LAYERS or len(cfg.upsampling_ratios) > _MAX_RATIOS:
             raise ValueError("too many transformer layers / upsampling ratios for csm_mimi_config_t")
         c = _MimiCfg(abi_version=ABI_VERSION, n_q=cfg.num_quantizers, n_sem=cfg.num_semantic_quantizers,
@@ -329,6 +331,30 @@ class MimiDecoder:
         torch.cuda.synchronize(self.device)
         with torch.cuda.device(self.device):
             self._ck(self.lib, self.lib.csm_mimi_decode(self._h, codes.data_ptr(), B, T, out.data_ptr()))
+        return out
+
+    # ---- streaming: one sequence, a few frames per call (e.g. every frame `generate_frame` returns) -----------------
+    def stream_reset(self):
+        self._ck(self.lib, self.lib.csm_mimi_stream_reset(self._h))
+
+    def stream_decode(self, audio_codes: torch.Tensor) -> torch.Tensor:
+        """`audio_codes` [n_q, T] or [1, n_q, T]: the NEW frames of the stream; returns their samples `[1, 1, T * samples_per_frame]`.
+        The chunks of a stream concatenate to `decode()` of the whole sequence (the handle keeps the transformer's K/V window
+        and every convolution's left context, like transformers' decoder_past_key_values + padding cache)."""
+        if audio_codes.dim() == 3:
+            if audio_codes.shape[0] != 1:
+                raise ValueError("a stream is one sequence")
+            audio_codes = audio_codes[0]
+        if audio_codes.dim() != 2 or audio_codes.shape[0] != self.cfg.num_quantizers:
+            raise ValueError(f"audio_codes must be [{self.cfg.num_quantizers}, T]")
+        T = audio_codes.shape[1]
+        if T < 1 or T > self.max_frames:
+            raise ValueError(f"T = {T} outside 1..{self.max_frames} (max_frames)")
+        codes = audio_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(1, 1, T * self.cfg.samples_per_frame, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib, self.lib.csm_mimi_stream_decode(self._h, codes.data_ptr(), T, out.data_ptr()))
         return out
 
     def close(self):

@@ -195,6 +195,11 @@ int csm_mimi_destroy(csm_mimi_t* m);
 int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w);   /* borrowed pointers */
 /* codes [B][n_q][T] int64 (device) -> audio [B][T * samples_per_frame] fp32 (device); samples_per_frame = up_stride * prod(ratios) */
 int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* audio);
+/* streaming: one sequence a few frames at a time (codes [n_q][T] of the NEW frames); the handle keeps the transformer's K/V
+ * window and every convolution's left context (transformers: decoder_past_key_values + MimiConv1dPaddingCache,
+ * modeling_mimi.py:73-166, 1388-1406), so the concatenated chunks equal one csm_mimi_decode of the whole sequence */
+int csm_mimi_stream_reset(csm_mimi_t* m);
+int csm_mimi_stream_decode(csm_mimi_t* m, const int64_t* codes, int T, float* audio);
 
 /* ---- continuous batching (no reference counterpart): a new utterance takes over batch row
  * `row` of the running batch between two frame-steps.  ids [S][C+1] / mask [S][C+1] on the device; S <= the batch's

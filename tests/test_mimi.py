@@ -105,6 +105,23 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
         assert wav.shape == (2, 1, 4 * 1920) and bool(torch.isfinite(wav).all())
         assert rel_max(wav.cpu(), MO.decode(sd, cfg, frames.permute(0, 2, 1).cpu())) < 1e-4
         m._drop_engine()
+    # streaming: the chunks of a stream (1, 1, 2, 5, ... frames; the tiny window of 6 positions wraps many times) concatenate
+    # to the one-shot decode -- K/V window, rotary positions and every convolution's left context carried in the handle
+    Ts = 23 if name == "tiny" else 9
+    c = torch.randint(0, cfg.codebook_size, (1, cfg.num_quantizers, Ts), generator=gen).to("cuda:0")
+    whole = dec.decode(c)
+    for chunks in ((1, 1, 2, 5, 3, 1, 4, 6), (Ts,), (2,) * 20):
+        dec.stream_reset()
+        parts, t = [], 0
+        for n in chunks:
+            n = min(n, Ts - t)
+            if n <= 0:
+                break
+            parts.append(dec.stream_decode(c[0, :, t:t + n]))
+            t += n
+        assert t == Ts
+        got = torch.cat(parts, dim=-1)
+        assert rel_max(got.cpu(), whole.cpu()) < 2e-6, chunks
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, cfg.num_quantizers, 65, dtype=torch.long))          # beyond max_frames
     with pytest.raises(ValueError):

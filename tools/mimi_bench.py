@@ -29,6 +29,18 @@ for T in frames:
         ts.append(time.perf_counter() - t0)
     sec = T / 12.5
     print(f"{T:4d} frames = {sec:6.2f} s of audio ({out.shape[-1]} samples): {min(ts) * 1e3:7.2f} ms  = {sec / min(ts):7.0f} x real time", flush=True)
+# streaming: one frame per call, the state a real-time stream carries (what follows every generate_frame)
+dec.stream_reset()
+codes = torch.randint(0, cfg.codebook_size, (cfg.num_quantizers, 64), generator=g).to("cuda:0")
+ts = []
+for t in range(64):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec.stream_decode(codes[:, t:t + 1])
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+ts = sorted(ts[8:])
+print(f"streaming, 1 frame (80 ms of audio) per call: median {ts[len(ts) // 2] * 1e3:.2f} ms per call = {0.08 / ts[len(ts) // 2]:.0f} x real time", flush=True)
 try:
     from transformers import MimiConfig, MimiModel
     m = MimiModel(MimiConfig()).eval()
