@@ -83,4 +83,15 @@ python tools/pmc_summary.py $O/pmc_fetch_size/r02_results.db 6 $O/pmc_write_size
 rm -rf $O/pmc_fetch_size $O/pmc_write_size
 timeout 300 python tools/streamer_probe.py > $O/streamer_probe.txt 2>&1
 for p in 1 220 512; do echo "== pool_mb=$p nt=0"; timeout 200 python tools/bench_gemv.py pool_mb=$p nt=0 2>/dev/null | tail -10; done > $O/gemv_pool_microbench.txt 2>&1
+# "next" rows: Mimi decode (f-2), continuous batching (f-4), the end-to-end streaming loop; the launch-chain micro-benchmark
+timeout 300 python tools/mimi_bench.py 2>&1 | grep -v "amdgpu\|rope_param" > $O/mimi_bench.txt
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/mimi -o mimi -- python $R/tools/mimi_bench.py 200 > /dev/null 2>&1
+cd $R
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/mimi_bench.py 200   (6 decodes of 200 frames = 16 s of audio each, kyutai/mimi shape, fp32)"; echo
+  python tools/rocprof_summary.py $O/mimi/mimi_results.db 6 2>/dev/null | grep -v "at::native" | head -30; } > $O/mimi_kernel_stats.md
+rm -rf $O/mimi
+timeout 400 python tools/serve_bench.py 64 16 2>&1 | grep -v amdgpu > $O/serve_bench.txt
+timeout 300 python tools/stream_demo.py 200 512 2>&1 | grep -v amdgpu | tail -1 > $O/stream_demo.txt
+(cd tools/ubench && hipcc --offload-arch=gfx950 -O3 flagchain.hip -o flagchain 2>/dev/null; timeout 120 ./flagchain) > $O/flagchain_ubench.txt 2>&1
 ls -la $O | head -40; cat $O/bench.json | head -5
