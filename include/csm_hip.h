@@ -21,6 +21,7 @@
 #ifndef CSM_HIP_H
 #define CSM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -115,3 +115,19 @@ def test_kv_start_validation():
     m[0, 3] = 0
     with pytest.raises(ValueError):
         CSMModel._kv_starts(m, 2, 5)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/csm_hip.h is the drop-in boundary: it must compile as C (no C++ / torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "csm_hip.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
