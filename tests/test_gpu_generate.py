@@ -402,6 +402,31 @@ def test_csm1b_batch16_rows_equal_solo_and_graph_equals_eager(csm1b_bf16):
     assert min(agree) >= 32 * 2 and sum(a == 32 * 6 for a in agree) >= 2, agree
 
 
+def test_csm1b_continuous_batching_on_the_matrix_core_path(csm1b_bf16):
+    """csm_prefill_slot on csm-1b: a batch of 4 rows (matrix-core kernels on activation planes) serves 7 utterances; the
+    ones that take over a row mid-batch give the token stream of their solo run wherever the margin allows -- the same
+    rule as the batched-rows test above (two kernel families, fp32-class differences)."""
+    from csm_hf_amd import ContinuousBatcher
+    m = csm1b_bf16
+    cfg = m.config
+    reqs = []
+    for i, (T, budget) in enumerate([(40, 4), (33, 9), (36, 3), (28, 6), (30, 5), (25, 4), (31, 3)]):
+        ids, mask = synth_context(cfg, 1, T // 4, T - T // 4, seed=900 + i)
+        reqs.append((ids[0], mask[0], budget))
+    cb = ContinuousBatcher(m, batch_size=4, topk=1, check_every=3)
+    rid = [cb.submit(a, b, max_new_frames=n) for a, b, n in reqs]
+    out = cb.run()
+    assert sorted(out) == rid and cb.joined_mid_batch >= 3
+    agree, full = [], 0
+    for r, (ids, mask, budget) in zip(rid, reqs):
+        solo = m.generate(ids[None].to(DEV), mask[None].to(DEV), max_new_frames=budget, topk=1, stop_on_all_zeros=False).cpu()[0]
+        assert out[r].shape == solo.shape
+        same = (solo == out[r]).reshape(-1)
+        agree.append(int((~same).nonzero()[0]) if not bool(same.all()) else same.numel())
+        full += bool(same.all())
+    assert min(agree) >= 32 and full >= 5, agree
+
+
 @pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (32, {}), (40, {}), (70, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
 def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
     """ragged batches (M < 16 on the matrix-core kernel; 18 and 32 rows = one launch of the 32-row kernel on planes,
