@@ -131,3 +131,10 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check: __graft_entry__.build() compiles (or finds) the library and its ABI assertion tracks
+    engine.ABI_VERSION -- it asserted a literal 3 after the ABI had moved to 4 and failed the check for a while"""
+    import __graft_entry__ as g
+    g.build()
