@@ -3,14 +3,17 @@
 #define CSM_ARGS_ONLY 1   // gemm.h: argument structs and launch_gemm only (the kernels live in launchers.hip)
 #include "../../include/csm_hip.h"
 #include "gemm.h"
+#include "gemv.h"
 #include "mimi.h"
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 int csm_set_error(int code, const char* msg);   // engine.hip: stores the message csm_last_error() returns
+int gemv_configure_all();                       // gemv.hip: dynamic-LDS limits of the skinny-GEMM kernels (once per process)
 
 static int mfail(int code, const char* fmt, ...) {
   char buf[512];
@@ -40,6 +43,7 @@ struct csm_mimi {
   int s_frames = 0, s_nh = 0, s_cur = 0;
   float* s_up_prev = nullptr;
   std::vector<float*> s_conv;
+  bool skinny = true;   // CSM_MIMI_SKINNY=0 at create: every GEMM on the 128 x 128 tile (A/B measurements, bitwise stream == one-shot)
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
 
@@ -112,6 +116,9 @@ extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
         m->hist[pp].push_back(h);
       }
     if (!r) r = malloc_f(m, &m->s_up_prev, (size_t)c.hidden);
+    const char* sk = getenv("CSM_MIMI_SKINNY");
+    m->skinny = !(sk && sk[0] == '0');
+    if (!r && gemv_configure_all()) r = mfail(CSM_ERR_STATE, "skinny-GEMM kernel configuration failed");
     for (size_t i = 0; i < cins.size() && !r; ++i) {
       float* q = nullptr;
       r = malloc_f(m, &q, (size_t)PADR * cins[i]);
@@ -145,8 +152,19 @@ extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w)
   return 0;
 }
 
-// C[R][N] = A (rows of K floats, lda apart) @ W[N][K]^T, fp32 weights, exact-fp32 MFMA
+// C[R][N] = A (rows of K floats, lda apart) @ W[N][K]^T, fp32 weights, exact-fp32 MFMA.
+// R <= 4 (a streaming call of one or two frames: the transformer, the first convolution and the first transposed
+// convolution see 2 T rows): the 128 x 128 tile would be N / 128 = 4..32 workgroups, each pulling its whole weight panel
+// through one CU -- measured 34 such GEMMs = 3.1 of the 3.9 ms of a one-frame call.  Those go to the weight-streaming
+// skinny GEMM of the frame generator (gemv.h: fp32 FMA, the weight stream spread over the chip): 1.2 ms per call.  Its
+// summation order is not the MFMA chain's, so a stream is 2.4e-6 of the peak away from the one-shot decode (bitwise equal
+// with CSM_MIMI_SKINNY=0); both stay within the codec's 1e-4 of the reference implementation.
 static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
+  if (R <= 4 && m->skinny && K % 8 == 0) {
+    GemvArgs a{};
+    a.W = W; a.N = N; a.K = K; a.x = A; a.ldx = lda; a.out = C; a.ldo = ldc; a.nt = 1;
+    return launch_gemv(m->stream, CSM_DTYPE_F32, CSM_DTYPE_F32, (int)R, PRO_PLAIN, EPI_STORE, a);
+  }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
   return launch_gemm(m->stream, CSM_DTYPE_F32, GEPI_STORE, g);

@@ -121,9 +121,57 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
             t += n
         assert t == Ts
         got = torch.cat(parts, dim=-1)
-        assert rel_max(got.cpu(), whole.cpu()) < 2e-6, chunks
+        # calls of one or two frames run their 2 T-row GEMMs on the skinny-GEMM kernels (fp32 FMA order, not the MFMA chain's):
+        # measured 2.4e-6 of the peak over 160 frames at the full shape; bitwise equal with CSM_MIMI_SKINNY=0 (test below)
+        assert rel_max(got.cpu(), whole.cpu()) < 1e-5, chunks
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, cfg.num_quantizers, 65, dtype=torch.long))          # beyond max_frames
     with pytest.raises(ValueError):
         dec.decode(torch.full((1, cfg.num_quantizers, 2), cfg.codebook_size, dtype=torch.long))
     dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
+    """one- and two-frame streaming calls put their 2 T-row GEMMs on the weight-streaming skinny GEMM (3.9 -> 1.2 ms per
+    frame at the kyutai/mimi shape).  Pinned three ways: against the ORACLE at the codec's 1e-4 of the peak (the anchor),
+    against the one-shot decode at 1e-5 (fp32 summation order of the two GEMM kernels), and -- with the skinny path
+    switched off at create -- bitwise against the one-shot decode (same kernel for every row count: same sums)."""
+    from csm_hf_amd import MimiDecoder
+    cfg = CASES[name]
+    sd = synth_mimi_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(11)
+    Ts = 40 if name == "tiny" else 12
+    c = torch.randint(0, cfg.codebook_size, (1, cfg.num_quantizers, Ts), generator=gen)
+    want = MO.decode(sd, cfg, c)
+    cd = c.to("cuda:0")
+
+    def stream(dec, chunks):
+        dec.stream_reset()
+        parts, t = [], 0
+        for n in chunks:
+            n = min(n, Ts - t)
+            if n <= 0:
+                break
+            parts.append(dec.stream_decode(cd[0, :, t:t + n]).clone())
+            t += n
+        assert t == Ts
+        return torch.cat(parts, dim=-1)
+
+    fast = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
+    monkeypatch.setenv("CSM_MIMI_SKINNY", "0")
+    plain = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
+    monkeypatch.delenv("CSM_MIMI_SKINNY")
+    whole = fast.decode(cd)
+    assert torch.equal(whole, plain.decode(cd))          # Ts > 2 frames: no GEMM of the one-shot decode has <= 4 rows
+    differs = False
+    for chunks in ((1,) * Ts, (2, 1) * Ts):
+        a, b = stream(fast, chunks), stream(plain, chunks)
+        assert rel_max(a.cpu(), want) < 1e-4, chunks
+        assert rel_max(a.cpu(), whole.cpu()) < 1e-5, chunks
+        assert torch.equal(b, whole), chunks
+        differs |= not torch.equal(a, b)
+    assert differs                                        # the switch selects a different kernel: the two paths are not one
+    fast.close()
+    plain.close()
