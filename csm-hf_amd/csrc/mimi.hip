@@ -43,7 +43,8 @@ struct csm_mimi {
   int s_frames = 0, s_nh = 0, s_cur = 0;
   float* s_up_prev = nullptr;
   std::vector<float*> s_conv;
-  bool skinny = true;   // CSM_MIMI_SKINNY=0 at create: every GEMM on the 128 x 128 tile (A/B measurements, bitwise stream == one-shot)
+  int skinny_rows = 16;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
+                          // every GEMM on the 128 x 128 tile: A/B measurements, bitwise stream == one-shot)
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
 
@@ -117,7 +118,7 @@ extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
       }
     if (!r) r = malloc_f(m, &m->s_up_prev, (size_t)c.hidden);
     const char* sk = getenv("CSM_MIMI_SKINNY");
-    m->skinny = !(sk && sk[0] == '0');
+    if (sk) m->skinny_rows = std::max(0, std::min(256, atoi(sk)));
     if (!r && gemv_configure_all()) r = mfail(CSM_ERR_STATE, "skinny-GEMM kernel configuration failed");
     for (size_t i = 0; i < cins.size() && !r; ++i) {
       float* q = nullptr;
@@ -153,17 +154,22 @@ extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w)
 }
 
 // C[R][N] = A (rows of K floats, lda apart) @ W[N][K]^T, fp32 weights, exact-fp32 MFMA.
-// R <= 4 (a streaming call of one or two frames: the transformer, the first convolution and the first transposed
-// convolution see 2 T rows): the 128 x 128 tile would be N / 128 = 4..32 workgroups, each pulling its whole weight panel
-// through one CU -- measured 34 such GEMMs = 3.1 of the 3.9 ms of a one-frame call.  Those go to the weight-streaming
-// skinny GEMM of the frame generator (gemv.h: fp32 FMA, the weight stream spread over the chip): 1.2 ms per call.  Its
-// summation order is not the MFMA chain's, so a stream is 2.4e-6 of the peak away from the one-shot decode (bitwise equal
-// with CSM_MIMI_SKINNY=0); both stay within the codec's 1e-4 of the reference implementation.
+// Few rows (a streaming call of T frames: the transformer, the first convolution and the first transposed convolution see
+// 2 T rows, the first residual block 16 T): the 128 x 128 tile would be N / 128 = 4..32 workgroups, each pulling its whole
+// weight panel through one CU -- measured 46 GEMMs = 3.4 of the 3.9 ms of a one-frame call.  GEMMs of <= skinny_rows rows
+// go to the weight-streaming skinny GEMM of the frame generator instead (gemv.h: fp32 FMA, <= 4 rows per launch, the
+// weight stream spread over the chip), in groups of 4 rows.  Measured per call of 1 / 2 / 4 / 8 frames: 4.0 / 4.1 / 4.1 /
+// 4.2 ms on the tile, 1.1 / 1.3 / 1.5 / 1.9 ms with a threshold of 16 rows; 64 rows measures the same as 16
+// (profiles/r02_mimi_stream_probe.txt).  The summation order is not the MFMA chain's: a stream is 2e-6 of the peak away
+// from the one-shot decode (bitwise equal with CSM_MIMI_SKINNY=0); both stay within the codec's 1e-4 of the reference.
 static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
-  if (R <= 4 && m->skinny && K % 8 == 0) {
-    GemvArgs a{};
-    a.W = W; a.N = N; a.K = K; a.x = A; a.ldx = lda; a.out = C; a.ldo = ldc; a.nt = 1;
-    return launch_gemv(m->stream, CSM_DTYPE_F32, CSM_DTYPE_F32, (int)R, PRO_PLAIN, EPI_STORE, a);
+  if (R <= (size_t)m->skinny_rows && K % 8 == 0) {   // groups of <= 4 rows, the weights streamed once per group
+    for (size_t m0 = 0; m0 < R; m0 += 4) {
+      GemvArgs a{};
+      a.W = W; a.N = N; a.K = K; a.x = A + m0 * lda; a.ldx = lda; a.out = C + m0 * ldc; a.ldo = ldc; a.nt = 1;
+      if (int r = launch_gemv(m->stream, CSM_DTYPE_F32, CSM_DTYPE_F32, (int)std::min<size_t>(4, R - m0), PRO_PLAIN, EPI_STORE, a)) return r;
+    }
+    return 0;
   }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;

@@ -121,8 +121,8 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
             t += n
         assert t == Ts
         got = torch.cat(parts, dim=-1)
-        # calls of one or two frames run their 2 T-row GEMMs on the skinny-GEMM kernels (fp32 FMA order, not the MFMA chain's):
-        # measured 2.4e-6 of the peak over 160 frames at the full shape; bitwise equal with CSM_MIMI_SKINNY=0 (test below)
+        # GEMMs of <= 16 rows (calls of up to 8 frames) run on the skinny-GEMM kernels (fp32 FMA order, not the MFMA chain's):
+        # measured 2.2e-6 of the peak over 160 frames at the full shape; bitwise equal with CSM_MIMI_SKINNY=0 (test below)
         assert rel_max(got.cpu(), whole.cpu()) < 1e-5, chunks
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, cfg.num_quantizers, 65, dtype=torch.long))          # beyond max_frames
@@ -134,15 +134,15 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny", "full"])
 def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
-    """one- and two-frame streaming calls put their 2 T-row GEMMs on the weight-streaming skinny GEMM (3.9 -> 1.2 ms per
-    frame at the kyutai/mimi shape).  Pinned three ways: against the ORACLE at the codec's 1e-4 of the peak (the anchor),
+    """streaming calls of a few frames put their GEMMs of <= 16 rows on the weight-streaming skinny GEMM (4.0 -> 1.1 ms per
+    one-frame call at the kyutai/mimi shape).  Pinned three ways: against the ORACLE at the codec's 1e-4 of the peak (the anchor),
     against the one-shot decode at 1e-5 (fp32 summation order of the two GEMM kernels), and -- with the skinny path
     switched off at create -- bitwise against the one-shot decode (same kernel for every row count: same sums)."""
     from csm_hf_amd import MimiDecoder
     cfg = CASES[name]
     sd = synth_mimi_state_dict(cfg, seed=0)
     gen = torch.Generator().manual_seed(11)
-    Ts = 40 if name == "tiny" else 12
+    Ts = 40 if name == "tiny" else 20          # > 16: see the one-shot comparison below
     c = torch.randint(0, cfg.codebook_size, (1, cfg.num_quantizers, Ts), generator=gen)
     want = MO.decode(sd, cfg, c)
     cd = c.to("cuda:0")
@@ -164,7 +164,9 @@ def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
     plain = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
     monkeypatch.delenv("CSM_MIMI_SKINNY")
     whole = fast.decode(cd)
-    assert torch.equal(whole, plain.decode(cd))          # Ts > 2 frames: no GEMM of the one-shot decode has <= 4 rows
+    # the smallest GEMM of a one-shot decode is the RVQ output projection with T rows: beyond 16 frames neither decoder
+    # uses the skinny path for it, so the two one-shot results are the same kernels on the same data
+    assert torch.equal(whole, plain.decode(cd))
     differs = False
     for chunks in ((1,) * Ts, (2, 1) * Ts):
         a, b = stream(fast, chunks), stream(plain, chunks)

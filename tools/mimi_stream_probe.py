@@ -15,13 +15,12 @@ got = torch.cat(parts, dim=-1)
 peak = float(whole.abs().max())
 print(f"CSM_MIMI_SKINNY={os.environ.get('CSM_MIMI_SKINNY', '1')}: "
       f"160 frames streamed one by one vs one-shot decode: max |diff| / peak = {float((got - whole).abs().max()) / peak:.3e}", flush=True)
-dec.stream_reset()
-for t in range(10):
-    dec.stream_decode(codes[0, :, t:t + 1])
-ts = []
-for t in range(10, 150):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    dec.stream_decode(codes[0, :, t:t + 1])
-    ts.append(time.perf_counter() - t0)
-ts.sort()
-print(f"   one frame (80 ms of audio) per call: median {ts[len(ts) // 2] * 1e3:.3f} ms, min {ts[0] * 1e3:.3f} ms", flush=True)
+for T in (1, 2, 4, 8):
+    dec.stream_reset()
+    ts = []
+    for i in range(160 // T):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dec.stream_decode(codes[0, :, i * T:(i + 1) * T])
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[len(ts) // 4:])
+    print(f"   {T} frame(s) ({80 * T} ms of audio) per call: median {ts[len(ts) // 2] * 1e3:.3f} ms, min {ts[0] * 1e3:.3f} ms", flush=True)
