@@ -140,6 +140,7 @@ struct csm_engine {
   size_t loss_lab_n = 0, loss_rows_n = 0;
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
+  int prefill_splitk_max = 8;   // most K splits of a residual prefill GEMM (the partials buffer holds 4 at max_prefill_rows: more only for fewer rows)
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
@@ -517,6 +518,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
+  else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
@@ -951,7 +953,9 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
   // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
   // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
   const bool can_split = allow_split && pl && e->prefill_splitk && e->p_part && R <= 4096;
-  int ks_o = can_split ? prefill_ksplit((int)R, H, nq * hd) : 1, ks_d = can_split ? prefill_ksplit((int)R, H, F) : 1;
+  // p_part holds 4 splits of max_prefill_rows rows: a shorter prefill may split further
+  const int ks_cap = (int)std::min<size_t>((size_t)e->prefill_splitk_max, 4 * (size_t)e->cfg.max_prefill_rows / R);
+  int ks_o = can_split ? prefill_ksplit((int)R, H, nq * hd, ks_cap) : 1, ks_d = can_split ? prefill_ksplit((int)R, H, F, ks_cap) : 1;
   if ((one || e->gemm_wide_exact) && e->gemm_wide && can_split && H % 256 == 0 && !e->tiled.empty()) {
     // one-plane activations: 128 x 256 tiles (gemm_wide_kernel) when they, times a K split that leaves each split at
     // least 16 k-steps, fill the chip; otherwise the 64 x 64 split-K choice above stands

@@ -45,11 +45,11 @@ struct GemmArgs {
 };
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64
-static inline int prefill_ksplit(int R, int N, int K) {
+static inline int prefill_ksplit(int R, int N, int K, int cap = 4) {
   const long tiles64 = (long)((R + 63) / 64) * (N / 64);
   if (((long)((R + 127) / 128) * (N / 128)) >= 256 || tiles64 >= 768) return 1;
   int s = (int)((1024 + tiles64 - 1) / tiles64);
-  if (s > 4) s = 4;
+  if (s > cap) s = cap;
   while (s > 1 && (K % (64 * s))) --s;
   return s;
 }
