@@ -94,4 +94,15 @@ rm -rf $O/mimi
 timeout 400 python tools/serve_bench.py 64 16 2>&1 | grep -v amdgpu > $O/serve_bench.txt
 timeout 300 python tools/stream_demo.py 200 512 2>&1 | grep -v amdgpu | tail -1 > $O/stream_demo.txt
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 flagchain.hip -o flagchain 2>/dev/null; timeout 120 ./flagchain) > $O/flagchain_ubench.txt 2>&1
+# Mimi streaming calls by the skinny-GEMM row threshold; a short one-shot decode per kernel; short-context prefill by the K-split cap;
+# phase knock-outs of the square-tile prefill GEMM
+for sk in 16 4 0 64; do CSM_MIMI_SKINNY=$sk timeout 200 python tools/mimi_stream_probe.py 2>&1 | grep -v amdgpu | tail -5; done > $O/mimi_stream_probe.txt
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/m25 -o m -- python $R/tools/mimi_short_profile.py > /dev/null 2>&1
+cd $R
+{ echo "# rocprofv3 --kernel-trace --stats -- python tools/mimi_short_profile.py   (45 one-shot decodes of 25 frames, kyutai/mimi shape)"; echo
+  python tools/rocprof_summary.py $O/m25/m_results.db 45 2>/dev/null | head -30; } > $O/mimi_short_decode_kernel_stats.md
+rm -rf $O/m25
+timeout 600 python tools/splitk_sweep.py 2>&1 | grep "^ctx" > $O/prefill_splitk_sweep.txt
+(cd tools/ubench && hipcc --offload-arch=gfx950 -O3 gemmphase.hip -o gemmphase 2>/dev/null; timeout 120 ./gemmphase) > $O/gemmphase_ubench.txt 2>&1
 ls -la $O | head -40; cat $O/bench.json | head -5
