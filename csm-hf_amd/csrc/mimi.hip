@@ -43,7 +43,7 @@ struct csm_mimi {
   int s_frames = 0, s_nh = 0, s_cur = 0;
   float* s_up_prev = nullptr;
   std::vector<float*> s_conv;
-  int skinny_rows = 16;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
+  int skinny_rows = 64;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
                           // every GEMM on the 128 x 128 tile: A/B measurements, bitwise stream == one-shot)
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
@@ -159,8 +159,10 @@ extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w)
 // weight panel through one CU -- measured 46 GEMMs = 3.4 of the 3.9 ms of a one-frame call.  GEMMs of <= skinny_rows rows
 // go to the weight-streaming skinny GEMM of the frame generator instead (gemv.h: fp32 FMA, <= 4 rows per launch, the
 // weight stream spread over the chip), in groups of 4 rows.  Measured per call of 1 / 2 / 4 / 8 frames: 4.0 / 4.1 / 4.1 /
-// 4.2 ms on the tile, 1.1 / 1.3 / 1.5 / 1.9 ms with a threshold of 16 rows; 64 rows measures the same as 16
-// (profiles/r02_mimi_stream_probe.txt).  The summation order is not the MFMA chain's: a stream is 2e-6 of the peak away
+// 4.2 ms on the tile, 1.1 / 1.3 / 1.5 / 1.9 ms with a threshold of 16 rows, the same at 64
+// (profiles/r02_mimi_stream_probe.txt); a one-shot decode of 25 frames (50-row GEMMs) 4.5 ms at 16, 3.3-3.7 ms at 64 and
+// 128; 100 frames and more unchanged up to 128 and twice as slow at 256; one-frame calls 12 % slower at 128
+// (profiles/r02_mimi_threshold.txt).  Default 64.  The summation order is not the MFMA chain's: a stream is 2e-6 of the peak away
 // from the one-shot decode (bitwise equal with CSM_MIMI_SKINNY=0); both stay within the codec's 1e-4 of the reference.
 static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
   if (R <= (size_t)m->skinny_rows && K % 8 == 0) {   // groups of <= 4 rows, the weights streamed once per group
