@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
-  for (int k0 = 0; k0 < a.K; k0 += BK) {
+  // GEPI_PARTIAL (grid.y = ksplit, K % (32 ksplit) == 0): this workgroup's K range only, result to Cpart (see GemmArgs)
+  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
+  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0, kend = kbeg + kspan;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     // ---- stage A tile (fp32) -------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
             else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
           }
         } else if (r < a.R) {
-          if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
+          if (EPI == GEPI_PARTIAL) a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
+          else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
         }
       }

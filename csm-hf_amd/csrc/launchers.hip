@@ -144,6 +144,10 @@ static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
     case GEPI_STORE: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
     case GEPI_RESID: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_RESID>), dim3(grid), dim3(256), 0, st, a); break;
     case GEPI_SWIGLU: hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_SWIGLU>), dim3(grid), dim3(256), 0, st, a); break;
+    case GEPI_PARTIAL:
+      if (a.ksplit < 1 || a.K % (32 * a.ksplit) || !a.Cpart) return -1;
+      hipLaunchKernelGGL((gemm_f32mfma_kernel<WT, GEPI_PARTIAL>), dim3(grid, a.ksplit), dim3(256), 0, st, a);
+      break;
     default: return -1;
   }
   return (int)hipGetLastError();

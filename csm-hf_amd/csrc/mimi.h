@@ -41,6 +41,19 @@ __global__ __launch_bounds__(256) void mimi_upsample_kernel(const float* x, cons
   out[i] = v;
 }
 
+// split-K GEMM (gemm_f32mfma_kernel, GEPI_PARTIAL): C[r][n] = sum over the ks partial products [ks][R][N], fixed order
+__global__ __launch_bounds__(256) void mimi_splitk_reduce_kernel(const float* part, int ks, size_t stride, float* C, int ldc, int N, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + i * 4);
+  for (int s = 1; s < ks; ++s) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + i * 4);
+    v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+  }
+  const size_t e = i * 4, r = e / N;
+  *reinterpret_cast<f32x4*>(C + r * ldc + (e - r * N)) = v;
+}
+
 // nn.LayerNorm with bias (modeling_mimi.py:737-738): one workgroup per row
 __global__ __launch_bounds__(256) void mimi_layernorm_kernel(const float* x, const float* w, const float* b, int C, float eps, float* out) {
   __shared__ float red[4];

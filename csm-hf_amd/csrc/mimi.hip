@@ -43,7 +43,10 @@ struct csm_mimi {
   int s_frames = 0, s_nh = 0, s_cur = 0;
   float* s_up_prev = nullptr;
   std::vector<float*> s_conv;
-  int skinny_rows = 64;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
+  float* part = nullptr;               // split-K partial products of a GEMM with too few tiles (gemm())
+  size_t part_floats = (size_t)8 << 20;
+  bool splitk = true;                  // CSM_MIMI_SPLITK=0 at create: no K split (A/B; with CSM_MIMI_SKINNY=0: one kernel, one order)
+  int skinny_rows = 16;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
                           // every GEMM on the 128 x 128 tile: A/B measurements, bitwise stream == one-shot)
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
@@ -117,6 +120,9 @@ extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
         m->hist[pp].push_back(h);
       }
     if (!r) r = malloc_f(m, &m->s_up_prev, (size_t)c.hidden);
+    if (!r) r = malloc_f(m, &m->part, m->part_floats);
+    const char* sp = getenv("CSM_MIMI_SPLITK");
+    m->splitk = !(sp && sp[0] == '0');
     const char* sk = getenv("CSM_MIMI_SKINNY");
     if (sk) m->skinny_rows = std::max(0, std::min(256, atoi(sk)));
     if (!r && gemv_configure_all()) r = mfail(CSM_ERR_STATE, "skinny-GEMM kernel configuration failed");
@@ -154,16 +160,19 @@ extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w)
 }
 
 // C[R][N] = A (rows of K floats, lda apart) @ W[N][K]^T, fp32 weights, exact-fp32 MFMA.
-// Few rows (a streaming call of T frames: the transformer, the first convolution and the first transposed convolution see
-// 2 T rows, the first residual block 16 T): the 128 x 128 tile would be N / 128 = 4..32 workgroups, each pulling its whole
-// weight panel through one CU -- measured 46 GEMMs = 3.4 of the 3.9 ms of a one-frame call.  GEMMs of <= skinny_rows rows
-// go to the weight-streaming skinny GEMM of the frame generator instead (gemv.h: fp32 FMA, <= 4 rows per launch, the
-// weight stream spread over the chip), in groups of 4 rows.  Measured per call of 1 / 2 / 4 / 8 frames: 4.0 / 4.1 / 4.1 /
-// 4.2 ms on the tile, 1.1 / 1.3 / 1.5 / 1.9 ms with a threshold of 16 rows, the same at 64
-// (profiles/r02_mimi_stream_probe.txt); a one-shot decode of 25 frames (50-row GEMMs) 4.5 ms at 16, 3.3-3.7 ms at 64 and
-// 128; 100 frames and more unchanged up to 128 and twice as slow at 256; one-frame calls 12 % slower at 128
-// (profiles/r02_mimi_threshold.txt).  Default 64.  The summation order is not the MFMA chain's: a stream is 2e-6 of the peak away
-// from the one-shot decode (bitwise equal with CSM_MIMI_SKINNY=0); both stay within the codec's 1e-4 of the reference.
+// The codec's GEMMs have few rows (2 T in the transformer, the first convolution and the first transposed convolution):
+// on the plain 128 x 128 tile they are N / 128 = 4..32 workgroups, each walking K alone at one CU's fp32 matrix rate --
+// measured 83-87 % of a decode's kernel time at ~80 us per launch (profiles/r02_mimi_stream_kernel_stats.md,
+// r02_mimi_short_decode_kernel_stats.md).  Two remedies, both measured (profiles/r02_mimi_splitk.txt, r02_mimi_threshold.txt):
+//  * <= skinny_rows rows: the weight-streaming skinny GEMM of the frame generator (gemv.h: fp32 FMA, <= 4 rows per
+//    launch, weights spread over the chip), in groups of 4 rows: a one-frame streaming call 4.0 -> 0.8-1.0 ms;
+//  * more rows but fewer than 128 tiles: K split over grid.y, partial products summed in fixed order
+//    (mimi_splitk_reduce_kernel): one-shot decodes of 50 / 100 / 200 / 500 frames 5.2 / 5.5 / 6.3 / 9.1 -> 2.1 / 2.5 /
+//    3.6 / 6.8 ms.
+// With the split available the best row threshold is 16 (swept 4 / 16 / 32 / 64: 25 frames one-shot 1.7 ms at 16, 3.4 ms
+// at 64; 4-frame calls 1.3 ms at 16, 1.6 ms at 4).  Neither path sums in the order of the unsplit MFMA chain: a stream is
+// ~2e-6 of the peak away from the one-shot decode (bitwise equal with CSM_MIMI_SKINNY=0 CSM_MIMI_SPLITK=0); everything
+// stays within the codec's 1e-4 of the reference implementation.
 static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
   if (R <= (size_t)m->skinny_rows && K % 8 == 0) {   // groups of <= 4 rows, the weights streamed once per group
     for (size_t m0 = 0; m0 < R; m0 += 4) {
@@ -175,6 +184,20 @@ static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int
   }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+  // too few 128 x 128 tiles to fill the chip (a decode of a few hundred frames: 2 T rows x N = 512..2048): split K over
+  // grid.y, partial products to m->part, summed in fixed order (deterministic).  Every split keeps >= 128 of K.
+  const size_t tiles = ((R + 127) / 128) * (size_t)(N / 128);
+  if (m->splitk && tiles < 128 && ldc % 4 == 0) {
+    int ks = 1;
+    while (ks < 16 && tiles * ks < 192 && K % (32 * ks * 2) == 0 && K / (ks * 2) >= 128 && (size_t)(ks * 2) * R * N <= m->part_floats) ks *= 2;
+    if (ks > 1) {
+      g.ksplit = ks; g.Cpart = m->part; g.part_stride = R * (size_t)N;
+      MLCK(launch_gemm(m->stream, CSM_DTYPE_F32, GEPI_PARTIAL, g));
+      const size_t total4 = R * (size_t)N / 4;
+      hipLaunchKernelGGL(mimi_splitk_reduce_kernel, dim3(nblk(total4)), dim3(256), 0, m->stream, m->part, ks, g.part_stride, C, ldc, N, total4);
+      return 0;
+    }
+  }
   return launch_gemm(m->stream, CSM_DTYPE_F32, GEPI_STORE, g);
 }
 

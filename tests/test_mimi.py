@@ -137,8 +137,8 @@ def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
     """GEMMs of few rows (streaming calls of a few frames, short one-shot decodes) run on the weight-streaming skinny GEMM
     (4.0 -> 1.0 ms per one-frame call at the kyutai/mimi shape).  Pinned three ways: against the ORACLE at the codec's 1e-4
     of the peak (the anchor), against the one-shot decode on the tile kernel at 1e-5 (fp32 summation order of the two GEMM
-    kernels), and -- with the skinny path switched off at create -- the stream bitwise against the one-shot decode (one
-    kernel for every row count: the same sums)."""
+    kernels), and -- with the skinny path and the K split switched off at create -- the stream bitwise against the one-shot
+    decode (one kernel and one summation order for every row count)."""
     from csm_hf_amd import MimiDecoder
     cfg = CASES[name]
     sd = synth_mimi_state_dict(cfg, seed=0)
@@ -162,9 +162,11 @@ def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
 
     fast = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
     monkeypatch.setenv("CSM_MIMI_SKINNY", "0")
+    monkeypatch.setenv("CSM_MIMI_SPLITK", "0")
     plain = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
     monkeypatch.delenv("CSM_MIMI_SKINNY")
-    whole = plain.decode(cd)                              # every GEMM on the 128 x 128 tile
+    monkeypatch.delenv("CSM_MIMI_SPLITK")
+    whole = plain.decode(cd)                              # every GEMM on the 128 x 128 tile, K walked in one piece
     assert rel_max(whole.cpu(), want) < 1e-4
     assert rel_max(fast.decode(cd).cpu(), want) < 1e-4   # short one-shot decodes take the skinny path too
     differs = False
