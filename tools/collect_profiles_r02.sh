@@ -104,5 +104,9 @@ cd $R
   python tools/rocprof_summary.py $O/m25/m_results.db 45 2>/dev/null | head -30; } > $O/mimi_short_decode_kernel_stats.md
 rm -rf $O/m25
 timeout 600 python tools/splitk_sweep.py 2>&1 | grep "^ctx" > $O/prefill_splitk_sweep.txt
+for sp in 1 0; do echo "== CSM_MIMI_SPLITK=$sp"; for T in 25 50 100; do CSM_MIMI_SPLITK=$sp timeout 200 python tools/mimi_short_profile.py $T 2>&1 | grep "per decode"; done
+  CSM_MIMI_SPLITK=$sp timeout 300 python tools/mimi_bench.py 2>&1 | grep "frames =\|streaming"; done > $O/mimi_splitk.txt
+for sk in 4 16 32 64; do echo "== CSM_MIMI_SKINNY=$sk (K split on)"; CSM_MIMI_SKINNY=$sk timeout 200 python tools/mimi_stream_probe.py 2>&1 | grep -v amdgpu | tail -5
+  for T in 6 12 16 25 32; do CSM_MIMI_SKINNY=$sk timeout 200 python tools/mimi_short_profile.py $T 2>&1 | grep "per decode"; done; done > $O/mimi_threshold.txt
 (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 gemmphase.hip -o gemmphase 2>/dev/null; timeout 120 ./gemmphase) > $O/gemmphase_ubench.txt 2>&1
 ls -la $O | head -40; cat $O/bench.json | head -5
