@@ -140,6 +140,8 @@ struct csm_engine {
   size_t loss_lab_n = 0, loss_rows_n = 0;
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
+  int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
+  size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
   int prefill_splitk_max = 8;   // most K splits of a residual prefill GEMM (the partials buffer holds 4 at max_prefill_rows: more only for fewer rows)
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
@@ -323,6 +325,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     const size_t Km = std::max(Hm_, nqm);
     if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * ffm))) return r;
     if (R <= 4096 && (r = dalloc(e, &e->p_part, 4 * R * Hm_))) return r;   // only small prefills are short of workgroups
+    e->p_part_h = Hm_;
   }
   if ((r = dalloc(e, &e->am_part, (size_t)2048))) return r;
   // split-K scratch of the MFMA skinny GEMM: panels x K-splits x 64x16 floats (4 MiB covers N = 4096, K = 8192)
@@ -518,6 +521,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
+  else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
@@ -968,6 +972,13 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     ks_o = wide_split(nq * hd, ks_o);
     ks_d = wide_split(F, ks_d);
   }
+  // QKV: the same K split, its partials summed by the RoPE / cache-append launch that reads the result anyway.  p_part is
+  // free between the RMSNorm that folded the previous layer's partials and this layer's o_proj
+  int ks_q = 1;
+  if (can_split && e->prefill_splitk_qkv) {
+    const size_t room = 4 * (size_t)e->cfg.max_prefill_rows * (size_t)e->p_part_h / (R * (size_t)s.nqkv());
+    ks_q = prefill_ksplit((int)R, s.nqkv(), H, (int)std::min<size_t>(std::min<size_t>((size_t)e->prefill_splitk_max, (size_t)e->prefill_splitk_qkv), room));
+  }
   const size_t part_stride = R * (size_t)H;
   int pending = 0;   // splits waiting in p_part for the next RMSNorm
   for (int l = 0; l < s.c.layers; ++l) {
@@ -979,8 +990,14 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
     g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot;
-    LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     RopeArgs ra{};
+    if (ks_q > 1) {
+      g.ksplit = ks_q; g.Cpart = e->p_part; g.part_stride = R * (size_t)s.nqkv();
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, g));
+      ra.part = e->p_part; ra.nsplit = ks_q; ra.part_stride = g.part_stride;
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
+    }
     ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
     ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
     ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;

@@ -254,8 +254,9 @@ int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int 
 }
 
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a) {
-  if (kvdtype == 1) hipLaunchKernelGGL((rope_scatter_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((rope_scatter_kernel<float>), dim3(rows), dim3(256), 0, st, a);
+  const dim3 grid(rows, (a.nsplit > 1 && rows < 1024) ? 4 : 1);
+  if (kvdtype == 1) hipLaunchKernelGGL((rope_scatter_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((rope_scatter_kernel<float>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 

@@ -191,6 +191,11 @@ struct RopeArgs {
   int lmax;
   const int* rope_pos;  // nullable: caller-supplied RoPE positions (reference `position_ids`, modeling_csm.py:296,349);
                         // the cache slot stays row_pos -- HF masks by cache index and rotates by position_ids
+  // split-K QKV GEMM of a short prefill: nsplit > 1 partial products [nsplit][rows][(n_q + 2 n_kv) hd], part_stride apart,
+  // summed here in fixed order (qkv is then ignored)
+  const float* part;
+  int nsplit;
+  size_t part_stride;
 };
 
 // ---- KV-cache interchange with the HF layout [B][n_kv][len][hd] fp32 (transformers DynamicCache layers) ----------------
@@ -232,13 +237,21 @@ __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
   const int rpos = a.rope_pos ? a.rope_pos[row] : pos;
   const int half = a.hd >> 1;
   const int nh = a.n_q + 2 * a.n_kv;
-  const float* src = a.qkv + (size_t)row * nh * a.hd;
+  const bool parts = a.nsplit > 1;
+  const float* src = (parts ? a.part : a.qkv) + (size_t)row * nh * a.hd;
+  auto ld = [&](int col) {
+    float v = src[col];
+    if (parts)
+      for (int sp = 1; sp < a.nsplit; ++sp) v += src[(size_t)sp * a.part_stride + col];
+    return v;
+  };
   KT* kc = reinterpret_cast<KT*>(a.kcache);
   KT* vc = reinterpret_cast<KT*>(a.vcache);
-  for (int p = threadIdx.x; p < nh * half; p += 256) {
+  // gridDim.y workgroups share a row (short prefills summing split-K partials: rows alone would leave most CUs idle)
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < nh * half; p += 256 * gridDim.y) {
     const int head = p / half, i = p - head * half;
     if (head < a.n_q + a.n_kv) {
-      const float v0 = src[head * a.hd + i], v1 = src[head * a.hd + i + half];
+      const float v0 = ld(head * a.hd + i), v1 = ld(head * a.hd + i + half);
       const float c = a.cos_tab[(size_t)rpos * half + i], s = a.sin_tab[(size_t)rpos * half + i];
       const float o0 = v0 * c - v1 * s, o1 = v1 * c + v0 * s;
       if (head < a.n_q) {
@@ -255,8 +268,8 @@ __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
     } else {
       const int j = head - a.n_q - a.n_kv;
       KT* vr = vc + (((size_t)b * a.n_kv + j) * a.lmax + pos) * a.hd;
-      store_kv(vr + 2 * i, src[head * a.hd + 2 * i]);
-      store_kv(vr + 2 * i + 1, src[head * a.hd + 2 * i + 1]);
+      store_kv(vr + 2 * i, ld(head * a.hd + 2 * i));
+      store_kv(vr + 2 * i + 1, ld(head * a.hd + 2 * i + 1));
     }
   }
 }

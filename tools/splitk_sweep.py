@@ -15,8 +15,8 @@ for ctx in (32, 64, 128, 256, 512):
         eng.set_option("prefill_bf16", mode)
         ref = None
         line = []
-        for cap in (4, 8, 16):
-            eng.set_option("prefill_splitk_max", cap)
+        for cap in (0, 2, 4, 8):
+            eng.set_option("prefill_splitk_qkv", cap)
             ts = []
             for rep in range(8):
                 eng.reset(); eng.set_kv_start([0])
@@ -25,5 +25,5 @@ for ctx in (32, 64, 128, 256, 512):
                 ts.append((time.perf_counter() - t0) * 1e3)
             o = eng.get_state()[0].double().cpu()
             if ref is None: ref = o
-            line.append(f"cap {cap}: {min(ts):.2f} ms (rel {float((o - ref).norm() / ref.norm()):.1e})")
+            line.append(f"qkv<={cap}: {min(ts):.2f} ms (rel {float((o - ref).norm() / ref.norm()):.1e})")
         print(f"ctx {ctx:4d} {'bf16 ' if mode else 'exact'}: " + "   ".join(line), flush=True)
