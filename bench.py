@@ -195,6 +195,25 @@ def _free_port() -> int:
     return p
 
 
+PREFILL_SAMPLES = 5
+
+
+def timed_prefill(eng, ids, mask, B) -> float:
+    """median of PREFILL_SAMPLES context prefills in ms (the first call or two after a precision switch run 0.1-0.15 ms
+    slow: a single sample read 2.88 ms where the steady value is 2.75).  Outside the timed region; informational."""
+    ts = []
+    for _ in range(PREFILL_SAMPLES):
+        eng.reset()
+        eng.set_kv_start([0] * B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prefill(ids, mask, want_outputs=False)
+        eng.sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print("[bench] prefill samples (ms): " + " ".join(f"{t:.2f}" for t in ts), file=sys.stderr, flush=True)
+    return sorted(ts)[len(ts) // 2]
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run with one rank per
     GPU.  Fails loudly (non-zero) when the box has fewer than N devices -- never reports a 1-GPU run as N."""
@@ -286,22 +305,9 @@ def main():
     prefill_ms_bf16 = None
     if a.weights != "fp32":
         eng.set_option("prefill_bf16", 1)
-        for _ in range(2):
-            eng.reset()
-            eng.set_kv_start([0] * B)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            eng.prefill(ids, mask, want_outputs=False)
-            eng.sync()
-            prefill_ms_bf16 = (time.perf_counter() - t0) * 1e3
+        prefill_ms_bf16 = timed_prefill(eng, ids, mask, B)
         eng.set_option("prefill_bf16", 0)
-    eng.reset()
-    eng.set_kv_start([0] * B)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.prefill(ids, mask, want_outputs=False)
-    eng.sync()
-    prefill_ms = (time.perf_counter() - t0) * 1e3
+    prefill_ms = timed_prefill(eng, ids, mask, B)   # the benchmarked run continues from this (exact) context
     s = eng.sampling(temperature=a.temperature, topk=a.topk, seed=1234)
     use_graph = not a.no_graph
     eng.generate(s, W, use_graph)
@@ -360,6 +366,7 @@ def main():
             "tokens_checksum_per_rank": checks,
             "weight_streamer": pf_stats,
             "prefill_ms": round(prefill_ms, 2),
+            "prefill_ms_statistic": f"median of {PREFILL_SAMPLES} calls",
             "prefill_ms_bf16_activations": None if prefill_ms_bf16 is None else round(prefill_ms_bf16, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
             "setup_s": round(t_setup, 1),
