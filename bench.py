@@ -2,7 +2,7 @@
 """Benchmark of the CSM generation hot path on MI355X -- BASELINE.json metric
 "audio frames/sec (csm-1b, 512-frame ctx, greedy)".
 
-A *step* = one frame-step of the hot path: the 31(+1)-pass decoder loop that emits codebooks 0..31 of one
+A *step* = one frame-step of the hot path: the decoder loop (31 weight passes, as in the reference) that emits codebooks 0..31 of one
 audio frame for every resident sequence, plus the backbone step that consumes that frame -- exactly one
 iteration of the reference's `generate()` loop (modeling_csm.py:644-690), replayed from one hipGraph.
 Workload at N=1: BASELINE configs[1] -- csm-1b, bf16 weights, B=1, 512-frame synthetic context
@@ -166,7 +166,12 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         assert toks.shape == (rows, frames, cfg.audio_num_codebooks), toks.shape
         passes = max(1, -(-(a1 - a0) // 64))
+        rows_pass = min(a1 - a0, 64)
+        step_ms = float(tm[1]) * 1e3 / frames                 # one frame-step of the last engine pass (rows_pass rows)
+        by = bytes_step(cfg, rows_pass, ctx + (frames - 1) / 2.0 + 1, kvbytes=4)
         out[leg] = {"rows_total": rows, "rows_per_gpu": a1 - a0, "frames": frames,
+                    "ms_per_step_decode": round(step_ms, 4), "rows_per_engine_pass": rows_pass,
+                    "roofline_frac_of_8TBs": round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "frames_per_s_end_to_end": round(rows * frames / float(tm[0]), 1),
                     "frames_per_s_decode_only": round(rows * frames / (float(tm[1]) * passes), 1),
                     "wall_s": round(float(tm[0]), 4), "decode_ms_last_pass": round(float(tm[1]) * 1e3, 2),
@@ -250,7 +255,8 @@ def main():
                     "(its launches would be counted with the step's own kernels)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--config4", type=int, default=-1, help="1/0: also run the BASELINE configs[3] sub-record (batch of "
-                    "utterances through generate_sharded, 16 rows/GPU weak + 128 rows strong); default: on when --gpus > 1")
+                    "utterances through generate_sharded, 16 rows/GPU weak + 128 rows strong); default: on for the "
+                    "default workload (B = 1, 512-frame context) at every N, off with --lean")
     ap.add_argument("--config4-frames", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
     a = ap.parse_args()
@@ -264,7 +270,9 @@ def main():
         print(f"[bench] --gpus {a.gpus} does not match WORLD_SIZE {world}", file=sys.stderr, flush=True)
         sys.exit(3)
     dist = None
-    if world > 1:
+    dist_backend = None
+    if "WORLD_SIZE" in os.environ:      # started by a launcher (torch.distributed.run), also with ONE rank: the same
+        # process-group code path (RCCL init, MAX all-reduce, all-gather) runs at every world size
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -274,9 +282,11 @@ def main():
             local = 0
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
+            dist_backend = "gloo"
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist_backend = "nccl"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -367,6 +377,7 @@ def main():
                                    f"hipGraph={'on' if use_graph else 'off'}",
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
             "tokens_checksum_per_rank": checks,
+            "dist_backend": dist_backend,      # null: single process without a launcher (no process group)
             "weight_streamer": pf_stats,
             "prefill_ms": round(prefill_ms, 2),
             "prefill_ms_statistic": f"median of {PREFILL_SAMPLES} calls after {PREFILL_WARM} untimed",
@@ -423,7 +434,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.lean:
             out["cpu_baseline"] = cpu_baseline(cfg, model, ids, mask, a.cpu_frames, toks)
     # BASELINE configs[3] (batch of utterances sharded over the GPUs): every rank takes part
-    want4 = a.config4 == 1 or (a.config4 < 0 and world > 1)
+    want4 = a.config4 != 0 and B == 1 and a.ctx == 512 or a.config4 == 1   # default: on (the B = 16 per-GPU shape is the
+    # one an 8-GPU curve multiplies -- it belongs in every driver-timed line); --config4 0 switches it off
     c4 = None
     if want4 and not a.lean and a.weights == "bf16":
         del eng

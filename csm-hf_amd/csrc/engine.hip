@@ -47,6 +47,8 @@ int launch_ce_rows(hipStream_t st, const CeArgs& a);
 int launch_ce_reduce(hipStream_t st, const float* row_loss, const int* labels, int V, int rows, double* acc);
 int launch_loss_finalize(hipStream_t st, const double* acc, int frames, float* out3);
 int launch_dec_input(hipStream_t st, int frames, const DecInArgs& a);
+int launch_kv_shift(hipStream_t st, int kvdtype, const KvShiftArgs& a);
+int launch_add_ints(hipStream_t st, int* p, int n, int delta);
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -1118,32 +1120,85 @@ extern "C" int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, co
   if (!e || !e->bound || !ids) return fail(CSM_ERR_ARG, "null argument");
   if (!e->ready || e->B < 1) return fail(CSM_ERR_STATE, "no running batch (csm_prefill first)");
   if (row < 0 || row >= e->B) return fail(CSM_ERR_ARG, "row %d outside the running batch of %d", row, e->B);
-  if (S < 1 || S > e->h_len) return fail(CSM_ERR_CAPACITY, "a joining context (%d frames) cannot be longer than the batch's current length (%d)", S, e->h_len);
-  if (S > e->cfg.max_prefill_rows) return fail(CSM_ERR_CAPACITY, "context %d exceeds max_prefill_rows %d", S, e->cfg.max_prefill_rows);
+  if (S < 1 || S > e->h_len)
+    return fail(CSM_ERR_CAPACITY, "a joining context (%d frames) is longer than the batch's current length (%d): csm_shift_context first", S, e->h_len);
   Stack& s = e->bb;
-  const int Hb = s.c.hidden, past = e->h_len - S;
+  const int Hb = s.c.hidden, past0 = e->h_len - S, C1 = e->cfg.n_codebooks + 1;
   const size_t kvb = e->cfg.kv_dtype == 1 ? 2 : 4;
   const size_t slot = (size_t)s.c.n_kv * s.lmax * s.c.head_dim * kvb;
   std::vector<void*> kc(s.c.layers), vc(s.c.layers);
   for (int l = 0; l < s.c.layers; ++l) { kc[l] = (char*)s.kc[l] + (size_t)row * slot; vc[l] = (char*)s.vc[l] + (size_t)row * slot; }
-  LCK(launch_set_int(e->stream, e->d_kv_start + row, past));
+  LCK(launch_set_int(e->stream, e->d_kv_start + row, past0));
   if (e->d_row_done) LCK(launch_set_int(e->stream, e->d_row_done + row, 0));
-  LCK(launch_rows_iota(e->stream, e->p_row_seq, e->p_row_pos, S, S, past));
-  EmbedArgs em{};
-  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
-  em.ids = ids; em.mask = mask; em.out = e->p_h;
-  LCK(launch_embed(e->stream, emb_dtype(e), S, em));
-  int pending = 0;
+  // contexts longer than the prefill scratch go through it in chunks (causal: chunk c attends to the row's earlier chunks)
+  const int chunk = e->cfg.max_prefill_rows;
+  int pending = 0, n = 0;
   size_t part_stride = 0;
-  if (int r = stack_rows(e, s, kc.data(), vc.data(), s.lmax, 1, S, past, e->d_kv_start + row, nullptr, true, &pending, &part_stride)) return r;
-  const float* hl = e->p_h + (size_t)(S - 1) * Hb;
+  for (int done = 0; done < S; done += n) {
+    n = std::min(chunk, S - done);
+    const int past = past0 + done;
+    LCK(launch_rows_iota(e->stream, e->p_row_seq, e->p_row_pos, n, n, past));
+    EmbedArgs em{};
+    em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
+    em.ids = ids + (size_t)done * C1; em.mask = mask ? mask + (size_t)done * C1 : nullptr; em.out = e->p_h;
+    LCK(launch_embed(e->stream, emb_dtype(e), n, em));
+    if (int r = stack_rows(e, s, kc.data(), vc.data(), s.lmax, 1, n, past, e->d_kv_start + row, nullptr, true, &pending, &part_stride)) return r;
+  }
+  const float* hl = e->p_h + (size_t)(n - 1) * Hb;
   LCK(launch_rmsnorm(e->stream, hl, Hb, s.final_norm, 1, Hb, s.c.rms_eps, e->last_h + (size_t)row * Hb, Hb, nullptr, 0, 0, nullptr, 0,
-                     pending > 1 ? e->p_part + (size_t)(S - 1) * Hb : nullptr, pending, part_stride, Hb));
+                     pending > 1 ? e->p_part + (size_t)(n - 1) * Hb : nullptr, pending, part_stride, Hb));
   GemvArgs a{};
   a.nt = e->nt_backbone;
   a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;
   a.x = hl; a.ldx = Hb; a.ln = s.final_norm; a.eps = s.c.rms_eps; a.out = e->head_out + (size_t)row * e->ld_head; a.ldo = e->ld_head;
   return gemv_rows(e, 1, PRO_NORM, EPI_STORE, a);
+}
+
+// Continuous batching, contexts longer than the running batch: every cached position of the resident batch moves `delta`
+// slots up (keys re-rotated by delta, see KvShiftArgs), kv_start of every row and the shared length grow by delta.  The
+// rows' attention results are unchanged up to fp32 rounding of the extra rotation (RoPE is relative); the slots below a
+// row's kv_start are never read.  Call between two frame-steps, then csm_prefill_slot with a context of up to the new length.
+extern "C" int csm_shift_context(csm_engine_t* e, int delta) {
+  if (!e || !e->bound) return fail(CSM_ERR_ARG, "null / unbound engine");
+  if (e->B < 1) return fail(CSM_ERR_STATE, "no running batch");
+  if (delta < 0) return fail(CSM_ERR_ARG, "delta < 0");
+  if (delta == 0) return 0;
+  Stack& s = e->bb;
+  const int len = e->h_len, B = e->B, nkv = s.c.n_kv, hd = s.c.head_dim;
+  if (len + delta > e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "length %d + shift %d exceeds max_len %d", len, delta, e->cfg.max_len);
+  if (delta >= s.rope_positions) return fail(CSM_ERR_CAPACITY, "shift %d beyond the RoPE table (%d positions)", delta, s.rope_positions);
+  const size_t es = e->esz_kv, cnt = (size_t)B * nkv * len * hd;
+  char *kt = nullptr, *vt = nullptr;
+  if (len > 0) {
+    if (hipMalloc((void**)&kt, cnt * es + 256) != hipSuccess || hipMalloc((void**)&vt, cnt * es + 256) != hipSuccess) {
+      if (kt) hipFree(kt);
+      return fail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) for the context shift failed", 2 * cnt * es);
+    }
+    for (int l = 0; l < s.c.layers; ++l) {
+      KvShiftArgs a{};
+      a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.ktmp = kt; a.vtmp = vt; a.B = B; a.n_kv = nkv; a.hd = hd; a.lmax = s.lmax; a.len = len;
+      a.cos_row = s.cos + (size_t)delta * (hd / 2); a.sin_row = s.sin + (size_t)delta * (hd / 2);
+      int r = launch_kv_shift(e->stream, e->cfg.kv_dtype, a);
+      hipError_t h1 = hipSuccess, h2 = hipSuccess;
+      if (!r) {
+        h1 = hipMemcpy2DAsync((char*)s.kc[l] + (size_t)delta * 4 * es, (size_t)s.lmax * 4 * es, kt, (size_t)len * 4 * es, (size_t)len * 4 * es,
+                              (size_t)B * nkv * (hd / 4), hipMemcpyDeviceToDevice, e->stream);
+        h2 = hipMemcpy2DAsync((char*)s.vc[l] + (size_t)delta * hd * es, (size_t)s.lmax * hd * es, vt, (size_t)len * hd * es, (size_t)len * hd * es,
+                              (size_t)B * nkv, hipMemcpyDeviceToDevice, e->stream);
+      }
+      if (r || h1 != hipSuccess || h2 != hipSuccess) {
+        hipStreamSynchronize(e->stream); hipFree(kt); hipFree(vt);
+        return fail(r ? r : (int)(h1 != hipSuccess ? h1 : h2), "context shift failed at layer %d", l);
+      }
+    }
+  }
+  LCK(launch_add_ints(e->stream, e->d_kv_start, B, delta));
+  LCK(launch_set_int(e->stream, e->d_len, len + delta));
+  HIPCK(hipStreamSynchronize(e->stream));
+  if (kt) hipFree(kt);
+  if (vt) hipFree(vt);
+  e->h_len = len + delta;
+  return 0;
 }
 
 // ---- training forward, labels branch (reference modeling_csm.py:367-465) -------------------------------------------------
@@ -1343,7 +1398,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
   HIPCK(hipEventRecord(e->ev0, e->stream));
   if (use_graph && n_frames > 0) {
     GraphKey k{};
-    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature; k.per_row = s->per_row_stop && e->B > 1;
+    k.B = e->B; k.topk = s->topk; k.nsplit = e->nsplit_eff(); k.temperature = s->temperature; k.per_row = s->per_row_stop != 0;   // exactly what the captured sampler launches use (SampleArgs::row_done), also at B = 1
     k.noise = s->noise; k.forced = s->forced; k.ltrace = s->logits_trace; k.htrace = s->last_h_trace;
     const bool greedy = s->topk <= 1 || s->temperature == 0.f;
     if (greedy) { k.topk = 1; k.temperature = 0.f; }   // every greedy setting runs the same launches

@@ -84,10 +84,16 @@ template <typename WT, int EPI, int DEPTH, int NPL>
 static int launch_gemm_wide_k(hipStream_t st, const dim3& grid, const GemmArgs& a) {
   constexpr size_t lds = (size_t)2 * NPL * 128 * 80 * sizeof(bf16_t);   // 40 KB (one plane) / 120 KB (three)
   auto fn = gemm_wide_kernel<WT, EPI, DEPTH, NPL>;
-  static bool configured = false;
-  if (!configured && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    configured = true;
+  // hipFuncSetAttribute applies to the CURRENT device: remember per device (a process may hold engines on several GPUs)
+  static unsigned long long configured = 0ull;
+  if (lds > 64 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      configured |= bit;
+    }
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a);
   return (int)hipGetLastError();
@@ -260,7 +266,7 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
   return (int)hipGetLastError();
 }
 
-int configure_sample() {   // once per process, outside any capture: the top-k path may need more than 64 KiB of LDS
+int configure_sample() {   // once per engine (= per device: the attribute is per device), outside any capture: the top-k path may need more than 64 KiB of LDS
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(160 * 1024 - 4096));
 }
@@ -270,6 +276,19 @@ int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a) {
   const int grid = (int)((n + 255) / 256);
   if (kvdtype == 1) hipLaunchKernelGGL((kv_convert_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((kv_convert_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_kv_shift(hipStream_t st, int kvdtype, const KvShiftArgs& a) {
+  const size_t n = (size_t)a.B * a.n_kv * a.len * (a.hd / 2);
+  if (n == 0) return 0;
+  const int grid = (int)((n + 255) / 256);
+  if (kvdtype == 1) hipLaunchKernelGGL((kv_shift_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((kv_shift_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+int launch_add_ints(hipStream_t st, int* p, int n, int delta) {
+  hipLaunchKernelGGL(add_ints_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n, delta);
   return (int)hipGetLastError();
 }
 

@@ -45,8 +45,8 @@ struct csm_mimi {
   std::vector<float*> s_conv;
   float* part = nullptr;               // split-K partial products of a GEMM with too few tiles (gemm())
   size_t part_floats = (size_t)8 << 20;
-  bool splitk = true;                  // CSM_MIMI_SPLITK=0 at create: no K split (A/B; with CSM_MIMI_SKINNY=0: one kernel, one order)
-  int skinny_rows = 16;   // GEMMs of at most this many rows take the skinny path; CSM_MIMI_SKINNY=<rows> at create (0: none --
+  bool splitk = true;                  // csm_mimi_set_option("splitk", 0): no K split (A/B; with "skinny_rows" 0: one kernel, one order)
+  int skinny_rows = 16;   // GEMMs of at most this many rows take the skinny path; csm_mimi_set_option("skinny_rows", n) (0: none --
                           // every GEMM on the 128 x 128 tile: A/B measurements, bitwise stream == one-shot)
 };
 constexpr int PADR = 8;   // zero rows in front of every convolution input (>= kernel_size - 1)
@@ -121,10 +121,6 @@ extern "C" int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out) {
       }
     if (!r) r = malloc_f(m, &m->s_up_prev, (size_t)c.hidden);
     if (!r) r = malloc_f(m, &m->part, m->part_floats);
-    const char* sp = getenv("CSM_MIMI_SPLITK");
-    m->splitk = !(sp && sp[0] == '0');
-    const char* sk = getenv("CSM_MIMI_SKINNY");
-    if (sk) m->skinny_rows = std::max(0, std::min(256, atoi(sk)));
     if (!r && gemv_configure_all()) r = mfail(CSM_ERR_STATE, "skinny-GEMM kernel configuration failed");
     for (size_t i = 0; i < cins.size() && !r; ++i) {
       float* q = nullptr;
@@ -171,7 +167,7 @@ extern "C" int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w)
 //    3.6 / 6.8 ms.
 // With the split available the best row threshold is 16 (swept 4 / 16 / 32 / 64: 25 frames one-shot 1.7 ms at 16, 3.4 ms
 // at 64; 4-frame calls 1.3 ms at 16, 1.6 ms at 4).  Neither path sums in the order of the unsplit MFMA chain: a stream is
-// ~2e-6 of the peak away from the one-shot decode (bitwise equal with CSM_MIMI_SKINNY=0 CSM_MIMI_SPLITK=0); everything
+// ~2e-6 of the peak away from the one-shot decode (bitwise equal with options skinny_rows = 0, splitk = 0); everything
 // stays within the codec's 1e-4 of the reference implementation.
 static int gemm(csm_mimi* m, const float* A, int lda, const float* W, int N, int K, size_t R, float* C, int ldc) {
   if (R <= (size_t)m->skinny_rows && K % 8 == 0) {   // groups of <= 4 rows, the weights streamed once per group
@@ -326,6 +322,16 @@ extern "C" int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T
 
 // ---- streaming decode (modeling_mimi.py:1388-1406 with decoder_past_key_values, MimiConv1dPaddingCache :73-166): one
 // sequence decoded a few frames at a time; the concatenated output equals one decode of the whole sequence ----
+// tuning switches of one handle (like csm_set_option): "skinny_rows" = GEMMs of at most this many rows go to the
+// weight-streaming skinny GEMM (0..256; 0 = none), "splitk" = K split of GEMMs with too few tiles (0 / 1)
+extern "C" int csm_mimi_set_option(csm_mimi_t* m, const char* name, int value) {
+  if (!m || !name) return mfail(CSM_ERR_ARG, "null argument");
+  if (!strcmp(name, "skinny_rows")) m->skinny_rows = std::max(0, std::min(256, value));
+  else if (!strcmp(name, "splitk")) m->splitk = value != 0;
+  else return mfail(CSM_ERR_ARG, "unknown option %s", name);
+  return 0;
+}
+
 extern "C" int csm_mimi_stream_reset(csm_mimi_t* m) {
   if (!m) return mfail(CSM_ERR_ARG, "null argument");
   m->s_frames = m->s_nh = m->s_cur = 0;

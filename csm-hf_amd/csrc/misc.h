@@ -208,7 +208,48 @@ struct KvConvArgs {
   int to_engine;   // 1: HF -> engine (import), 0: engine -> HF (export)
 };
 
+// ---- continuous batching: move every cached position of the resident batch `delta` slots up (csm_shift_context) so that a
+// context LONGER than the batch's current length can join right-aligned.  K is stored post-RoPE, rotated by its slot index;
+// attention only sees position differences, so the moved keys are rotated by `delta` more (cos/sin row `delta` of the
+// engine's own table) and every later query / key of the row -- rotated by its new slot -- keeps the same distances.
+struct KvShiftArgs {
+  const void* kcache;   // engine layout K [B][n_kv][hd/4][lmax][4], V [B][n_kv][lmax][hd]
+  const void* vcache;
+  void* ktmp;           // compact [B][n_kv][hd/4][len][4]
+  void* vtmp;           // compact [B][n_kv][len][hd]
+  const float* cos_row; // cos/sin of angle delta * inv_freq[i], i < hd/2
+  const float* sin_row;
+  int B, n_kv, hd, lmax, len;
+};
+
 #ifndef CSM_ARGS_ONLY
+template <typename KT>
+__global__ __launch_bounds__(256) void kv_shift_kernel(KvShiftArgs a) {
+  const int half = a.hd >> 1;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)a.B * a.n_kv * a.len * half;
+  if (i >= n) return;
+  const int d = (int)(i % half);
+  const int t = (int)((i / half) % a.len);
+  const size_t bj = i / ((size_t)half * a.len);
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache);
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache);
+  KT* kt = reinterpret_cast<KT*>(a.ktmp);
+  KT* vt = reinterpret_cast<KT*>(a.vtmp);
+  const int d1 = d + half;
+  const float k0 = to_f32(kc[((bj * (a.hd >> 2) + (d >> 2)) * a.lmax + t) * 4 + (d & 3)]);
+  const float k1 = to_f32(kc[((bj * (a.hd >> 2) + (d1 >> 2)) * a.lmax + t) * 4 + (d1 & 3)]);
+  const float c = a.cos_row[d], s = a.sin_row[d];
+  store_kv(kt + ((bj * (a.hd >> 2) + (d >> 2)) * a.len + t) * 4 + (d & 3), k0 * c - k1 * s);
+  store_kv(kt + ((bj * (a.hd >> 2) + (d1 >> 2)) * a.len + t) * 4 + (d1 & 3), k1 * c + k0 * s);
+  vt[(bj * a.len + t) * a.hd + d] = vc[(bj * a.lmax + t) * a.hd + d];
+  vt[(bj * a.len + t) * a.hd + d1] = vc[(bj * a.lmax + t) * a.hd + d1];
+}
+__global__ void add_ints_kernel(int* p, int n, int delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += delta;
+}
+
 template <typename KT>
 __global__ __launch_bounds__(256) void kv_convert_kernel(KvConvArgs a) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -17,7 +17,7 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
@@ -30,7 +30,7 @@ EXPORTS = [
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
     "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
-    "csm_mimi_stream_decode",
+    "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
 ]
 
 
@@ -126,6 +126,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_prefill_slot.argtypes = [vp, i32, vp, vp, i32]
+    lib.csm_shift_context.argtypes = [vp, i32]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
     lib.csm_set_length.argtypes = [vp, i32, i32]
@@ -398,15 +399,25 @@ class Engine:
 
     def prefill_slot(self, row: int, ids: torch.Tensor, mask: Optional[torch.Tensor]):
         """Continuous batching: a new utterance (ids/mask [S,C+1] or [1,S,C+1]) takes over batch row `row` of the running
-        batch; its context is placed right-aligned against the current length (S <= self.length)."""
+        batch; its context is placed right-aligned against the current length.  A context LONGER than the batch's current
+        length first moves the resident rows up by the difference (`shift_context`; the cache must have the room:
+        S <= max_len).  Contexts longer than max_prefill_rows are prefilled in chunks inside the library."""
         if ids.dim() == 2:
             ids = ids.unsqueeze(0)
             mask = None if mask is None else mask.unsqueeze(0)
         S = ids.shape[1]
+        if S > self.length:
+            self.shift_context(S - self.length)
         ids, m = self._prep_ids(ids, mask)
         torch.cuda.current_stream().synchronize()
         _ck(self.lib, self.lib.csm_prefill_slot(self._h, int(row), _ptr(ids), _ptr(m), S))
         self.sync()
+
+    def shift_context(self, delta: int):
+        """Move every resident row `delta` cache slots up (csm_shift_context): makes room for a joining context longer than
+        the batch's current length.  The shared length grows by delta."""
+        _ck(self.lib, self.lib.csm_shift_context(self._h, int(delta)))
+        self.length += int(delta)
 
     def forward_loss(self, ids: torch.Tensor, mask: Optional[torch.Tensor], labels: torch.Tensor):
         """The reference's training forward (modeling_csm.py:367-465), forward only: returns (losses [3] fp32 on the

@@ -283,6 +283,7 @@ class MimiDecoder:
         self.lib.csm_mimi_bind_weights.argtypes = [C.c_void_p, C.POINTER(_MimiWeights)]
         self.lib.csm_mimi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self.lib.csm_mimi_stream_reset.argtypes = [C.c_void_p]
+        self.lib.csm_mimi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         self.lib.csm_mimi_stream_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         if cfg.num_hidden_layers > _MAX_LAYERS or len(cfg.upsampling_ratios) > _MAX_RATIOS:
             raise ValueError("too many transformer layers / upsampling ratios for csm_mimi_config_t")
@@ -312,6 +313,10 @@ class MimiDecoder:
                     setattr(w, name, v.data_ptr())
             torch.cuda.synchronize(self.device)
             _ck(self.lib, self.lib.csm_mimi_bind_weights(self._h, C.byref(w)))
+
+    def set_option(self, name: str, value: int):
+        """`skinny_rows` (GEMMs of <= n rows on the weight-streaming skinny GEMM, default 16; 0 = none) / `splitk` (0 / 1)."""
+        self._ck(self.lib, self.lib.csm_mimi_set_option(self._h, name.encode(), int(value)))
 
     @classmethod
     def from_pretrained(cls, path: str, device="cuda:0", max_frames: int = 512) -> "MimiDecoder":

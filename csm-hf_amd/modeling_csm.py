@@ -86,6 +86,18 @@ def _hf_cache_layers(pkv):
     return None
 
 
+def _hf_cache_is_empty(pkv) -> bool:
+    """an HF cache object (or legacy tuple) that holds no positions yet"""
+    if isinstance(pkv, (tuple, list)):
+        return len(pkv) == 0
+    if hasattr(pkv, "get_seq_length") and (hasattr(pkv, "layers") or hasattr(pkv, "key_cache")):
+        try:
+            return int(pkv.get_seq_length()) == 0
+        except Exception:
+            return False
+    return False
+
+
 _default_engine_for_sampling = {}
 
 
@@ -247,11 +259,14 @@ class CSMModel(nn.Module):
         self._epoch += 1
         self._frame_pending = False
 
-    def _ensure_engine(self, batch: int, need_len: int, need_frames: int, prefill_rows: int, cont: bool = False) -> Engine:
+    def _ensure_engine(self, batch: int, need_len: int, need_frames: int, prefill_rows: int, cont: bool = False,
+                       must_prefill_rows: int = 0) -> Engine:
         """Create or re-size the engine.  `cont`: the call continues a live context (past_key_values): the engine may
         still grow (the reference's DynamicCache grows without bound), but then the resident KV cache, counters, frame
         ring and pending logits are MOVED into the larger engine (csm_kv_copy) -- a continuation never restarts from an
-        empty cache.  The prefill scratch is not a growth reason: Engine.prefill chunks by max_prefill_rows."""
+        empty cache.  `prefill_rows` is a sizing HINT for the prefill scratch (capped at 8192 rows: Engine.prefill chunks
+        longer contexts); `must_prefill_rows` is a REQUIREMENT of callers that cannot chunk (the training forward needs
+        B*S rows in one pass) and is a growth reason, uncapped."""
         p = next(self.parameters())
         if p.device.type != "cuda":
             raise RuntimeError("CSMModel must be on an AMD GPU (model.to('cuda')): csm_hf_amd has no CPU path")
@@ -261,14 +276,14 @@ class CSMModel(nn.Module):
                 raise ValueError("weight_format changed while a KV cache is live")
             self._drop_engine()
         grow = (self._engine is None or batch > self._engine.max_batch or need_len > self._engine.max_len or
-                need_frames > self._engine.max_frames)
+                need_frames > self._engine.max_frames or must_prefill_rows > self._engine.max_prefill_rows)
         if grow:
             c["max_batch"] = max(c["max_batch"], batch)
             # a live context that outgrows its cache doubles it (amortised like the reference's cat-grown cache)
             c["max_len"] = max(c["max_len"], need_len if not cont else max(need_len, 2 * self._engine.max_len),
                                self.config.max_seq_len)
             c["max_frames"] = max(c["max_frames"], need_frames, 256)
-            c["max_prefill_rows"] = max(c["max_prefill_rows"], min(prefill_rows, 8192))
+            c["max_prefill_rows"] = max(c["max_prefill_rows"], min(prefill_rows, 8192), int(must_prefill_rows))
             old = self._engine
             packed = old.packed if old is not None else None
             if old is not None and not cont:
@@ -323,9 +338,13 @@ class CSMModel(nn.Module):
             return self._forward_loss(input_ids, attention_mask, labels, position_ids, past_key_values, use_cache, return_dict)
         if position_ids is not None and tuple(position_ids.shape) not in ((B, S), (1, S)):
             raise ValueError(f"position_ids must be [B, S] or [1, S], got {tuple(position_ids.shape)}")
+        if past_key_values is not None and not isinstance(past_key_values, CSMKVCache) and _hf_cache_is_empty(past_key_values):
+            past_key_values = None     # `DynamicCache()` / `()`: the usual HF way to start a context; the reference accepts it
         hf_layers = None if isinstance(past_key_values, CSMKVCache) else _hf_cache_layers(past_key_values)
         if hf_layers is not None:
-            # a cache in the HF layout (exported earlier, forked, or built elsewhere): import it and continue from it
+            # a cache in the HF layout (exported earlier, forked, or built elsewhere): import it and continue from it.
+            # The HF layout carries no pad information: every imported position is attended to (kv_start = 0), which is
+            # what the reference does with such a cache on decode steps; export pad-free batches.
             L = hf_layers[0][0].shape[2]
             if hf_layers[0][0].shape[0] != B:
                 raise ValueError("past_key_values batch does not match input_ids")
@@ -375,7 +394,7 @@ class CSMModel(nn.Module):
         B, S = input_ids.shape[0], input_ids.shape[1]
         if tuple(labels.shape) != tuple(input_ids.shape):
             raise ValueError(f"labels {tuple(labels.shape)} must match input_ids {tuple(input_ids.shape)}")
-        eng = self._ensure_engine(B, S + 1, 1, max(B * S, 32))
+        eng = self._ensure_engine(B, S + 1, 1, max(B * S, 32), must_prefill_rows=B * S)   # one pass over all B*S rows
         eng.reset()
         self._epoch += 1
         self._frame_pending = False

@@ -7,8 +7,11 @@ next queued utterance through `csm_prefill_slot`: the new context is prefilled r
 current length (the layout of a left-padded row, which the reference positions the same way), the other rows never
 notice.  Finished rows that find no successor are frozen by the per-row stop (they emit zeros).
 
-Limits (by construction of the shared-length cache): a joining context cannot be longer than the batch's current
-length; it waits in the queue until the batch has grown that far (or starts the next batch).
+A joining context LONGER than the batch's current length is admitted too: the resident rows are first moved up in the
+cache by the difference (`csm_shift_context`: keys re-rotated, RoPE is relative, so their continuation changes by fp32
+rounding only) and the batch's shared length grows to the new context's; the cache is re-homed into a larger engine
+first when it lacks the room.  A row that finds no queued utterance stays idle (frozen by the per-row stop) and is
+offered the queue again after every chunk.
 """
 from __future__ import annotations
 
@@ -33,6 +36,7 @@ class ContinuousBatcher:
         self._queue = deque()
         self._next_id = 0
         self.joined_mid_batch = 0      # utterances that took over a row of a running batch (statistics)
+        self.shifted_for_long_context = 0   # joins whose context was longer than the running batch (resident rows moved up)
 
     def submit(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: Optional[int] = None) -> int:
         """input_ids / attention_mask `[T, 33]` (or `[1, T, 33]`) of ONE utterance; returns its request id."""
@@ -99,15 +103,25 @@ class ContinuousBatcher:
                     r[2].append(toks[b, i])
                 if done or len(r[2]) >= r[1]:
                     results[r[0]] = torch.stack(r[2]) if r[2] else torch.zeros(0, C, dtype=torch.long)
-                    rows[b] = self._join(eng, b)
+                    rows[b] = None
+            # every idle row (just finished, or idle since an earlier chunk) is offered the queue
+            for b in range(B):
+                if rows[b] is None and self._queue:
+                    rows[b], eng = self._join(eng, b, k)
         m._epoch += 1
 
-    def _join(self, eng, row):
-        """first queued utterance whose context fits under the batch's current length takes over `row`"""
-        for j, (rid, ri, rm, budget) in enumerate(self._queue):
-            if ri.shape[0] <= eng.length:
-                del self._queue[j]
-                eng.prefill_slot(row, ri, rm)
-                self.joined_mid_batch += 1
-                return [rid, budget, []]
-        return None
+    def _join(self, eng, row, k):
+        """The first queued utterance takes over `row`.  Its context is placed right-aligned against the batch's current
+        length; a longer one first moves the resident rows up (Engine.prefill_slot -> shift_context), after the engine has
+        been re-homed into a larger one if the cache lacks the room.  Returns (row state, engine)."""
+        m = self.model
+        rid, ri, rm, budget = self._queue.popleft()
+        S = ri.shape[0]
+        need = max(eng.length, S) + k + 1
+        if need > eng.max_len:
+            eng = m._ensure_engine(self.B, need, max(4 * k, 32), 1, cont=True)
+        if S > eng.length:
+            self.shifted_for_long_context += 1
+        eng.prefill_slot(row, ri, rm)
+        self.joined_mid_batch += 1
+        return [rid, budget, []], eng

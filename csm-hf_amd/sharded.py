@@ -52,7 +52,10 @@ def _generate_rows(model, ids, mask, row0: int, kw) -> torch.Tensor:
             # the sampler's Philox counter uses the GLOBAL row (shard start + local row): every rank derives the same
             # seed from torch's seed, so without the offset local row i of every GPU would draw the same noise
             model.row_offset = row0 + a
-            outs.append(model.generate(ids[a:a + MAX_ROWS_PER_PASS], mask[a:a + MAX_ROWS_PER_PASS], **kw))
+            kwa = kw
+            if kw.get("noise") is not None:   # explicit draws [n, B_total, 32, V]: the rows of this pass (GLOBAL row index)
+                kwa = dict(kw, noise=kw["noise"][:, row0 + a: row0 + a + min(MAX_ROWS_PER_PASS, ids.shape[0] - a)])
+            outs.append(model.generate(ids[a:a + MAX_ROWS_PER_PASS], mask[a:a + MAX_ROWS_PER_PASS], **kwa))
     finally:
         model.row_offset = prev
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)

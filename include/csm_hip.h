@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 4
+#define CSM_ABI_VERSION 5
 
 enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
@@ -193,6 +193,9 @@ typedef struct {                                          /* fp32 device pointer
 } csm_mimi_weights_t;
 int csm_mimi_create(const csm_mimi_config_t* cfg, csm_mimi_t** out);
 int csm_mimi_destroy(csm_mimi_t* m);
+/* tuning switches of one handle: "skinny_rows" (GEMMs of <= n rows on the weight-streaming skinny GEMM; 0 = none),
+ * "splitk" (K split of GEMMs with too few tiles; 0 / 1).  With both 0 a stream is bitwise the one-shot decode. */
+int csm_mimi_set_option(csm_mimi_t* m, const char* name, int value);
 int csm_mimi_bind_weights(csm_mimi_t* m, const csm_mimi_weights_t* w);   /* borrowed pointers */
 /* codes [B][n_q][T] int64 (device) -> audio [B][T * samples_per_frame] fp32 (device); samples_per_frame = up_stride * prod(ratios) */
 int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* audio);
@@ -204,9 +207,14 @@ int csm_mimi_stream_decode(csm_mimi_t* m, const int64_t* codes, int T, float* au
 
 /* ---- continuous batching (no reference counterpart): a new utterance takes over batch row
  * `row` of the running batch between two frame-steps.  ids [S][C+1] / mask [S][C+1] on the device; S <= the batch's
- * current length (the context is placed right-aligned, like a left-padded row of the reference).  The row's frames from
+ * current length (the context is placed right-aligned, like a left-padded row of the reference; longer contexts:
+ * csm_shift_context first; contexts longer than max_prefill_rows are prefilled in chunks).  The row's frames from
  * the current frame index on belong to the new utterance; other rows are untouched. */
 int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, const uint8_t* mask, int S);
+/* A context LONGER than the running batch's current length: first move every resident row `delta` cache slots up (keys
+ * re-rotated by `delta`: RoPE is relative, the rows' results change by fp32 rounding only; kv_start of every row and the
+ * shared length grow by delta; length + delta <= max_len), then csm_prefill_slot.  No reference counterpart. */
+int csm_shift_context(csm_engine_t* e, int delta);
 /* ---- CSMModel.forward with labels (modeling_csm.py:367-465): the training objective, FORWARD ONLY.
  * labels [B,S,C+1] int64 on the device, -100 = ignored.  out3 (device, 3 floats) = (loss, backbone_loss, decoder_loss):
  * cross-entropy of the codebook-0 logits of position t against labels[:, t+1, 0], plus cross-entropy of the decoder's

@@ -232,6 +232,22 @@ def margin_check(toks, g, thresh=1e-4):
     return compared
 
 
+def solo_margin_agree(model, ids_row, mask_row, batch_row_toks, n, thresh=1e-4):
+    """A batch row against its SOLO run (single-sequence fp32-FMA kernels), by the same rule the reference-anchored tests
+    use: the two greedy streams must be equal up to (not including) the first sample whose solo top-1 margin is below
+    `thresh` -- two kernel families differ by fp32 summation order only, so nothing else may flip a token.  Returns
+    (samples compared, samples in the stream)."""
+    solo, lt, _ = traced_generate(model, ids_row, mask_row, n)
+    tv = torch.topk(lt[:, 0], 2, -1)[0]                     # [n, C, 2]
+    margin = (tv[..., 0] - tv[..., 1]).reshape(-1).numpy()
+    low = np.nonzero(margin < thresh)[0]
+    stop = int(low[0]) if len(low) else margin.size
+    a, b = solo[0].reshape(-1).numpy(), batch_row_toks.reshape(-1).numpy()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a[:stop], b[:stop]), f"batch row differs from its solo run before the first low-margin sample {stop}"
+    return stop, margin.size
+
+
 def test_csm1b_config1_fp32_bit_exact(gold):
     """BASELINE config 1: csm-1b, 64-frame context, 8 greedy frames, fp32 -- bit-exact token ids."""
     cfg = CSMConfig()
@@ -383,7 +399,8 @@ def test_csm1b_config2_200_frames(gold, csm1b_bf16):
 # ---------------------------------------------------------------------------------------------------
 def test_csm1b_batch16_rows_equal_solo_and_graph_equals_eager(csm1b_bf16):
     """config 4 per-GPU shape (16 utterances): the matrix-core batched kernels give every row the token stream
-    of its solo (M = 1, fp32-FMA kernels) run wherever the margin allows; eager == hipGraph bit for bit."""
+    of its solo (M = 1, fp32-FMA kernels) run up to the first sample whose solo margin is below 1e-4 (the rule of the
+    reference-anchored tests); eager == hipGraph bit for bit."""
     m = csm1b_bf16
     cfg = m.config
     ids, mask = synth_context(cfg, 16, 16, 48, seed=41)
@@ -392,14 +409,11 @@ def test_csm1b_batch16_rows_equal_solo_and_graph_equals_eager(csm1b_bf16):
     eager = m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False).cpu()
     m.use_graph = True
     assert torch.equal(full, eager)
-    agree = []
+    compared = total = 0
     for b in (0, 7, 15):
-        solo = m.generate(ids[b:b + 1].to(DEV), mask[b:b + 1].to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False).cpu()
-        same = (solo[0] == full[b]).reshape(-1)
-        first_diff = int((~same).nonzero()[0]) if not bool(same.all()) else same.numel()
-        agree.append(first_diff)
-    # fp32-class differences between the two kernel families can flip a near-tie; require long agreement
-    assert min(agree) >= 32 * 2 and sum(a == 32 * 6 for a in agree) >= 2, agree
+        c, t = solo_margin_agree(m, ids[b:b + 1], mask[b:b + 1], full[b], 6)
+        compared, total = compared + c, total + t
+    assert compared >= total // 2, (compared, total)     # the rule is not vacuous: low-margin samples are rare
 
 
 def test_csm1b_continuous_batching_on_the_matrix_core_path(csm1b_bf16):
@@ -417,14 +431,12 @@ def test_csm1b_continuous_batching_on_the_matrix_core_path(csm1b_bf16):
     rid = [cb.submit(a, b, max_new_frames=n) for a, b, n in reqs]
     out = cb.run()
     assert sorted(out) == rid and cb.joined_mid_batch >= 3
-    agree, full = [], 0
+    compared = total = 0
     for r, (ids, mask, budget) in zip(rid, reqs):
-        solo = m.generate(ids[None].to(DEV), mask[None].to(DEV), max_new_frames=budget, topk=1, stop_on_all_zeros=False).cpu()[0]
-        assert out[r].shape == solo.shape
-        same = (solo == out[r]).reshape(-1)
-        agree.append(int((~same).nonzero()[0]) if not bool(same.all()) else same.numel())
-        full += bool(same.all())
-    assert min(agree) >= 32 and full >= 5, agree
+        assert out[r].shape == (budget, cfg.audio_num_codebooks)
+        c, t = solo_margin_agree(m, ids[None], mask[None], out[r], budget)
+        compared, total = compared + c, total + t
+    assert compared >= total // 2, (compared, total)
 
 
 @pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (32, {}), (40, {}), (70, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
@@ -444,13 +456,12 @@ def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
     finally:
         if m._engine is not None:
             for k in opts:
-                m._engine.set_option(k, {"use_planes": 15, "tile_weights": 1}[k])
-    agree = []
+                m._engine.set_option(k, {"use_planes": 31, "tile_weights": 1}[k])
+    compared = total = 0
     for b in sorted({0, min(17, B - 1), B - 1}):
-        solo = m.generate(ids[b:b + 1].to(DEV), mask[b:b + 1].to(DEV), max_new_frames=4, topk=1, stop_on_all_zeros=False).cpu()
-        same = (solo[0] == full[b]).reshape(-1)
-        agree.append(int((~same).nonzero()[0]) if not bool(same.all()) else same.numel())
-    assert min(agree) >= 32 * 2, agree
+        c, t = solo_margin_agree(m, ids[b:b + 1], mask[b:b + 1], full[b], 4)
+        compared, total = compared + c, total + t
+    assert compared >= total // 2, (compared, total)
 
 
 def test_csm1b_config3_batch16_voiceclone_rows_vs_reference(gold, csm1b_bf16):

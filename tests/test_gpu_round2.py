@@ -162,18 +162,16 @@ def test_weight_streamer_is_transparent(dtype):
     cfg, sd, m = tiny_model(dtype)
     ids, mask = synth_context(cfg, 1, 4, 6, seed=12)
     ids, mask = ids.to(DEV), mask.to(DEV)
-    # (a first call loads every kernel's code object on a fresh box -- tens of milliseconds in which a streamer waiting for
-    # the chain's first launch may time out, harmlessly; the statistics below are those of a warm call)
-    m.generate(ids, mask, max_new_frames=2, topk=1, stop_on_all_zeros=False)
+    # Deterministic statistics: the streamer's give-up is a 20 ms timeout by design (harmless -- it only reads -- but it
+    # would show in `gave_up`).  On a fresh box the first calls load every kernel's code object and capture + upload the
+    # graph, which can take longer than that, so the graph is warmed with the SAME call (same frame count, same graph
+    # key) and the stream drained before the call whose statistics are read: that one only replays.
+    for _ in range(2):
+        m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False)
+    m._engine.sync()
+    torch.cuda.synchronize()
     on = m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
     st = m._engine.prefetch_stats()
-    if st["gave_up"]:
-        # the streamer's give-up is a 20 ms timeout by design (harmless: it only reads); this call captured a new graph
-        # (12 frames) and on a fresh box that can take longer.  One more warm call must be clean -- two in a row fail.
-        # Seen once in a full-suite run on a fresh box, not reproduced in 12 further runs.  Tokens stay strict.
-        again = m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
-        assert torch.equal(on, again)
-        st = m._engine.prefetch_stats()
     assert 0 <= st["xcd_rotation"] < 8, "dispatch is not round-robin over the XCDs on this box: streamer disabled"
     assert st["gave_up"] == 0 and st["finished"] > 0 and st["segments"] > 0 and st["streamed_launches"] > 100, st
     assert 0 < st["scheduled_bytes"] <= st["streamed_launch_bytes"], st

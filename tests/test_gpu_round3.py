@@ -1,0 +1,252 @@
+"""GPU suite, round 3: contexts longer than the running batch join it (csm_shift_context: resident rows moved up in the
+cache, keys re-rotated), csm_prefill_slot in chunks, the training forward growing an engine whose prefill scratch is too
+small, graph-cache keys at B = 1, an empty HF cache as a fresh context, the README flow end to end
+(save_pretrained -> from_pretrained -> CSMProcessor -> generate -> MimiDecoder.decode), and bench.py under the RCCL
+backend with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from csm_hf_amd import CSMConfig, CSMModel
+from csm_hf_amd.synth import synth_state_dict, synth_context
+from oracle import csm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tiny_model(dtype=torch.float32, seed=0):
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=seed, std=0.05)
+    m = CSMModel(cfg)
+    m.load_state_dict({k: v.to(dtype) for k, v in sd.items()})
+    return cfg, sd, m.to(DEV).eval()
+
+
+def oracle_solo(sd, cfg, ids, mask, n, want_margin=False):
+    tr = {}
+    toks = O.generate(sd, cfg, ids[None], mask[None], max_new_frames=n, topk=1, stop_on_all_zeros=False, trace=tr)[0]
+    lg = tr["logits"][:, 0]                                    # [n, C, V]
+    tv = torch.topk(lg, 2, -1)[0]
+    return toks, (tv[..., 0] - tv[..., 1]).reshape(-1)
+
+
+def assert_margin_equal(got, want, margin, thresh=1e-4, what=""):
+    low = (margin < thresh).nonzero()
+    stop = int(low[0]) if len(low) else margin.numel()
+    a, b = got.reshape(-1)[:stop], want.reshape(-1)[:stop]
+    assert torch.equal(a, b), f"{what}: differs before the first low-margin sample ({stop})"
+    return stop
+
+
+def test_shift_context_keeps_every_row_on_its_stream():
+    """csm_shift_context moves the resident rows `delta` cache slots up and rotates their keys by delta: attention sees
+    position DIFFERENCES only, so every row continues on the stream of its solo oracle run (margin rule: the extra
+    rotation is an fp32 rounding)."""
+    cfg, sd, m = tiny_model()
+    ids, mask = synth_context(cfg, 3, 3, 7, seed=21)
+    ids[1, :4], mask[1, :4] = 0, 0                              # a left-padded row among them
+    n1, n2 = 3, 6
+    eng = m._ensure_engine(3, 10 + 40 + n1 + n2 + 1, n1 + n2, 3 * 10)
+    eng.reset()
+    eng.set_kv_start(m._kv_starts(mask, 3, 10))
+    eng.prefill(ids, mask, want_outputs=False)
+    s = eng.sampling(temperature=1.0, topk=1, seed=1)
+    eng.generate(s, n1, True)
+    eng.shift_context(37)
+    assert eng.length == 10 + n1 + 37 and eng.device_counters()[0] == eng.length
+    eng.generate(s, n2, True)
+    got = eng.read_frames(0, n1 + n2).cpu()
+    compared = 0
+    for b in range(3):
+        v = mask[b].sum(-1) > 0
+        want, margin = oracle_solo(sd, cfg, ids[b][v], mask[b][v], n1 + n2)
+        compared += assert_margin_equal(got[b], want, margin, what=f"row {b}")
+    assert compared >= 3 * (n1 + n2) * 32 * 3 // 4
+    with pytest.raises(ValueError):
+        eng.shift_context(10 ** 6)                              # beyond the cache: capacity error, state untouched
+    eng.generate(s, 1, True)
+    m._drop_engine()
+
+
+def test_long_context_joins_a_running_batch_and_slot_prefill_chunks():
+    """SURVEY.md section 8 row f-4, the gap VERDICT r2 named: a queued context LONGER than the running batch's current
+    length is admitted (resident rows moved up), also when it is longer than the engine's prefill scratch (chunks of
+    max_prefill_rows inside csm_prefill_slot) and when the cache must be re-homed first.  Every utterance's greedy frames
+    equal its solo run through the oracle (margin rule for rows that were moved)."""
+    from csm_hf_amd import ContinuousBatcher
+    cfg, sd, m = tiny_model()
+    specs = [(3, 6, 14), (2, 4, 3), (6, 150, 5), (2, 5, 4), (1, 30, 3)]     # (text frames, audio frames, budget)
+    reqs = []
+    for i, (nt, na, budget) in enumerate(specs):
+        ids, mask = synth_context(cfg, 1, nt, na, seed=300 + i)
+        reqs.append((ids[0], mask[0], budget))
+    cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=3, initial_frames=8)
+    rid = [cb.submit(i, k, max_new_frames=b) for i, k, b in reqs]
+    out = cb.run()
+    assert sorted(out) == sorted(rid)
+    assert cb.shifted_for_long_context >= 1 and cb.joined_mid_batch >= 3
+    assert m._engine.max_prefill_rows < 156                     # the 156-frame context went through the slot prefill in chunks
+    for r, (ids, mask, budget) in zip(rid, reqs):
+        want, margin = oracle_solo(sd, cfg, ids, mask, budget)
+        assert out[r].shape == (budget, 32)
+        assert_margin_equal(out[r], want, margin, what=f"request {r}")
+    m._drop_engine()
+
+
+def test_training_forward_grows_a_small_engine():
+    """after a short generate() the engine's prefill scratch holds 128 rows; forward(labels=...) with
+    B*S = 300 must grow it (the loss pass cannot chunk) instead of raising, and give the fresh-model result."""
+    cfg, sd, m = tiny_model()
+    ids0, mask0 = synth_context(cfg, 1, 2, 4, seed=5)
+    m.generate(ids0.to(DEV), mask0.to(DEV), max_new_frames=2, topk=1, stop_on_all_zeros=False)
+    assert m._engine.max_prefill_rows == 128
+    ids, mask = synth_context(cfg, 3, 10, 90, seed=6)
+    labels = torch.full_like(ids, -100)
+    labels[:, 10:, :32] = ids[:, 10:, :32]
+    out = m.forward(ids.to(DEV), mask.to(DEV), labels=labels.to(DEV), return_dict=True)
+    assert m._engine.max_prefill_rows >= 300
+    want = O.forward_loss({k: v.float() for k, v in sd.items()}, cfg, ids, mask, labels)
+    for got, w in zip((out.loss, out.backbone_loss, out.decoder_loss), want[:3]):
+        assert abs(float(got) - float(w)) < 2e-4 * abs(float(w)), (float(got), float(w))
+    m._drop_engine()
+
+
+def test_graph_key_separates_per_row_stop_at_batch_one():
+    """at B = 1 a frame-step captured with the per-row stop (its sampler launches freeze a finished row) must not
+    be replayed for a generate() without it: two cache entries, not one."""
+    cfg, sd, m = tiny_model()
+    ids, mask = synth_context(cfg, 1, 2, 5, seed=8)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    a = m.generate(ids, mask, max_new_frames=3, topk=1, stop_on_all_zeros=True, per_row_stop=True).cpu()
+    c0 = m._engine.graph_stats()[0]
+    b = m.generate(ids, mask, max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu()
+    assert m._engine.graph_stats()[0] == c0 + 1
+    assert torch.equal(a, b)                                    # no all-zero frame with these weights: same tokens
+    m._drop_engine()
+
+
+def test_empty_hf_cache_is_a_fresh_context():
+    """`past_key_values=DynamicCache()` (or `()`) is how HF callers start a context; the reference accepts it."""
+    from transformers import DynamicCache
+    cfg, sd, m = tiny_model()
+    ids, mask = synth_context(cfg, 2, 2, 5, seed=9)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    want = m.forward(ids, mask, use_cache=True, return_dict=True)
+    for empty in (DynamicCache(), ()):
+        got = m.forward(ids, mask, past_key_values=empty, use_cache=True, return_dict=True)
+        assert torch.equal(got.logits, want.logits) and got.past_key_values.get_seq_length() == 7
+    fr = m.generate_frame(ids, mask, temperature=1.0, topk=1, past_key_values=DynamicCache(), use_cache=True)
+    assert torch.equal(fr.samples.cpu(), O.generate(sd, cfg, ids.cpu(), mask.cpu(), max_new_frames=1, topk=1, stop_on_all_zeros=False)[:, 0])
+    m._drop_engine()
+
+
+class _TinyText:
+    """stand-in for the Llama tokenizer inside the tiny config's 211-entry text vocabulary"""
+    bos, eos = 209, 210
+
+    def encode(self, text, add_special_tokens=True):
+        ids = [3 + (ord(c) * 131 + i * 7) % 200 for i, c in enumerate(text)]
+        return [self.bos] + ids + [self.eos] if add_special_tokens else ids
+
+
+class _TinyAudio(torch.nn.Module):
+    """stand-in for Mimi ENCODE (out of scope) inside the tiny config's 51-entry audio vocabulary: [1, 32, T // 1920] codes"""
+    sample_rate = 24000
+
+    def __init__(self):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def encode(self, wav):
+        F = wav.shape[-1] // 1920
+        x = wav[0, 0, : F * 1920].reshape(F, 1920)
+        base = (x.abs().sum(-1) * 1000).long()
+        return ((base[None, :] + torch.arange(32)[:, None] * 37) % 50 + 1).unsqueeze(0).float()
+
+
+def test_readme_flow_end_to_end(tmp_path):
+    """The reference's README example (README.md:23-123) on the tiny configuration, every step through this package:
+    checkpoint directory -> CSMModel.from_pretrained -> CSMProcessor(messages, audios) -> model.generate ->
+    audio_tokenizer.decode(gen_frames.permute(0, 2, 1)) (MimiDecoder).  Checked against the oracle (tokens) and the codec
+    oracle (waveform, 1e-4 of the peak)."""
+    import dataclasses
+    from csm_hf_amd import CSMProcessor, MimiDecoder
+    from csm_hf_amd.mimi import MimiDecodeConfig, synth_mimi_state_dict
+    from oracle import mimi_oracle as MO
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    src = CSMModel(cfg)
+    src.load_state_dict(sd)
+    src.save_pretrained(str(tmp_path / "ckpt"))
+    model = CSMModel.from_pretrained(str(tmp_path / "ckpt"), torch_dtype=torch.float32)
+    model.to("cuda")
+    processor = CSMProcessor(_TinyText(), _TinyAudio())
+    g = torch.Generator().manual_seed(3)
+    inputs = processor(
+        messages=[{"role": "speaker_0", "content": [{"type": "text", "text": "clip transcript"}, {"type": "audio"}]},
+                  {"role": "speaker_0", "content": [{"type": "text", "text": "Hello, this is voice cloning speaking"}]}],
+        audios=[torch.rand(1920 * 6 + 17, generator=g)], return_tensors="pt")
+    ids, mask = inputs["input_ids"], inputs["attention_mask"]
+    assert ids.shape[0] == 1 and ids.shape[2] == 33 and int(ids[..., :32].max()) < cfg.audio_vocab_size
+    with torch.inference_mode():
+        gen_frames = model.generate(input_ids=ids.cuda(), attention_mask=mask.cuda(), max_new_frames=7, topk=1, temperature=1.0,
+                                    use_cache=True, stop_on_all_zeros=True)
+    want = O.generate(sd, cfg, ids, mask, max_new_frames=7, topk=1, temperature=1.0, stop_on_all_zeros=True)
+    assert gen_frames.shape == want.shape == (1, 7, 32) and torch.equal(gen_frames.cpu(), want)
+    mcfg = dataclasses.replace(MimiDecodeConfig.tiny(), num_quantizers=32)
+    msd = synth_mimi_state_dict(mcfg, seed=0)
+    audio_tokenizer = MimiDecoder(mcfg, msd, "cuda:0", max_frames=16)
+    decoded_audio = audio_tokenizer.decode(gen_frames.permute(0, 2, 1)).squeeze(0).squeeze(0)
+    want_audio = MO.decode(msd, mcfg, want.permute(0, 2, 1))[0, 0]
+    assert decoded_audio.shape == want_audio.shape == (7 * mcfg.samples_per_frame,)
+    assert float((decoded_audio.cpu().double() - want_audio.double()).abs().max() / want_audio.double().abs().max()) < 1e-4
+    audio_array = (decoded_audio * 32768).to(torch.int16).cpu().numpy()
+    assert audio_array.dtype == np.int16 and audio_array.shape == (7 * mcfg.samples_per_frame,)
+    audio_tokenizer.close()
+    model._drop_engine()
+
+
+def _torchrun_bench(extra_env, args, timeout=900):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    return r.returncode, line, r.stderr[-3000:]
+
+
+def test_bench_under_rccl_with_one_rank():
+    """the RCCL branch of bench.py -- init_process_group("nccl", device_id=...), the float64 MAX
+    all-reduce, the int64 all-gather of the frames and the config-4 gather -- executes on real hardware (world size 1 is
+    legal), launched exactly as the driver launches N > 1; its tokens equal the gloo run's and the launcher-less run's."""
+    args = ["--gpus", "1", "--steps", "4", "--warmup", "2", "--ctx", "64", "--no-cpu-baseline", "--config4", "1", "--config4-frames", "3"]
+    rc, nc, err = _torchrun_bench({}, args)
+    assert rc == 0 and nc is not None, err
+    assert nc["dist_backend"] == "nccl" and nc["n_gpus"] == 1
+    rc, gl, err = _torchrun_bench({"CSM_BENCH_ONE_DEVICE": "1"}, args)
+    assert rc == 0 and gl is not None and gl["dist_backend"] == "gloo", err
+    assert nc["tokens_checksum_per_rank"] == gl["tokens_checksum_per_rank"]
+    for leg in ("weak", "strong"):
+        assert nc["config4"][leg]["tokens_checksum"] == gl["config4"][leg]["tokens_checksum"]
+        assert nc["config4"][leg]["rows_total"] == (16 if leg == "weak" else 128)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900)
+    solo = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and solo and solo[-1]["dist_backend"] is None, r.stderr[-2000:]
+    assert solo[-1]["tokens_checksum_per_rank"] == nc["tokens_checksum_per_rank"]

@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in csm_hip.h but not exported"
     assert declared == set(EXPORTS)
-    assert lib.csm_abi_version() == 4
+    from csm_hf_amd.engine import ABI_VERSION
+    assert lib.csm_abi_version() == ABI_VERSION == 5
 
 
 def test_no_gpu_fails_loudly():

@@ -122,7 +122,7 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
         assert t == Ts
         got = torch.cat(parts, dim=-1)
         # GEMMs of <= 16 rows (calls of up to 8 frames) run on the skinny-GEMM kernels (fp32 FMA order, not the MFMA chain's):
-        # measured 2.2e-6 of the peak over 160 frames at the full shape; bitwise equal with CSM_MIMI_SKINNY=0 (test below)
+        # measured 2.2e-6 of the peak over 160 frames at the full shape; bitwise equal with option skinny_rows = 0 (test below)
         assert rel_max(got.cpu(), whole.cpu()) < 1e-5, chunks
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, cfg.num_quantizers, 65, dtype=torch.long))          # beyond max_frames
@@ -133,11 +133,11 @@ def test_hip_decode_vs_transformers_golden_and_oracle(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["tiny", "full"])
-def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
+def test_stream_decode_small_calls_on_the_skinny_gemm(name):
     """GEMMs of few rows (streaming calls of a few frames, short one-shot decodes) run on the weight-streaming skinny GEMM
     (4.0 -> 1.0 ms per one-frame call at the kyutai/mimi shape).  Pinned three ways: against the ORACLE at the codec's 1e-4
     of the peak (the anchor), against the one-shot decode on the tile kernel at 1e-5 (fp32 summation order of the two GEMM
-    kernels), and -- with the skinny path and the K split switched off at create -- the stream bitwise against the one-shot
+    kernels), and -- with the skinny path and the K split switched off (csm_mimi_set_option) -- the stream bitwise against the one-shot
     decode (one kernel and one summation order for every row count)."""
     from csm_hf_amd import MimiDecoder
     cfg = CASES[name]
@@ -161,11 +161,11 @@ def test_stream_decode_small_calls_on_the_skinny_gemm(name, monkeypatch):
         return torch.cat(parts, dim=-1)
 
     fast = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
-    monkeypatch.setenv("CSM_MIMI_SKINNY", "0")
-    monkeypatch.setenv("CSM_MIMI_SPLITK", "0")
     plain = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
-    monkeypatch.delenv("CSM_MIMI_SKINNY")
-    monkeypatch.delenv("CSM_MIMI_SPLITK")
+    plain.set_option("skinny_rows", 0)
+    plain.set_option("splitk", 0)
+    with pytest.raises(RuntimeError):
+        plain.set_option("no_such_option", 1)
     whole = plain.decode(cd)                              # every GEMM on the 128 x 128 tile, K walked in one piece
     assert rel_max(whole.cpu(), want) < 1e-4
     assert rel_max(fast.decode(cd).cpu(), want) < 1e-4   # short one-shot decodes take the skinny path too

@@ -1,5 +1,6 @@
 """CPU suite: host logic of the continuous batcher (csm_hf_amd/serving.py) on a stub engine -- who joins which row
-when, budgets, the all-zero end-of-utterance frame, contexts that must wait, the frame ring wrapping."""
+when, budgets, the all-zero end-of-utterance frame, contexts longer than the running batch (the resident rows are moved
+up), idle rows offered the queue again after every chunk, the frame ring wrapping."""
 import types
 
 import torch
@@ -51,7 +52,10 @@ class StubEngine:
         return self.ring[:, first:first + n].clone()
 
     def prefill_slot(self, row, ids, mask):
-        assert ids.shape[0] <= self.length, "joining context longer than the batch"
+        if ids.shape[0] > self.length:            # Engine.prefill_slot: resident rows move up, the shared length grows
+            assert ids.shape[0] + 1 <= self.max_len, "the batcher must re-home the cache before a long context joins"
+            self.log.append(("shift", ids.shape[0] - self.length))
+            self.length = ids.shape[0]
         self.key[row] = int(ids[-1, 0])
         self.t[row] = 0
         self.log.append(("join", row, ids.shape[0], self.length))
@@ -64,7 +68,7 @@ class StubModel:
         self.max_len, self.max_frames = max_len, max_frames
         self.engines = []
 
-    def _ensure_engine(self, B, need_len, frames, rows, cont=False):
+    def _ensure_engine(self, B, need_len, frames, rows, cont=False, must_prefill_rows=0):
         if cont:
             e = self.engines[-1]
             e.max_len = max(need_len, 2 * e.max_len)
@@ -106,19 +110,58 @@ def test_rows_are_handed_over_and_results_are_per_utterance():
     assert all(j[2] <= j[3] for j in joins)
 
 
-def test_context_longer_than_the_batch_waits_for_the_next_batch_and_ring_wraps():
+def test_context_longer_than_the_batch_joins_by_moving_the_resident_rows_up_and_ring_wraps():
     m = StubModel(max_frames=8)
     cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=4)
     a = cb.submit(*utterance(1, 3), max_new_frames=2)
     b = cb.submit(*utterance(2, 3), max_new_frames=30)                          # 30 frames through an 8-frame ring
-    c = cb.submit(*utterance(3, 500), max_new_frames=2)                         # cannot join a batch of length ~10
-    d = cb.submit(*utterance(4, 3), max_new_frames=2)                           # ... but the one behind it can
+    c = cb.submit(*utterance(3, 500), max_new_frames=2)                         # longer than the running batch (length 7)
+    d = cb.submit(*utterance(4, 3), max_new_frames=2)
     out = cb.run()
     assert [out[x].shape[0] for x in (a, b, c, d)] == [2, 30, 2, 2]
-    assert torch.equal(out[b][:, 5], torch.arange(30) + 201)
-    assert len(m.engines) == 2 and ("rewind",) in m.engines[0].log
-    assert [x for x in m.engines[0].log if x[0] == "join"][0][1:3] == (0, 3)     # utterance 4 took over row 0
-    assert m.engines[1].log[0] == ("prefill", 2, 500)                           # utterance 3 started the next batch (row 1 idle)
+    assert torch.equal(out[b][:, 5], torch.arange(30) + 201)                    # the resident row never notices
+    e = m.engines[0]
+    assert len(m.engines) == 1 and ("rewind",) in e.log
+    joins = [x for x in e.log if x[0] == "join"]
+    assert joins[0][1:3] == (0, 500) and joins[1][1:3] == (0, 3)                # utterance 3, then 4, took over row 0
+    assert ("shift", 493) in e.log and cb.shifted_for_long_context == 1         # 7 cached positions -> 500
+
+
+def test_long_context_re_homes_the_cache_first_and_idle_rows_are_offered_the_queue_again():
+    m = StubModel(max_len=0)
+    cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=4, initial_frames=8)
+    a = cb.submit(*utterance(1, 3), max_new_frames=2)
+    b = cb.submit(*utterance(2, 3), max_new_frames=12)
+    out_first = None
+    c = cb.submit(*utterance(3, 300), max_new_frames=2)                         # needs a larger cache than the batch has
+    out = cb.run()
+    assert [out[x].shape[0] for x in (a, b, c)] == [2, 12, 2]
+    e = m.engines[0]
+    grow = [i for i, x in enumerate(e.log) if x[0] == "grow"]
+    shift = [i for i, x in enumerate(e.log) if x[0] == "shift"]
+    assert grow and shift and grow[0] < shift[0]                                # re-homed BEFORE the rows were moved up
+    # an utterance submitted while a row sits idle is picked up at the next chunk boundary
+    m2 = StubModel()
+    cb2 = ContinuousBatcher(m2, batch_size=2, topk=1, check_every=2)
+    x = cb2.submit(*utterance(1, 3), max_new_frames=2)
+    y = cb2.submit(*utterance(2, 3), max_new_frames=20)
+    orig = m2._ensure_engine
+
+    def late_submit(*a_, **k_):
+        eng = orig(*a_, **k_)
+        gen = eng.generate
+
+        def generate(s, n, use_graph=True):
+            gen(s, n, use_graph)
+            if eng.frames == 6 and not getattr(eng, "_late", False):            # row 0 has been idle for two chunks
+                eng._late = True
+                cb2.late = cb2.submit(*utterance(3, 3), max_new_frames=2)
+        eng.generate = generate
+        return eng
+    m2._ensure_engine = late_submit
+    out2 = cb2.run()
+    assert out2[cb2.late].shape[0] == 2 and len(m2.engines) == 1                # joined the running batch, no new one
+    assert [z for z in m2.engines[0].log if z[0] == "join"][0][1] == 0
 
 
 def test_cache_growth_is_requested_as_a_continuation():

@@ -89,3 +89,23 @@ def test_generate_sharded_gloo(world, B):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r for r, _ in res) == list(range(world)) and all(ok for _, ok in res)
+
+
+def test_explicit_noise_is_sliced_per_engine_pass():
+    """generate_sharded(noise=[n, B_total, 32, V]): every 64-row engine pass receives the draws of ITS rows (global row
+    index), not the full-batch tensor (which CSMModel._check_noise rejects on shape)."""
+    seen = []
+
+    class NoiseModel(StubModel):
+        def generate(self, ids, mask, max_new_frames=3, noise=None, **kw):
+            assert noise is not None and noise.shape[1] == ids.shape[0], (noise.shape, ids.shape)
+            seen.append((self.row_offset, ids.shape[0], float(noise[0, 0, 0, 0]), float(noise[0, -1, 0, 0])))
+            return super().generate(ids, mask, max_new_frames=max_new_frames, **kw)
+
+    B, n, V = 70, 2, 5
+    ids = torch.ones(B, 2, 33, dtype=torch.long)
+    mask = torch.ones(B, 2, 33, dtype=torch.int32)
+    noise = torch.arange(B, dtype=torch.float32)[None, :, None, None].expand(n, B, 32, V).contiguous()   # value = global row
+    out = generate_sharded(NoiseModel(), ids, mask, max_new_frames=n, stop_on_all_zeros=False, noise=noise)
+    assert out.shape[0] == B
+    assert seen == [(0, 64, 0.0, 63.0), (64, 6, 64.0, 69.0)]
