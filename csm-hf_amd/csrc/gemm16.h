@@ -287,42 +287,57 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #pragma unroll
   for (int t = 0; t < PT; ++t) *reinterpret_cast<f32x4*>(red + ((wave * PT + t) * 64 + lane) * 4) = acc[t];
   __syncthreads();
-  for (int i = tid; i < PT * 256; i += 64 * NW) {
-    float s = 0.f;
+  // quad q = 4 consecutive panel elements: summed over the waves, and (KB > 1) published, by ONE thread as 16 bytes
+  constexpr int NQ = (PT * 64 + 64 * NW - 1) / (64 * NW);
+  f32x4 mine[NQ];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += red[w * PT * 256 + i];
-    panel[i] = s;
+  for (int e = 0; e < NQ; ++e) {
+    const int q = tid + e * 64 * NW;
+    mine[e] = (f32x4)(0.f);
+    if (q < PT * 64) {
+      f32x4 s = (f32x4)(0.f);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(red + w * PT * 256 + q * 4);
+      mine[e] = s;
+      *reinterpret_cast<f32x4*>(panel + q * 4) = s;
+    }
   }
   if (KB > 1) {
-    // ---- K reduction across workgroups: slab + ticket, last arriver combines (cdna guide, Guideline 16).
+    // ---- K reduction across workgroups: slab + ticket, last arriver combines (cdna guide, section 5 "in-launch split-K
+    // reduction", the write-through form): 16-byte sc1 slab stores (one fabric write per quad; the 4-byte agent-scope atomic
+    // stores used before are ~6x the time per byte), every wave drains its stores, one relaxed agent ticket; the reducer
+    // reads the slabs with 16-byte sc1 loads (L1 bypassed, served coherently) -- valid because the producers stored sc1 --
+    // instead of an agent acquire fence (buffer_inv sc1, ~1.7 us on its own) + plain loads.  Placement-independent.
     // A two-launch variant (partials, then a reduce kernel) measured the same or slower (dec 11.7 vs 11.1 us,
-    // backbone 19.6 vs 16.9 us at M = 16): the tail is not the limiter of this kernel. ---------------------
-    float* slab = slabs + ((size_t)blockIdx.x * KB + blockIdx.y) * (PT * 256);
-    // write-through (sc1) slab stores: no release fence / L2 write-back per workgroup needed
-    for (int i = tid; i < PT * 256; i += 64 * NW)   // same thread wrote panel[i]
-      __hip_atomic_store(slab + i, panel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // backbone 19.6 vs 16.9 us at M = 16). ---------------------
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
+    const unsigned slab_off = (unsigned)(((size_t)blockIdx.x * KB + blockIdx.y) * (PT * 256) * sizeof(float));
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = tid + e * 64 * NW;
+      if (q < PT * 64) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, /*sc1*/ 16);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = tk == KB - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (last) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *flag = last;
     }
     __syncthreads();
     if (!*flag) return;
-    const float* base = slabs + (size_t)blockIdx.x * KB * (PT * 256);
-    for (int i = tid; i < PT * 256; i += 64 * NW) {
-      float v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
+    const unsigned base_off = (unsigned)((size_t)blockIdx.x * KB * (PT * 256) * sizeof(float));
+    for (int q = tid; q < PT * 64; q += 64 * NW) {
+      f32x4 v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) v[kb] = kb < KB ? base[(size_t)kb * (PT * 256) + i] : 0.f;
-      float s = 0.f;
+      for (int kb = 0; kb < 16; ++kb)
+        v[kb] = kb < KB ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, /*sc1*/ 16))
+                        : (f32x4)(0.f);
+      f32x4 s = (f32x4)(0.f);
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) s += v[kb];
-      panel[i] = s;
+      *reinterpret_cast<f32x4*>(panel + q * 4) = s;
     }
   }
   __syncthreads();

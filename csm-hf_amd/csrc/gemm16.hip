@@ -66,12 +66,15 @@ static int launch_gemm16_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
     return launch_nw<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
   // 64-row panels (x slice reused by 4 tiles) when that still leaves >= 128 workgroups, else 16-row panels; gate/up
-  // on activation planes: 32-row panels (two workgroups per CU, one's tail under the other's stream: B=16 5.20 -> 5.04 ms)
+  // on activation planes: 32-row panels (two workgroups per CU, one's tail under the other's stream: B=16 5.20 -> 5.04 ms);
+  // round 3: the K-split down_proj of the decoder (64 tiles x 8 splits) on planes takes 32-row panels too -- 256 workgroups,
+  // half the plane traffic through the CUs' L1s (swept nw x kb x pt in {8x8, 16x4, 4x16} x {1, 2, 4}: 5.05 ... 5.43 ms per
+  // step, 8 x 8 x 2 best, 5.15 -> 5.05; profiles/r03_b16_g16_down_sweep.txt)
   const int ntiles = (a.N + 15) / 16;
   const bool big = a.g16_pt ? a.g16_pt == 4 : (KB > 1 ? ntiles >= 128 : ntiles / 4 >= 128);
 #define G16(P, E)                                                                                              \
   if (pro == P && epi == E) {                                                                                  \
-    if (a.g16_pt == 2 || (!a.g16_pt && a.xplanes && E == EPI_SWIGLU))                                              \
+    if (a.g16_pt == 2 || (!a.g16_pt && a.xplanes && (E == EPI_SWIGLU || (KB > 1 && !big))))                         \
       return launch_nw<WT, float, P, E, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);             \
     if (big) return launch_nw<WT, float, P, E, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);       \
     return launch_nw<WT, float, P, E, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);                \

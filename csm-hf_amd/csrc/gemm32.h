@@ -124,38 +124,49 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     for (int mt = 0; mt < MT; ++mt)
       *reinterpret_cast<f32x4*>(red + ((wave * U + t * MT + mt) * 64 + lane) * 4) = acc[t][mt];
   __syncthreads();
-  for (int i = tid; i < U * 256; i += 64 * NW) {
-    float s = 0.f;
+  constexpr int NQ = (U * 64 + 64 * NW - 1) / (64 * NW);   // quads (4 consecutive panel elements) per thread
+  f32x4 mine[NQ];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += red[w * U * 256 + i];
-    panel[i] = s;
+  for (int e = 0; e < NQ; ++e) {
+    const int q = tid + e * 64 * NW;
+    mine[e] = (f32x4)(0.f);
+    if (q < U * 64) {
+      f32x4 s = (f32x4)(0.f);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(red + w * U * 256 + q * 4);
+      mine[e] = s;
+      *reinterpret_cast<f32x4*>(panel + q * 4) = s;
+    }
   }
-  if (KB > 1) {   // split-K across workgroups: slab + ticket, last arriver combines (as in gemm16.h)
-    float* slab = slabs + ((size_t)blockIdx.x * KB + blockIdx.y) * (U * 256);
-    for (int i = tid; i < U * 256; i += 64 * NW)
-      __hip_atomic_store(slab + i, panel[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (KB > 1) {   // split-K across workgroups: 16-byte sc1 slab stores + ticket, the last arriver combines with sc1 loads (gemm16.h)
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
+    const unsigned slab_off = (unsigned)(((size_t)blockIdx.x * KB + blockIdx.y) * (U * 256) * sizeof(float));
+#pragma unroll
+    for (int e = 0; e < NQ; ++e) {
+      const int q = tid + e * 64 * NW;
+      if (q < U * 64) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, /*sc1*/ 16);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = tk == KB - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (last) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *flag = last;
     }
     __syncthreads();
     if (!*flag) return;
-    const float* base = slabs + (size_t)blockIdx.x * KB * (U * 256);
-    for (int i = tid; i < U * 256; i += 64 * NW) {
-      float v[16];
+    const unsigned base_off = (unsigned)((size_t)blockIdx.x * KB * (U * 256) * sizeof(float));
+    for (int q = tid; q < U * 64; q += 64 * NW) {
+      f32x4 v[16];
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) v[kb] = kb < KB ? base[(size_t)kb * (U * 256) + i] : 0.f;
-      float s = 0.f;
+      for (int kb = 0; kb < 16; ++kb)
+        v[kb] = kb < KB ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * U * 1024 + q * 16), 0, /*sc1*/ 16))
+                        : (f32x4)(0.f);
+      f32x4 s = (f32x4)(0.f);
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) s += v[kb];
-      panel[i] = s;
+      *reinterpret_cast<f32x4*>(panel + q * 4) = s;
     }
   }
   __syncthreads();

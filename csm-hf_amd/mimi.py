@@ -62,6 +62,33 @@ class MimiDecodeConfig:
                    upsampling_ratios=[4, 2], num_filters=64)
 
 
+def decode_gemm_work(cfg: "MimiDecodeConfig", T: int):
+    """Algorithmic work of one decode of T frames (one sequence), from the GEMM list of csrc/mimi.hip: decode_one --
+    (flops of the matrix products incl. the windowed attention, bytes of the weight matrices read once).  Roofline inputs of
+    tools/mimi_bench.py: one-shot decodes are matrix-pipe bound (fp32 MFMA), a one-frame streaming call is weight-stream bound."""
+    H, D, A, F = cfg.hidden_size, cfg.codebook_dim, cfg.num_attention_heads * cfg.head_dim, cfg.intermediate_size
+    gemms = [(T, H, 2 * D)]                                     # (rows, N, K): RVQ output projections
+    L1 = T * cfg.upsample_stride
+    for _ in range(cfg.num_hidden_layers):
+        gemms += [(L1, 3 * A, H), (L1, H, A), (L1, F, H), (L1, H, F)]
+    attn = 0
+    for p in range(L1):                                         # QK^T and PV over the causal sliding window
+        attn += 2 * 2 * A * min(p + 1, cfg.sliding_window)
+    attn *= cfg.num_hidden_layers
+    ch, L = cfg.num_filters << len(cfg.upsampling_ratios), L1
+    gemms.append((L, ch, cfg.kernel_size * H))
+    for r in cfg.upsampling_ratios:
+        co, hid = ch // 2, ch // 2 // cfg.compress
+        gemms.append((L, r * co, 2 * ch))
+        L *= r
+        gemms += [(L, hid, cfg.residual_kernel_size * co), (L, co, hid)]
+        ch = co
+    last = 2 * L * ch * cfg.last_kernel_size
+    flops = sum(2 * r * n * k for r, n, k in gemms) + attn + last
+    wbytes = sum(n * k * 4 for _, n, k in gemms) + ch * cfg.last_kernel_size * 4
+    return flops, wbytes
+
+
 def mimi_state_dict_spec(cfg: MimiDecodeConfig):
     """(key, shape, kind) of every tensor the decode path reads, in the `kyutai/mimi` (transformers) key layout."""
     H, D = cfg.hidden_size, cfg.codebook_dim

@@ -36,7 +36,13 @@ def hf_config(cfg: MimiDecodeConfig) -> MimiConfig:
 
 
 def main():
-    for name, cfg, B, T in (("tiny", MimiDecodeConfig.tiny(), 2, 9), ("full", MimiDecodeConfig(), 1, 12)):
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    # full_long: the kyutai/mimi shape PAST its attention window -- sliding_window = 250 transformer positions, two per
+    # frame (the codes are upsampled 12.5 -> 25 Hz ahead of the transformer), i.e. 125 frames: 150 frames wrap it; two sequences
+    for name, cfg, B, T in (("tiny", MimiDecodeConfig.tiny(), 2, 9), ("full", MimiDecodeConfig(), 1, 12),
+                            ("full_long", MimiDecodeConfig(), 2, 150)):
+        if only and name not in only:
+            continue
         t0 = time.time()
         sd = synth_mimi_state_dict(cfg, seed=0)
         model = MimiModel(hf_config(cfg)).eval()
@@ -50,8 +56,14 @@ def main():
         mine = MO.decode(sd, cfg, codes)
         err = float((mine - ref).abs().max()) / float(ref.abs().max())
         assert ref.shape == (B, 1, T * cfg.samples_per_frame) and err < 1e-4, (ref.shape, err)
-        np.savez_compressed(os.path.join(GOLD, f"mimi_{name}.npz"), codes=codes.numpy(), audio=ref.numpy().astype(np.float32),
-                            oracle_max_rel_err=np.float32(err))
+        if name == "full_long":
+            # 2 x 150 x 1920 fp32 samples are 2.3 MB: keep sequence 0 whole and every 8th sample of sequence 1
+            np.savez_compressed(os.path.join(GOLD, f"mimi_{name}.npz"), codes=codes.numpy(), audio0=ref[0].numpy().astype(np.float32),
+                                audio1_every8=ref[1, :, ::8].numpy().astype(np.float32), peak=np.float32(ref.abs().max()),
+                                oracle_max_rel_err=np.float32(err))
+        else:
+            np.savez_compressed(os.path.join(GOLD, f"mimi_{name}.npz"), codes=codes.numpy(), audio=ref.numpy().astype(np.float32),
+                                oracle_max_rel_err=np.float32(err))
         print(f"[golden] mimi_{name}: {tuple(ref.shape)} samples, |audio| max {float(ref.abs().max()):.3f}, rms {float(ref.pow(2).mean().sqrt()):.3f}, "
               f"oracle vs transformers max rel err {err:.2e} ({time.time() - t0:.1f}s)", flush=True)
 

@@ -38,6 +38,64 @@ def test_oracle_vs_transformers_golden(name):
         assert torch.equal(out[..., :keep], out2[..., :keep]) and not torch.equal(out, out2)
 
 
+def _long_fixture():
+    g = np.load(os.path.join(GOLD, "mimi_full_long.npz"))
+    return torch.from_numpy(g["codes"]), torch.from_numpy(g["audio0"]), torch.from_numpy(g["audio1_every8"]), float(g["peak"])
+
+
+def _long_err(out, a0, a1s, peak):
+    """distance of a [2, 1, n] waveform from the fixture (sequence 0 whole, sequence 1 every 8th sample), relative to the peak"""
+    return max(float((out[0].double() - a0.double()).abs().max()), float((out[1, :, ::8].double() - a1s.double()).abs().max())) / peak
+
+
+def test_oracle_past_the_attention_window_vs_transformers():
+    """kyutai/mimi shape, 150 frames = 300 transformer positions > sliding_window 250: the window wraps.  The oracle against
+    the waveform transformers' MimiModel.decode produced (fixture mimi_full_long, oracle/make_golden_mimi.py)."""
+    cfg = CASES["full"]
+    codes, a0, a1s, peak = _long_fixture()
+    assert codes.shape == (2, cfg.num_quantizers, 150) and 2 * codes.shape[2] > cfg.sliding_window
+    out = MO.decode(synth_mimi_state_dict(cfg, seed=0), cfg, codes)
+    assert _long_err(out, a0, a1s, peak) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_decode_past_the_attention_window():
+    """the real shape had never wrapped its attention window against the oracle.  150 frames (window = 125),
+    `max_frames = 512`: one-shot B = 2 and B = 1, and a stream in ragged chunks, all < 1e-4 of the peak against the
+    transformers-generated fixture; 500 frames (the window wraps four times) against the oracle."""
+    from csm_hf_amd import MimiDecoder
+    cfg = CASES["full"]
+    codes, a0, a1s, peak = _long_fixture()
+    sd = synth_mimi_state_dict(cfg, seed=0)
+    dec = MimiDecoder(cfg, sd, "cuda:0", max_frames=512)
+    cd = codes.to("cuda:0")
+    both = dec.decode(cd).cpu()                                   # B = 2, one shot
+    assert both.shape == (2, 1, 150 * cfg.samples_per_frame) and _long_err(both, a0, a1s, peak) < 1e-4
+    solo = dec.decode(cd[:1]).cpu()                               # B = 1: same sequence, other GEMM row counts
+    assert float((solo[0].double() - a0.double()).abs().max()) / peak < 1e-4
+    for row, chunks in ((0, (1, 7, 16, 2, 33, 5, 64, 3, 40)), (1, (13,) * 12)):      # ragged / regular chunks, both past the window
+        dec.stream_reset()
+        parts, t = [], 0
+        for n in chunks:
+            n = min(n, 150 - t)
+            if n <= 0:
+                break
+            parts.append(dec.stream_decode(cd[row, :, t:t + n]).clone())
+            t += n
+        assert t == 150
+        got = torch.cat(parts, dim=-1).cpu()[0]
+        want = a0 if row == 0 else None
+        if row == 0:
+            assert float((got.double() - a0.double()).abs().max()) / peak < 1e-4, chunks
+        else:
+            assert float((got[:, ::8].double() - a1s.double()).abs().max()) / peak < 1e-4, chunks
+    g = torch.Generator().manual_seed(17)
+    c500 = torch.randint(0, cfg.codebook_size, (1, cfg.num_quantizers, 500), generator=g)
+    want = MO.decode(sd, cfg, c500)
+    assert rel_max(dec.decode(c500.to("cuda:0")).cpu(), want) < 1e-4
+    dec.close()
+
+
 def test_checkpoint_directory_round_trip(tmp_path):
     """`kyutai/mimi`-layout directory (config.json + model.safetensors, as transformers writes it) -> config + decode-path
     tensors; a weight-normalised convolution (g, v) is folded to the plain weight."""
