@@ -320,6 +320,16 @@ def main():
         eng.set_option("prefill_bf16", 1)
         prefill_ms_bf16, prefill_min_bf16 = timed_prefill(eng, ids, mask, B)
         eng.set_option("prefill_bf16", 0)
+    prefill_ms_mx = prefill_min_mx = None
+    if a.weights == "fp8":
+        # BASELINE configs[4] "fp8 weights (CDNA4 fp8 MFMA)": the context GEMMs on v_mfma_scale_f32_16x16x128_f8f6f4 with
+        # weights AND activations in OCP MX-fp8 (csrc/gemm_mx.h) -- its own accuracy class, opt-in; timed beside the others
+        eng.enable_mx(model.state_dict())
+        eng.set_option("prefill_bf16", 1)
+        eng.set_option("prefill_mx", 1)
+        prefill_ms_mx, prefill_min_mx = timed_prefill(eng, ids, mask, B)
+        eng.set_option("prefill_mx", 0)
+        eng.set_option("prefill_bf16", 0)
     prefill_ms, prefill_min = timed_prefill(eng, ids, mask, B)   # the benchmarked run continues from this (exact) context
     s = eng.sampling(temperature=a.temperature, topk=a.topk, seed=1234)
     use_graph = not a.no_graph
@@ -384,6 +394,8 @@ def main():
             "prefill_ms_min": round(prefill_min, 2),
             "prefill_ms_bf16_activations_min": None if prefill_min_bf16 is None else round(prefill_min_bf16, 2),
             "prefill_ms_bf16_activations": None if prefill_ms_bf16 is None else round(prefill_ms_bf16, 2),
+            "prefill_ms_mxfp8": None if prefill_ms_mx is None else round(prefill_ms_mx, 2),
+            "prefill_ms_mxfp8_min": None if prefill_min_mx is None else round(prefill_min_mx, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
             "setup_s": round(t_setup, 1),
             "roofline": {"bound": "hbm", "kernel": "frame-step hipGraph (decoder loop + backbone step)",

@@ -25,13 +25,15 @@
 #include "gemm.h"
 #include "gemm16.h"
 #include "gemm32.h"
+#include "gemm_mx.h"
 #include "gemv.h"
 #include "misc.h"
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a);
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
                    int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes = nullptr,
-                   size_t plane_stride = 0, const float* part = nullptr, int nsplit = 0, size_t part_stride = 0, int ldp = 0);
+                   size_t plane_stride = 0, const float* part = nullptr, int nsplit = 0, size_t part_stride = 0, int ldp = 0,
+                   uint8_t* mxq = nullptr, uint8_t* mxs = nullptr);
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a);
@@ -148,6 +150,12 @@ struct csm_engine {
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
+  // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
+  // the quantised-activation scratch [max_prefill_rows][widest K] + scales
+  std::vector<csm_mx_layer_t> mx_layers;
+  int prefill_mx = 0;
+  uint8_t *p_mx_q = nullptr, *p_mx_s = nullptr, *p_mx_q2 = nullptr, *p_mx_s2 = nullptr;   // q2 / s2: the SwiGLU output (down_proj's operand)
+  int mx_fuse_swiglu = 1;   // gate/up writes its SwiGLU output as MX-fp8 itself (0: fp32 + quantiser launch, A/B)
   int prefill_x3_attn = 1;     // exact mode: context attention as three-piece products on the bf16 matrix pipe (0 = fp32 MFMA)
   int prefill_bf16_attn = 1;   // with prefill_bf16: the context attention on the bf16 matrix pipe too (0 = keep the fp32-MFMA flash kernel)
   // host mirrors
@@ -522,6 +530,11 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
   else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
+  else if (!strcmp(name, "mx_fuse_swiglu")) e->mx_fuse_swiglu = value;
+  else if (!strcmp(name, "prefill_mx")) {
+    if (value && e->mx_layers.empty()) return fail(CSM_ERR_STATE, "prefill_mx needs MX-fp8 weights (csm_bind_mx_weights)");
+    e->prefill_mx = value ? 1 : 0;
+  }
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -939,6 +952,110 @@ static const void* tiled_of(const csm_engine* e, const void* W) {
   return it == e->tiled.end() ? nullptr : it->second;
 }
 
+// K splits of an MX-fp8 prefill GEMM with too few 128 x 128 tiles to fill the chip (k-steps of 128, >= 4 per split)
+static inline int mx_ksplit(int R, int N, int K, int cap) {
+  const long tiles = (long)((R + 127) / 128) * (N / 128);
+  if (tiles >= 384) return 1;
+  int ks = (int)((512 + tiles - 1) / tiles);
+  if (ks > cap) ks = cap;
+  while (ks > 1 && (K % (128 * ks) || K / ks < 512)) --ks;
+  return ks;
+}
+
+// stack_rows with every linear on the block-scaled fp8 matrix instruction (gemm_mx.h; backbone only): the producers
+// (RMSNorm, attention, SwiGLU epilogue) leave fp32 rows, mx_quant_rows_kernel turns them into e4m3 + E8M0 scales, the GEMM
+// multiplies them with the MX copy of the weights.  Same residual / split-K / RoPE / attention launches as the other modes.
+static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* vc, int lmax, int B, int S, int past,
+                         const int* kv_start, const int32_t* rope_pos, bool allow_split, int* pending_out, size_t* part_stride_out) {
+  const size_t R = (size_t)B * S;
+  const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn, A = nq * hd, NQKV = s.nqkv();
+  if (!e->p_mx_q) {
+    const size_t Kmax = std::max<size_t>(std::max(H, A), F), rows = (size_t)e->cfg.max_prefill_rows;
+    if (int r = dalloc(e, &e->p_mx_q, rows * Kmax)) return r;
+    if (int r = dalloc(e, &e->p_mx_s, rows * (Kmax / 32))) return r;
+    if (int r = dalloc(e, &e->p_mx_q2, rows * (size_t)F)) return r;
+    if (int r = dalloc(e, &e->p_mx_s2, rows * (size_t)(F / 32))) return r;
+  }
+  const bool can_split = allow_split && e->prefill_splitk && e->p_part && R <= 4096;
+  const int cap = (int)std::min<size_t>((size_t)e->prefill_splitk_max, 4 * (size_t)e->cfg.max_prefill_rows / R);
+  const int ks_o = can_split ? mx_ksplit((int)R, H, A, cap) : 1, ks_d = can_split ? mx_ksplit((int)R, H, F, cap) : 1;
+  int ks_q = 1;
+  if (can_split && e->prefill_splitk_qkv) {
+    const size_t room = 4 * (size_t)e->cfg.max_prefill_rows * (size_t)e->p_part_h / (R * (size_t)NQKV);
+    ks_q = mx_ksplit((int)R, NQKV, H, (int)std::min<size_t>(std::min<size_t>((size_t)e->prefill_splitk_max, (size_t)e->prefill_splitk_qkv), room));
+  }
+  const size_t part_stride = R * (size_t)H;
+  auto quant = [&](const float* x, int K) {
+    MxQuantArgs q{};
+    q.x = x; q.ldx = K; q.rows = (int)R; q.K = K; q.q = e->p_mx_q; q.s = e->p_mx_s;
+    return launch_mx_quant(e->stream, q);
+  };
+  auto gemm = [&](int epi, const uint8_t* Wq, const uint8_t* Ws, int N, int K, float* C, int ldc, int ks, size_t pstride) {
+    GemmMxArgs g{};
+    g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = Wq; g.Ws = Ws; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
+    g.ksplit = ks; g.Cpart = e->p_part; g.part_stride = pstride;
+    return launch_gemm_mx(e->stream, epi, g);
+  };
+  int pending = 0;
+  for (int l = 0; l < s.c.layers; ++l) {
+    const csm_layer_weights_t& w = s.layers[l];
+    const csm_mx_layer_t& m = e->mx_layers[l];
+    LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln1, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, nullptr, 0,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));   // normed rows leave as MX-fp8
+    pending = 0;
+    RopeArgs ra{};
+    if (ks_q > 1) {
+      LCK(gemm(GEPI_PARTIAL, m.qkv, m.qkv_s, NQKV, H, nullptr, 0, ks_q, R * (size_t)NQKV));
+      ra.part = e->p_part; ra.nsplit = ks_q; ra.part_stride = R * (size_t)NQKV;
+    } else {
+      LCK(gemm(GEPI_STORE, m.qkv, m.qkv_s, NQKV, H, e->p_qkv, NQKV, 1, 0));
+    }
+    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
+    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
+    ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
+    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    PrefillAttnArgs fa{};
+    fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.out = e->p_att;
+    int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, e->prefill_bf16_attn ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
+    if (fr == -2) {
+      AttnArgs t{};
+      t.q = e->p_q; t.kcache = kc[l]; t.vcache = vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = lmax;
+      t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = kv_start; t.nsplit = 1; t.out = e->p_att;
+      fr = launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t);
+    }
+    LCK(fr);
+    LCK(quant(e->p_att, A));
+    if (ks_o > 1) {
+      LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
+      pending = ks_o;
+    } else {
+      LCK(gemm(GEPI_RESID, m.o, m.o_s, H, A, e->p_h, H, 1, 0));
+    }
+    LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln2, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, nullptr, 0,
+                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));
+    pending = 0;
+    const bool fq = e->mx_fuse_swiglu != 0;
+    {
+      GemmMxArgs g{};
+      g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H; g.C = e->p_act; g.ldc = F;
+      if (fq) { g.Cq = e->p_mx_q2; g.Cs = e->p_mx_s2; }
+      LCK(launch_gemm_mx(e->stream, GEPI_SWIGLU, g));
+    }
+    if (!fq) LCK(quant(e->p_act, F));
+    {
+      GemmMxArgs g{};
+      g.Aq = fq ? e->p_mx_q2 : e->p_mx_q; g.As = fq ? e->p_mx_s2 : e->p_mx_s; g.Wq = m.d; g.Ws = m.d_s; g.R = (int)R; g.N = H; g.K = F;
+      g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride;
+      LCK(launch_gemm_mx(e->stream, ks_d > 1 ? GEPI_PARTIAL : GEPI_RESID, g));
+      if (ks_d > 1) pending = ks_d;
+    }
+  }
+  *pending_out = pending;
+  *part_stride_out = part_stride;
+  return 0;
+}
+
 // R = B * S rows (row b * S + s = position past + s of sequence b; e->p_row_seq / p_row_pos filled by the caller) through
 // every layer of a stack: residual stream in e->p_h [R][hidden], K/V appended to kc[l] / vc[l] ([B][n_kv][lmax][hd]
 // layouts of the engine caches).  On return *pending_out split-K partials of the LAST layer's down_proj wait in e->p_part
@@ -949,6 +1066,9 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
   const size_t R = (size_t)B * S;
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn;
   const int wd = e->cfg.weight_dtype;
+  if (e->prefill_mx && &s == &e->bb && (int)e->mx_layers.size() == s.c.layers && H % 128 == 0 && F % 128 == 0 && (nq * hd) % 128 == 0 &&
+      s.nqkv() % 128 == 0 && (2 * F) % 128 == 0)
+    return stack_rows_mx(e, s, kc, vc, lmax, B, S, past, kv_start, rope_pos, allow_split, pending_out, part_stride_out);
   // bf16 / fp8 weights: RMSNorm, the flash attention and the SwiGLU epilogue hand their outputs to the next GEMM as
   // exact bf16 planes (split once per element instead of once per column block of the consumer)
   const bool pl = e->prefill_planes && e->p_pl_h && wd != CSM_DTYPE_F32 && H % 8 == 0 && F % 8 == 0 && (nq * hd) % 8 == 0;
@@ -1727,6 +1847,36 @@ extern "C" int csm_rope_scatter(csm_engine_t* e, int which, int layer, const flo
   ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = row_seq; ra.row_pos = row_pos; ra.qbuf = q_out;
   ra.kcache = s.kc[layer]; ra.vcache = s.vc[layer]; ra.lmax = s.lmax;
   LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, rows, ra));
+  return 0;
+}
+
+// ---- MX-fp8 (OCP microscaling: e4m3 elements + one E8M0 scale per 32 along K): row quantiser, GEMM hook, weight binding ----
+extern "C" int csm_mx_quantize(csm_engine_t* e, const float* x, int rows, int K, uint8_t* q_out, uint8_t* s_out) {
+  if (!e || !x || !q_out || !s_out || rows < 1 || K < 32 || K % 32) return fail(CSM_ERR_ARG, "bad mx_quantize arguments");
+  MxQuantArgs q{};
+  q.x = x; q.ldx = K; q.rows = rows; q.K = K; q.q = q_out; q.s = s_out;
+  LCK(launch_mx_quant(e->stream, q));
+  return 0;
+}
+extern "C" int csm_gemm_mx(csm_engine_t* e, const uint8_t* Wq, const uint8_t* Ws, int N, int K, const uint8_t* Aq, const uint8_t* As,
+                           int R, float* C) {
+  if (!e || !C) return fail(CSM_ERR_ARG, "null argument");
+  GemmMxArgs g{};
+  g.Aq = Aq; g.As = As; g.Wq = Wq; g.Ws = Ws; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
+  const int r = launch_gemm_mx(e->stream, GEPI_STORE, g);
+  if (r == -2) return fail(CSM_ERR_ARG, "csm_gemm_mx covers N %% 128 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
+  LCK(r);
+  return 0;
+}
+extern "C" int csm_bind_mx_weights(csm_engine_t* e, const csm_mx_layer_t* layers, int n_layers) {
+  if (!e) return fail(CSM_ERR_ARG, "null engine");
+  if (!layers || n_layers == 0) { e->mx_layers.clear(); e->prefill_mx = 0; return 0; }
+  if (n_layers != e->cfg.backbone.layers) return fail(CSM_ERR_ARG, "expected %d backbone layers, got %d", e->cfg.backbone.layers, n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    const csm_mx_layer_t& m = layers[l];
+    if (!m.qkv || !m.qkv_s || !m.o || !m.o_s || !m.gu || !m.gu_s || !m.d || !m.d_s) return fail(CSM_ERR_ARG, "null MX weight pointer (layer %d)", l);
+  }
+  e->mx_layers.assign(layers, layers + n_layers);
   return 0;
 }
 

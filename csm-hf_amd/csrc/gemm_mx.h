@@ -1,0 +1,270 @@
+// Prefill GEMM on the CDNA4 block-scaled fp8 matrix instruction (BASELINE configs[4]: "fp8 weights (CDNA4 fp8 MFMA)"):
+//   C[R,N] (+)= A[R,K] @ W[N,K]^T,  A and W in OCP MX-fp8: e4m3 elements + one E8M0 (power-of-two) scale per 32 elements
+//   along K, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (dequantisation fused into the instruction, fp32 accumulate;
+//   2x the bf16 matrix rate -- the non-scaled fp8 MFMA of gfx950 issues at the bf16 rate, cdna guide section 3).
+//
+// Structure (the guide's "128^2 tile + global_load_lds width 16" rung with the counted-vmcnt overlap): 256 threads = 4 waves
+// as 2 x 2, wave tile 64 x 64 = 4 x 4 MFMA tiles, k-step 128; BOTH operand tiles and their scales are staged by LDS-DMA
+// (`global_load_lds`: no VGPR round trip, no ds_write pass), two LDS stages, the DMA of step s+1 in flight under the
+// MFMAs of step s (raw s_barrier + counted s_waitcnt vmcnt, never a __syncthreads()).  LDS-DMA writes a wave's 64 x 16 B
+// lane-linearly, so the bank swizzle is applied to the per-lane GLOBAL source address: 16-byte chunk c of row r is stored
+// at chunk c ^ f(r), f(r) = bit1(r) << 1 | bit3(r) << 2 -- conflict-free for the operand reads (lane = row & 15, chunks
+// g and g + 4 for g = lane >> 4) under the lane grouping in which this chip services ds_read_b128 (gemm.h: gemm_wide_kernel).
+// The WEIGHTS are the A operand of the instruction and the activations the B operand, so a lane of the accumulator holds
+// four consecutive output COLUMNS of one activation row: 16-byte epilogue accesses, SwiGLU (gate, up) pairs in-lane.
+//
+// Numerics: every product e4m3 x e4m3 x 2^(sa + sb) is exact in fp32; the instruction accumulates in fp32.  What is NOT
+// exact is the activation format (3 mantissa bits): measured on the synthetic csm-1b checkpoint, 128-frame context, last
+// hidden state against the same MX-dequantised weights with fp32 activations: rel-L2 0.23 (bf16 activations: 0.012) --
+// a different accuracy class, which is why this path is opt-in (`prefill_precision = "mxfp8"`).
+//
+// Replaces the q/k/v/o/gate/up/down nn.Linear calls of transformers.LlamaModel at q_len > 1 (reference call site
+// modeling_csm.py:345-354) when the engine holds MX-quantised backbone weights.  Roofline: MFMA, 2 R N K flops against the
+// dense MX-fp8 peak (~4.6 PFLOP/s measured ceiling, 5 PFLOP/s nominal).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+struct GemmMxArgs {
+  const uint8_t* Aq;   // [R][K] e4m3
+  const uint8_t* As;   // [R][K/32] E8M0 (value 2^(byte - 127))
+  const uint8_t* Wq;   // [N][K] e4m3
+  const uint8_t* Ws;   // [N][K/32]
+  int R, N, K;         // N % 128 == 0, K % 128 == 0
+  float* C;            // STORE / RESID: [R][ldc]; SWIGLU: [R][ldc], N/2 columns
+  int ldc;
+  int ksplit;          // GEPI_PARTIAL: grid.y splits of K (K % (128 ksplit) == 0), partial products to Cpart + s * part_stride
+  float* Cpart;
+  size_t part_stride;
+  // GEPI_SWIGLU, nullable: the SwiGLU output leaves the launch ALREADY in MX-fp8 ([R][N/2] e4m3 + [R][N/64] scales), the A
+  // operand of the down_proj GEMM -- a wave tile's 64 weight rows are exactly one 32-column block of an activation row, so
+  // the block maximum is two cross-lane steps away; saves the fp32 round trip (4 bytes written + read per element) and the
+  // quantiser launch.  C is then not written.
+  uint8_t* Cq;
+  uint8_t* Cs;
+};
+
+// fp32 rows -> MX-fp8: q [rows][K] e4m3 + s [rows][K/32] E8M0, the OCP MX recipe (shared scale 2^(floor(log2(amax)) - 8),
+// elements saturated to +-448, round to nearest even)
+struct MxQuantArgs {
+  const float* x;   // [rows][ldx]
+  int ldx;
+  int rows, K;      // K % 32 == 0
+  uint8_t* q;
+  uint8_t* s;
+};
+
+#ifndef CSM_ARGS_ONLY
+typedef __attribute__((ext_vector_type(8))) int mx_v8i;
+
+__global__ __launch_bounds__(256) void mx_quant_rows_kernel(MxQuantArgs a) {
+  // 4 lanes per 32-element block (8 elements each); a 256-thread workgroup covers 64 blocks
+  const size_t blk = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3;
+  const int bpr = a.K >> 5;
+  const size_t nblk = (size_t)a.rows * bpr;
+  const bool live = blk < nblk;
+  const size_t row = live ? blk / bpr : 0;
+  const int kb = live ? (int)(blk - row * bpr) : 0;
+  const float* src = a.x + row * a.ldx + kb * 32 + sub * 8;
+  f32x4 v0 = (f32x4)(0.f), v1 = (f32x4)(0.f);
+  if (live) { v0 = *reinterpret_cast<const f32x4*>(src); v1 = *reinterpret_cast<const f32x4*>(src + 4); }
+  float m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                  fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  // biased exponent of amax (floor(log2) for normal numbers; amax == 0 or subnormal -> smallest scale), minus emax(e4m3) = 8
+  int eb = (int)((__float_as_uint(m) >> 23) & 0xff) - 8;
+  eb = eb < 0 ? 0 : (eb > 254 ? 254 : eb);
+  const float inv = __uint_as_float((uint32_t)(254 - eb) << 23);   // 2^-(eb - 127): exact (eb in 0..254 -> exponent field 254..0;
+  // field 0 would be zero/subnormal: only for eb = 254, i.e. amax >= 2^135, which fp32 data of this model never reaches)
+  float w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float t = (i < 4 ? v0[i] : v1[i - 4]) * inv;
+    w[i] = fminf(fmaxf(t, -448.f), 448.f);
+  }
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(w[0], w[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(w[2], w[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(w[4], w[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(w[6], w[7], hi, true);
+  if (live) {
+    *reinterpret_cast<uint2*>(a.q + row * a.K + kb * 32 + sub * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    if (sub == 0) a.s[row * bpr + kb] = (uint8_t)eb;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
+  constexpr int BM = 128, BN = 128, BK = 128;          // activation rows, weight rows, k (= bytes) per step
+  constexpr int TILE = BM * BK;                        // 16 KiB per operand tile
+  constexpr int STAGE = 2 * TILE + 2 * BM * 4;         // + the two scale tiles [128 rows][4 k blocks]
+  extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A tile | W tile | A scales | W scales]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int j16 = lane & 15, kb = lane >> 4;
+  const int nbm = (a.R + BM - 1) / BM, nbn = a.N / BN;
+  // tile order (as gemm_wide_kernel): the workgroups of one XCD (blockIdx % 8) walk every row block of ONE weight panel
+  // before the next panel, and an XCD only ever touches the weight panels n = 8 q + xcd: W is fetched once per chip
+  int bm, bn;
+  if (nbn % 8 == 0) {
+    const int q = (int)blockIdx.x >> 3;
+    bm = q % nbm;
+    bn = (q / nbm) * 8 + ((int)blockIdx.x & 7);
+  } else {
+    bm = (int)blockIdx.x % nbm;
+    bn = (int)blockIdx.x / nbm;
+  }
+  const int r0 = bm * BM, n0 = bn * BN;
+  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
+  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0;
+  const int nk = kspan / BK;
+  const int K32 = a.K >> 5;
+
+  // ---- LDS-DMA sources of this lane.  Operand tiles: wave w, instruction i covers tile rows 32 w + 8 i .. + 8; lane l
+  // lands at row + (l >> 3), chunk position l & 7, and must therefore FETCH chunk (l & 7) ^ f(row).
+  const uint8_t* asrc[4];
+  const uint8_t* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
+    const int ra = min(r0 + row, a.R - 1);                        // rows past R: a valid address, the result is never stored
+    asrc[i] = a.Aq + (size_t)ra * a.K + kbeg + c * 16;
+    wsrc[i] = a.Wq + (size_t)(n0 + row) * a.K + kbeg + c * 16;
+  }
+  // scale tiles: waves 0 / 1 fetch the activation rows 0-63 / 64-127, waves 2 / 3 the weight rows (4 bytes = 4 k blocks each)
+  const uint8_t* ssrc;
+  {
+    const int row = (wave & 1) * 64 + lane;
+    ssrc = wave < 2 ? a.As + (size_t)min(r0 + row, a.R - 1) * K32 + (kbeg >> 5) : a.Ws + (size_t)(n0 + row) * K32 + (kbeg >> 5);
+  }
+  auto issue = [&](int ks, int st) {
+    uint8_t* base = mx_lds + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)ks * BK),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BK),
+                                       (__attribute__((address_space(3))) void*)(base + TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)ks * 4),
+                                     (__attribute__((address_space(3))) void*)(base + 2 * TILE + wave * 256), 4, 0, 0);
+  };
+
+  f32x4 acc[4][4];   // [activation-row tile][weight-row tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+
+  // operand read offsets of this lane inside a tile: row (tile t) = half * 64 + 16 t + j16.  The instruction's K layout
+  // (measured, tools/ubench/mx_layout.py): lane (row, g) holds k = 16 g .. 16 g + 15 in its first four registers and
+  // k = 64 + 16 g .. in the last four, while the SCALE of 32-block b is taken from lane row + 16 b -- so lane g reads the
+  // 16-byte chunks g and g + 4 (stored at g ^ f, (g + 4) ^ f; f depends on row & 15 = j16 only: tiles are 16 rows apart)
+  const int fsw = (((j16 >> 1) & 1) << 1) | (((j16 >> 3) & 1) << 2);
+  const int c0 = (kb ^ fsw) * 16, c1 = ((kb + 4) ^ fsw) * 16;
+  const int arow0 = (wr * 64 + j16) * BK, wrow0 = (wc * 64 + j16) * BK;
+  const int asc0 = (wr * 64 + j16) * 4 + kb, wsc0 = (wc * 64 + j16) * 4 + kb;
+
+  issue(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int st = ks & 1;
+    if (ks + 1 < nk) {
+      issue(ks + 1, st ^ 1);
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // this wave's 9 DMA instructions of step ks have landed; step ks+1 stays in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                          // ... and so have every other wave's
+    const uint8_t* At = mx_lds + st * STAGE;
+    const uint8_t* Wt = At + TILE;
+    const uint8_t* Asc = At + 2 * TILE;
+    const uint8_t* Wsc = Asc + BM * 4;
+    mx_v8i af[4], wf[4];
+    int sa[4], sw[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c0);
+      const u32x4 a1 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c1);
+      af[t] = mx_v8i{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BK + c0);
+      const u32x4 w1 = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BK + c1);
+      wf[t] = mx_v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+      sa[t] = (int)Asc[asc0 + t * 64];
+      sw[t] = (int)Wsc[wsc0 + t * 64];
+    }
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ri][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[ri], acc[ri][ni], 0, 0, 0, sw[ni], 0, sa[ri]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave has read stage st before step ks+2 overwrites it
+  }
+
+  // ---- epilogue: lane (j16, g = kb) holds C[activation row 16 ri + j16][weight rows 16 ni + 4 g .. + 3] -----------------
+  if (EPI == GEPI_SWIGLU && a.Cq) {
+    const int F2 = a.N >> 1;                       // SwiGLU output columns
+    const int cb0 = (n0 + wc * 64) >> 1;           // first output column of this wave tile = one 32-column MX block
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const int r = r0 + wr * 64 + ri * 16 + j16;
+      float h[4][2];
+      float m = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const f32x4 v = acc[ri][ni];
+        h[ni][0] = (v[0] / (1.f + __expf(-v[0]))) * v[1];
+        h[ni][1] = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+        m = fmaxf(m, fmaxf(fabsf(h[ni][0]), fabsf(h[ni][1])));
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));         // the four lanes (j16, g = 0..3) hold the row's 32 columns
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      int eb = (int)((__float_as_uint(m) >> 23) & 0xff) - 8;
+      eb = eb < 0 ? 0 : (eb > 254 ? 254 : eb);
+      const float inv = __uint_as_float((uint32_t)(254 - eb) << 23);
+      if (r < a.R) {
+        uint8_t* dst = a.Cq + (size_t)r * F2 + cb0 + kb * 2;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const float q0 = fminf(fmaxf(h[ni][0] * inv, -448.f), 448.f), q1 = fminf(fmaxf(h[ni][1] * inv, -448.f), 448.f);
+          const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q0, q1, 0, false);
+          *reinterpret_cast<uint16_t*>(dst + ni * 8) = (uint16_t)pk;
+        }
+        if (kb == 0) a.Cs[(size_t)r * (F2 >> 5) + (cb0 >> 5)] = (uint8_t)eb;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri) {
+    const int r = r0 + wr * 64 + ri * 16 + j16;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * kb;
+      f32x4 v = acc[ri][ni];
+      if (EPI == GEPI_SWIGLU) {   // (gate, up) pairs: output columns n/2, n/2 + 1
+        const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+        *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
+      } else if (EPI == GEPI_PARTIAL) {
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+      } else if (EPI == GEPI_RESID) {
+        f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+        const f32x4 o = *c;
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        *c = v;
+      } else {
+        *reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n) = v;
+      }
+    }
+  }
+}
+#endif  // CSM_ARGS_ONLY
+
+// host-side launchers (gemm_mx.hip); -2 = shape not covered
+int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a);
+int launch_mx_quant(hipStream_t st, const MxQuantArgs& a);

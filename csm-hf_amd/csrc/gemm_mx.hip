@@ -1,0 +1,42 @@
+// Instantiations + launchers of the MX-fp8 prefill GEMM and the row quantiser (gemm_mx.h).
+#include <hip/hip_runtime.h>
+
+#include "gemm_mx.h"
+
+template <int EPI>
+static int launch_mx_epi(hipStream_t st, const dim3& grid, const GemmMxArgs& a) {
+  constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * 128 * 4);   // two stages of (A tile | W tile | scales) = 66 KiB
+  auto fn = gemm_mx_kernel<EPI>;
+  // more than 64 KiB of dynamic LDS: raise the limit once per DEVICE (the attribute is per device)
+  static unsigned long long configured = 0ull;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(configured & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    configured |= bit;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a) {
+  if (a.R < 1 || a.N % 128 || a.K % 128 || !a.Aq || !a.As || !a.Wq || !a.Ws) return -2;
+  const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
+  if (ks < 1 || a.K % (128 * ks)) return -2;
+  const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
+  switch (epi) {
+    case GEPI_STORE: return launch_mx_epi<GEPI_STORE>(st, grid, a);
+    case GEPI_RESID: return launch_mx_epi<GEPI_RESID>(st, grid, a);
+    case GEPI_SWIGLU: return launch_mx_epi<GEPI_SWIGLU>(st, grid, a);
+    case GEPI_PARTIAL: return launch_mx_epi<GEPI_PARTIAL>(st, grid, a);
+    default: return -1;
+  }
+}
+
+int launch_mx_quant(hipStream_t st, const MxQuantArgs& a) {
+  if (a.rows < 1 || a.K % 32 || a.ldx % 4) return -2;
+  const size_t nblk = (size_t)a.rows * (a.K / 32);
+  hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((nblk + 63) / 64)), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}

@@ -252,10 +252,10 @@ int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a) {
 
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
                    int ldo, const int* frame_ptr, size_t frame_stride, int frame_add, bf16_t* planes, size_t plane_stride,
-                   const float* part, int nsplit, size_t part_stride, int ldp) {
-  if (H % 4 != 0) return -1;
+                   const float* part, int nsplit, size_t part_stride, int ldp, uint8_t* mxq, uint8_t* mxs) {
+  if (H % 4 != 0 || (mxq && (H % 32 != 0 || !mxs))) return -1;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, H, eps, out, ldo, frame_ptr,
-                     frame_stride, frame_add, planes, plane_stride, part, nsplit, part_stride, ldp);
+                     frame_stride, frame_add, planes, plane_stride, part, nsplit, part_stride, ldp, mxq, mxs);
   return (int)hipGetLastError();
 }
 

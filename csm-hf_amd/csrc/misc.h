@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
                                                       float* out, int ldo, const int* frame_ptr,
                                                       size_t frame_stride, int frame_add, bf16_t* planes,
                                                       size_t plane_stride, const float* part, int nsplit,
-                                                      size_t part_stride, int ldp) {
+                                                      size_t part_stride, int ldp, uint8_t* mxq, uint8_t* mxs) {
+  // mxq != nullptr (prefill_precision = mxfp8, H % 32 == 0): the normed row goes out as OCP MX-fp8 -- e4m3 elements
+  // [rows][H] + one E8M0 scale per 32 [rows][H/32] (gemm_mx.h: the recipe of mx_quant_rows_kernel, 8 lanes per block) --
+  // the A operand of the next GEMM; `out` is then not written
   // part != nullptr: the row first takes up the split-K partial products of the preceding residual GEMM
   // (gemm.h GEPI_PARTIAL): x[row] += part[0][row] + part[1][row] + ... in that order, written back in place
   // planes != nullptr: the normed row goes out as three exact bf16 planes [3][rows][H] for the prefill GEMM
@@ -166,7 +169,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
     v[1] = (v[1] * sc) * g[1];
     v[2] = (v[2] * sc) * g[2];
     v[3] = (v[3] * sc) * g[3];
-    if (planes) store_rowplanes4(planes + (size_t)row * H + k, plane_stride, v);
+    if (mxq) {
+      float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      m = fmaxf(m, __shfl_xor(m, 4, 64));
+      int eb = (int)((__float_as_uint(m) >> 23) & 0xff) - 8;
+      eb = eb < 0 ? 0 : (eb > 254 ? 254 : eb);
+      const float inv = __uint_as_float((uint32_t)(254 - eb) << 23);
+      int pk = 0;
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0] * inv, -448.f), 448.f), fminf(fmaxf(v[1] * inv, -448.f), 448.f), pk, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2] * inv, -448.f), 448.f), fminf(fmaxf(v[3] * inv, -448.f), 448.f), pk, true);
+      *reinterpret_cast<uint32_t*>(mxq + (size_t)row * H + k) = (uint32_t)pk;
+      if ((tid & 7) == 0) mxs[(size_t)row * (H >> 5) + (k >> 5)] = (uint8_t)eb;
+    } else if (planes) store_rowplanes4(planes + (size_t)row * H + k, plane_stride, v);
     else *reinterpret_cast<f32x4*>(o + k) = v;
   }
 }

@@ -31,6 +31,7 @@ EXPORTS = [
     "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
     "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
+    "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx",
 ]
 
 
@@ -61,6 +62,10 @@ class Weights(C.Structure):
     _fields_ = [("backbone", StackW), ("decoder", StackW), ("text_emb", C.c_void_p), ("audio_emb", C.c_void_p),
                 ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p), ("proj_table", C.c_void_p),
                 ("s_proj_head0", C.c_void_p), ("s_audio_head", C.c_void_p)]
+
+
+class MxLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("qkv", "qkv_s", "o", "o_s", "gu", "gu_s", "d", "d_s")]
 
 
 class Sampling(C.Structure):
@@ -127,6 +132,9 @@ def load_library(path: Optional[str] = None):
     lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_prefill_slot.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_shift_context.argtypes = [vp, i32]
+    lib.csm_bind_mx_weights.argtypes = [vp, C.POINTER(MxLayer), i32]
+    lib.csm_mx_quantize.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.csm_gemm_mx.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
     lib.csm_set_length.argtypes = [vp, i32, i32]
@@ -187,6 +195,29 @@ def quantize_fp8_rows(w: torch.Tensor):
 
 def dequantize_fp8_rows(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     return q.view(torch.float8_e4m3fn).float() * s.unsqueeze(-1)
+
+
+def quantize_mx_rows(w: torch.Tensor):
+    """OCP MX-fp8 along the last dimension: blocks of 32, one shared E8M0 scale 2^(floor(log2(amax)) - 8) per block
+    (8 = exponent of the largest e4m3 binade, 448 = 1.75 * 2^8), elements = w / scale saturated to +-448, rounded to
+    nearest-even e4m3.  Returns (uint8 elements [..., K], uint8 scales [..., K/32], value 2^(byte - 127))."""
+    K = w.shape[-1]
+    if K % 32:
+        raise ValueError("MX quantisation needs K % 32 == 0")
+    x = w.float().reshape(*w.shape[:-1], K // 32, 32)
+    amax = x.abs().amax(-1, keepdim=True)
+    eb = ((amax.view(torch.int32) >> 23) & 0xff) - 8          # biased exponent of amax, minus emax(e4m3)
+    eb = eb.clamp(0, 254)
+    inv = ((254 - eb) << 23).view(torch.float32)              # 2^-(eb - 127), exact
+    q = (x * inv).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).reshape(w.shape).contiguous(), eb.to(torch.uint8).reshape(*w.shape[:-1], K // 32).contiguous()
+
+
+def dequantize_mx_rows(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    K = q.shape[-1]
+    v = q.view(torch.float8_e4m3fn).float().reshape(*q.shape[:-1], K // 32, 32)
+    sc = torch.exp2(s.float() - 127.0).unsqueeze(-1)
+    return (v * sc).reshape(q.shape)
 
 
 def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: torch.dtype, max_len: int, fp8: bool = False):
@@ -296,6 +327,9 @@ class Engine:
         self.batch = 0
         self.length = 0
         self.frames = 0
+        self.has_mx = False
+        if "mx" in self.packed:      # a re-homed engine keeps the MX copies of its predecessor
+            self.enable_mx()
 
     def _bind(self):
         w = Weights()
@@ -324,6 +358,35 @@ class Engine:
             w.s_proj_head0 = self.packed["s_proj_head0"].data_ptr()
             w.s_audio_head = self.packed["s_audio_head_t"].data_ptr()
         _ck(self.lib, self.lib.csm_bind_weights(self._h, C.byref(w)))
+
+    def enable_mx(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        """MX-fp8 copies of the backbone's packed linears (quantised from the checkpoint's own bf16 / fp32 values, not from
+        the per-row fp8 copy) for `prefill_mx`: the context prefill on v_mfma_scale_f32_16x16x128_f8f6f4 (csrc/gemm_mx.h)."""
+        if "mx" not in self.packed:
+            if state_dict is None:
+                raise ValueError("enable_mx needs the checkpoint (state_dict) the first time")
+            lc = self.cfg.backbone_config
+            layers = []
+            for i in range(lc.num_hidden_layers):
+                p = f"backbone.layers.{i}"
+                t = lambda k: state_dict[f"{p}.{k}.weight"].detach().to(self.device, torch.float32)
+                g, u = t("mlp.gate_proj"), t("mlp.up_proj")
+                mats = dict(qkv=torch.cat([t("self_attn.q_proj"), t("self_attn.k_proj"), t("self_attn.v_proj")], 0),
+                            o=t("self_attn.o_proj"), gu=torch.stack([g, u], dim=1).reshape(2 * g.shape[0], g.shape[1]),
+                            d=t("mlp.down_proj"))
+                del g, u
+                L = {}
+                for k, w in mats.items():
+                    L[k], L[k + "_s"] = quantize_mx_rows(w)
+                layers.append(L)
+            self.packed["mx"] = layers
+        arr = (MxLayer * len(self.packed["mx"]))()
+        for i, L in enumerate(self.packed["mx"]):
+            for k in ("qkv", "qkv_s", "o", "o_s", "gu", "gu_s", "d", "d_s"):
+                setattr(arr[i], k, L[k].data_ptr())
+        torch.cuda.synchronize(self.device)
+        _ck(self.lib, self.lib.csm_bind_mx_weights(self._h, arr, len(self.packed["mx"])))
+        self.has_mx = True
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -621,6 +684,23 @@ class Engine:
         torch.cuda.current_stream().synchronize()
         wd = {torch.bfloat16: DT_BF16, torch.uint8: DT_FP8}.get(W.dtype, DT_F32)
         _ck(self.lib, self.lib.csm_gemm(self._h, _ptr(W), wd, _ptr(sc), W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out)))
+        self.sync()
+        return out
+
+    def k_mx_quantize(self, x):
+        x = x.to(self.device, torch.float32).contiguous()
+        q = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        s = torch.empty(x.shape[0], x.shape[1] // 32, dtype=torch.uint8, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_mx_quantize(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(q), _ptr(s)))
+        self.sync()
+        return q, s
+
+    def k_gemm_mx(self, Wq, Ws, Aq, As):
+        Wq, Ws, Aq, As = (t.to(self.device).contiguous() for t in (Wq, Ws, Aq, As))
+        out = torch.empty(Aq.shape[0], Wq.shape[0], dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_gemm_mx(self._h, _ptr(Wq), _ptr(Ws), Wq.shape[0], Wq.shape[1], _ptr(Aq), _ptr(As), Aq.shape[0], _ptr(out)))
         self.sync()
         return out
 

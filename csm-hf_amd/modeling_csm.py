@@ -187,7 +187,9 @@ class CSMModel(nn.Module):
         self.use_graph = True
         self.stop_check_interval = 8     # stop_on_all_zeros: frames replayed between two reads of the device-side stop counters
         self.last_row_lengths = None     # per-row frame counts of the last generate(per_row_stop=True)
-        self.prefill_precision = "exact"   # "bf16": context GEMMs on bf16-rounded activations (one MFMA pass instead of three)
+        self.prefill_precision = "exact"   # "bf16": context GEMMs on bf16-rounded activations (one MFMA pass instead of three);
+        # "mxfp8": context GEMMs on the block-scaled fp8 matrix instruction, weights AND activations in OCP MX-fp8 (e4m3 + one
+        # E8M0 scale per 32 along K) -- 3 mantissa bits: its own accuracy class, opt-in
         self.seed = 0
         self.row_offset = 0             # global index of row 0 of this model's batch (batch-sharded generation)
 
@@ -298,12 +300,20 @@ class CSMModel(nn.Module):
                 eng.adopt_state(old)
                 old.close()
             self._engine = eng
-        if self.prefill_precision not in ("exact", "bf16"):
-            raise ValueError(f"prefill_precision must be 'exact' or 'bf16', got {self.prefill_precision!r}")
-        want = 1 if self.prefill_precision == "bf16" else 0
+        if self.prefill_precision not in ("exact", "bf16", "mxfp8"):
+            raise ValueError(f"prefill_precision must be 'exact', 'bf16' or 'mxfp8', got {self.prefill_precision!r}")
+        want = 1 if self.prefill_precision in ("bf16", "mxfp8") else 0     # mxfp8: attention and the rest as in bf16 mode
         if getattr(self._engine, "_prefill_bf16", 0) != want:
             self._engine.set_option("prefill_bf16", want)
             self._engine._prefill_bf16 = want
+        want_mx = 1 if self.prefill_precision == "mxfp8" else 0
+        if getattr(self._engine, "_prefill_mx", 0) != want_mx:
+            if want_mx and not self._engine.has_mx:
+                if p.dtype != torch.bfloat16:
+                    raise ValueError("prefill_precision='mxfp8' needs a bf16 model")
+                self._engine.enable_mx(self.state_dict())
+            self._engine.set_option("prefill_mx", want_mx)
+            self._engine._prefill_mx = want_mx
         return self._engine
 
     # ---- helpers -----------------------------------------------------------------------------------------------

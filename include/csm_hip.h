@@ -215,6 +215,21 @@ int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, const uint8_t
  * re-rotated by `delta`: RoPE is relative, the rows' results change by fp32 rounding only; kv_start of every row and the
  * shared length grow by delta; length + delta <= max_len), then csm_prefill_slot.  No reference counterpart. */
 int csm_shift_context(csm_engine_t* e, int delta);
+
+/* ---- MX-fp8 on the CDNA4 block-scaled matrix instruction (BASELINE configs[4]: "fp8 weights (CDNA4 fp8 MFMA)"; no
+ * reference counterpart -- the reference runs bf16).  OCP microscaling: e4m3 elements + one E8M0 scale byte (2^(b - 127))
+ * per 32 consecutive elements along K.  csm_bind_mx_weights hands the engine MX copies of the backbone's packed linears
+ * ([N][K] bytes + [N][K/32] scales each; borrowed pointers); `csm_set_option(e, "prefill_mx", 1)` then runs every linear
+ * of a context prefill (transformers LlamaModel at q_len > 1, reference call site modeling_csm.py:345-354) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with activations quantised to the same format.  The two hooks are the unit-parity
+ * entries: x fp32 [rows][K] -> (q, s) on the device; C[R][N] = dequant(A) dequant(W)^T in fp32. */
+typedef struct {
+  const uint8_t *qkv, *qkv_s, *o, *o_s, *gu, *gu_s, *d, *d_s;
+} csm_mx_layer_t;
+int csm_bind_mx_weights(csm_engine_t* e, const csm_mx_layer_t* backbone_layers, int n_layers);   /* NULL / 0: unbind */
+int csm_mx_quantize(csm_engine_t* e, const float* x, int rows, int K, uint8_t* q_out, uint8_t* s_out);
+int csm_gemm_mx(csm_engine_t* e, const uint8_t* Wq, const uint8_t* Ws, int N, int K, const uint8_t* Aq, const uint8_t* As,
+                int R, float* C);
 /* ---- CSMModel.forward with labels (modeling_csm.py:367-465): the training objective, FORWARD ONLY.
  * labels [B,S,C+1] int64 on the device, -100 = ignored.  out3 (device, 3 floats) = (loss, backbone_loss, decoder_loss):
  * cross-entropy of the codebook-0 logits of position t against labels[:, t+1, 0], plus cross-entropy of the decoder's

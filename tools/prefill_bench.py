@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Prefill timing of csm-1b (bf16 weights) in both precisions: python tools/prefill_bench.py [ctx] [batch] [reps] [mode]
+"""Prefill timing of csm-1b (bf16 weights) in both precisions: python tools/prefill_bench.py [ctx] [batch] [reps] [mode 0|1|2]
 (run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)."""
 import os
 import sys
@@ -24,8 +24,11 @@ m.load_state_dict(sd)
 del sd
 ids, mask = synth_context(cfg, B, ctx // 4, ctx - ctx // 4, seed=2)
 eng = m._ensure_engine(B, ctx + 8, 4, B * ctx)
-for mode in modes:
-    eng.set_option("prefill_bf16", mode)
+for mode in modes:      # 0 exact, 1 bf16 activations, 2 MX-fp8 weights and activations (gemm_mx.h)
+    eng.set_option("prefill_bf16", 1 if mode else 0)
+    if mode == 2 and not eng.has_mx:
+        eng.enable_mx(m.state_dict())
+    eng.set_option("prefill_mx", 1 if mode == 2 else 0)
     ts = []
     for _ in range(reps):
         eng.reset()
@@ -36,5 +39,6 @@ for mode in modes:
         eng.sync()
         ts.append((time.perf_counter() - t0) * 1e3)
     flops = 2 * 973e6 * B * ctx
-    print(f"ctx {ctx} B {B} prefill_bf16={mode}: min {min(ts):.2f} ms  median {sorted(ts)[len(ts) // 2]:.2f} ms  "
+    name = ("exact", "bf16", "mxfp8")[mode]
+    print(f"ctx {ctx} B {B} mode={name}: min {min(ts):.2f} ms  median {sorted(ts)[len(ts) // 2]:.2f} ms  "
           f"({flops / min(ts) / 1e9:.0f} TFLOP/s on the GEMM flops alone)", flush=True)
