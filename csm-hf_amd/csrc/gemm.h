@@ -42,6 +42,11 @@ struct GemmArgs {
   // sets in registers (1: two workgroups per CU, 4: one); wide_exact = 1 also routes three-plane (exact) launches to it
   // (measured slower: off); krot = start the k walk at a per-workgroup step (changes the fp32 summation order: off)
   int wide, wide_depth, wide_exact, krot;
+  // gemm_dma_bf16_kernel (gemm_mx.h: both operands staged by LDS-DMA from row-major memory, 128 x 128 x 64 tile) for one-plane
+  // bf16 launches: 0 off, 1 for launches of at most dma_max_rows rows, 2 whenever the shape is covered (A/B).  Measured
+  // (csm-1b, prefill_precision = bf16, whole prefill, profiles/r03_prefill.txt): 64 / 512 / 2048 rows 1.68 / 2.78 / 6.80 ->
+  // 1.53 / 2.29 / 6.31 ms; 8192 rows (16 x 512) 19.6 -> 22.3 ms: there gemm_wide_kernel's 128 x 256 tile wins
+  int dma, dma_max_rows;
 };
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64

@@ -263,8 +263,132 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
     }
   }
 }
+
+// ---- the same structure for prefill_precision = bf16 (one bf16 activation plane x bf16 weights, v_mfma_f32_16x16x32_bf16) ----
+// A k-step of 64 bf16 elements is the same 128-byte LDS row as the fp8 kernel's 128 elements, and a lane (row, g) of the
+// 16x16x32 operand holds k = 32 s + 8 g .. + 7 of sub-step s = chunk g (s = 0) and chunk g + 4 (s = 1) of the row: the tile
+// image, the swizzle and the two 16-byte reads per lane are IDENTICAL -- only the multiply differs (two MFMAs, no scales).
+// The matrix instruction accumulates its products as one fp32 chain in ascending k, so without a K split the result is
+// bitwise that of gemm_bf16x3_kernel<NPL = 1> and gemm_wide_kernel (test_csm1b_prefill_precision_bf16).
+// Both operands arrive by LDS-DMA from ROW-MAJOR memory: no fragment-order weight copy is needed (gemm_wide_kernel's +1.9 GB).
+typedef __attribute__((ext_vector_type(8))) short dma_bf16x8;
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
+  constexpr int BM = 128, BN = 128, BKB = 128, BKE = 64;   // k-step: 128 bytes = 64 elements
+  constexpr int TILE = BM * BKB, STAGE = 2 * TILE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A tile | W tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int j16 = lane & 15, g = lane >> 4;
+  const int nbm = (a.R + BM - 1) / BM, nbn = a.N / BN;
+  int bm, bn;
+  if (nbn % 8 == 0) {
+    const int q = (int)blockIdx.x >> 3;
+    bm = q % nbm;
+    bn = (q / nbm) * 8 + ((int)blockIdx.x & 7);
+  } else {
+    bm = (int)blockIdx.x % nbm;
+    bn = (int)blockIdx.x / nbm;
+  }
+  const int r0 = bm * BM, n0 = bn * BN;
+  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
+  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0;
+  const int nk = kspan / BKE;
+  const uint8_t* Ab = reinterpret_cast<const uint8_t*>(a.Aplanes);
+  const uint8_t* Wb = reinterpret_cast<const uint8_t*>(a.W);
+  const size_t rowb = (size_t)a.K * 2;
+  const uint8_t* asrc[4];
+  const uint8_t* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
+    const int ra = min(r0 + row, a.R - 1);
+    asrc[i] = Ab + (size_t)ra * rowb + (size_t)kbeg * 2 + c * 16;
+    wsrc[i] = Wb + (size_t)(n0 + row) * rowb + (size_t)kbeg * 2 + c * 16;
+  }
+  auto issue = [&](int ks, int st) {
+    uint8_t* base = mx_lds + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)ks * BKB),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BKB),
+                                       (__attribute__((address_space(3))) void*)(base + TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
+  const int fsw = (((j16 >> 1) & 1) << 1) | (((j16 >> 3) & 1) << 2);
+  const int c0 = (g ^ fsw) * 16, c1 = ((g + 4) ^ fsw) * 16;
+  const int arow0 = (wr * 64 + j16) * BKB, wrow0 = (wc * 64 + j16) * BKB;
+
+  issue(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int st = ks & 1;
+    if (ks + 1 < nk) {
+      issue(ks + 1, st ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // 8 DMA instructions per wave and stage
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const uint8_t* At = mx_lds + st * STAGE;
+    const uint8_t* Wt = At + TILE;
+    dma_bf16x8 af[4][2], wf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      *reinterpret_cast<u32x4*>(&af[t][0]) = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BKB + c0);
+      *reinterpret_cast<u32x4*>(&af[t][1]) = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BKB + c1);
+      *reinterpret_cast<u32x4*>(&wf[t][0]) = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BKB + c0);
+      *reinterpret_cast<u32x4*>(&wf[t][1]) = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BKB + c1);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[ri][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][s2], af[ri][s2], acc[ri][ni], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri) {
+    const int r = r0 + wr * 64 + ri * 16 + j16;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+      f32x4 v = acc[ri][ni];
+      if (EPI == GEPI_SWIGLU) {
+        const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+        if (a.Cplanes) {   // one bf16 plane (c_plane_stride == 0: checked by the launcher)
+          *reinterpret_cast<uint32_t*>(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1)) = (uint32_t)f32_to_bf16(h0) | ((uint32_t)f32_to_bf16(h1) << 16);
+        } else {
+          *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
+        }
+      } else if (EPI == GEPI_PARTIAL) {
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+      } else if (EPI == GEPI_RESID) {
+        f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+        const f32x4 o = *c;
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        *c = v;
+      } else {
+        *reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n) = v;
+      }
+    }
+  }
+}
 #endif  // CSM_ARGS_ONLY
 
+// -2 = shape / operands not covered (the caller falls back to the other prefill GEMM kernels)
+int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a);
 // host-side launchers (gemm_mx.hip); -2 = shape not covered
 int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a);
 int launch_mx_quant(hipStream_t st, const MxQuantArgs& a);

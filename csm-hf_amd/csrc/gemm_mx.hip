@@ -40,3 +40,24 @@ int launch_mx_quant(hipStream_t st, const MxQuantArgs& a) {
   hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((nblk + 63) / 64)), dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
+
+template <int EPI>
+static int launch_dma_epi(hipStream_t st, const dim3& grid, const GemmArgs& a) {
+  constexpr size_t lds = 2 * (2 * 128 * 128);   // two stages of (A tile | W tile) = 64 KiB
+  hipLaunchKernelGGL(gemm_dma_bf16_kernel<EPI>, grid, dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
+  if (!a.Aplanes || a.a_plane_stride != 0 || !a.W || a.wscale || a.R < 1 || a.N % 128 || a.K % 64 || a.ldc % 4) return -2;
+  if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return -2;
+  const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
+  if (ks < 1 || a.K % (64 * ks) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
+  const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
+  switch (epi) {
+    case GEPI_STORE: return launch_dma_epi<GEPI_STORE>(st, grid, a);
+    case GEPI_RESID: return launch_dma_epi<GEPI_RESID>(st, grid, a);
+    case GEPI_SWIGLU: return launch_dma_epi<GEPI_SWIGLU>(st, grid, a);
+    case GEPI_PARTIAL: return launch_dma_epi<GEPI_PARTIAL>(st, grid, a);
+    default: return -1;
+  }
+}

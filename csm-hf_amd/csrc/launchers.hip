@@ -134,8 +134,15 @@ static bool gemm_wide_ok(int epi, const GemmArgs& a) {
   return wgs >= (epi == GEPI_PARTIAL ? 256 : 320);
 }
 
+int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a);   // gemm_mx.hip
 template <typename WT>
 static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
+  if (a.dma && sizeof(WT) == 2) {   // bf16 weights, one activation plane: the LDS-DMA tile
+    if (a.dma >= 2 || a.R <= a.dma_max_rows) {
+      const int r = launch_gemm_dma_bf16(st, epi, a);
+      if (r != -2) return r;
+    }
+  }
   if (gemm_wide_ok(epi, a)) return launch_gemm_wide<WT>(st, epi, a);
   // 128x128 tiles unless they would occupy fewer than 256 workgroups
   if (epi == GEPI_PARTIAL) return a.K % 64 ? -1 : launch_gemm_x3_bk<WT, 64, 64>(st, epi, a);

@@ -327,3 +327,32 @@ def test_mxfp8_prefill_tiny_vs_oracle_simulation():
     again = m.forward(ids.to(DEV), mask.to(DEV), return_dict=True).last_hidden_state.float().cpu()
     assert torch.equal(again, exact)
     m._drop_engine()
+
+
+def test_lds_dma_bf16_gemm_is_bitwise_the_square_tile():
+    """the prefill GEMM with both operands staged by LDS-DMA (gemm_dma_bf16_kernel, csrc/gemm_mx.h) for
+    `prefill_precision = "bf16"`.  The matrix instruction sums its products as one fp32 chain in ascending k, so without a K
+    split the kernel is BITWISE the square-tile kernel (and the wide tile): same last hidden state, same logits; with the
+    split-K launches of a short prefill the difference is fp32 summation order only."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    m.prefill_precision = "bf16"
+    ids, mask = synth_context(cfg, 1, 64, 192, seed=2)
+
+    def run(opts):
+        eng = m._ensure_engine(1, 300, 4, 256)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.reset()
+        eng.set_kv_start([0])
+        lh, lg = eng.prefill(ids, mask)
+        return lh.cpu(), lg.cpu()
+    base = run(dict(gemm_dma=0, gemm_wide=0, prefill_splitk=0))
+    dma = run(dict(gemm_dma=2, gemm_wide=0, prefill_splitk=0))
+    assert torch.equal(base[0], dma[0]) and torch.equal(base[1], dma[1])
+    split = run(dict(gemm_dma=2, gemm_wide=1, prefill_splitk=1))
+    assert float((split[0] - base[0]).norm() / base[0].norm()) < 5e-2     # bf16 mode: a last-bit change re-rounds downstream
+    m._drop_engine()
