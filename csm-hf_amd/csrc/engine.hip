@@ -129,6 +129,10 @@ struct csm_engine {
   int ld_head = 0;
   float *dec_x = nullptr, *q_dec = nullptr, *att_dec = nullptr, *act_dec = nullptr, *logits_dec = nullptr;
   float* last_h = nullptr;
+  // two-token first decoder pass (B == 1; reference modeling_csm.py:534-552 runs positions 0 and 1 as ONE forward)
+  float *dec_x2 = nullptr, *q_dec2 = nullptr, *att_dec2 = nullptr, *act_dec2 = nullptr;
+  int *d_pos01 = nullptr, *d_seq00 = nullptr;
+  int two_token_pass = 0;   // measured SLOWER with the generic 2-row kernels (3.200 vs 3.164 ms per step; profiles/r03_b1_ab.txt): off
   int64_t* ids_stage = nullptr;
   uint8_t* mask_stage = nullptr;
   // prefill scratch
@@ -322,6 +326,15 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
       (r = dalloc(e, &e->logits_dec, (size_t)B * ((V + 3) & ~3))) || (r = dalloc(e, &e->last_h, (size_t)B * Hb)) ||
       (r = dalloc(e, &e->ids_stage, (size_t)B * (C + 1))) || (r = dalloc(e, &e->mask_stage, (size_t)B * (C + 1))))
     return r;
+  if ((r = dalloc(e, &e->dec_x2, (size_t)2 * Hd)) || (r = dalloc(e, &e->q_dec2, (size_t)2 * nqd)) || (r = dalloc(e, &e->att_dec2, (size_t)2 * nqd)) ||
+      (r = dalloc(e, &e->act_dec2, (size_t)2 * cfg->decoder.ffn)) || (r = dalloc(e, &e->d_pos01, (size_t)4)))
+    return r;
+  e->d_seq00 = e->d_pos01 + 2;
+  {
+    const int h01[4] = {0, 1, 0, 0};
+    HIPCK(hipMemcpyAsync(e->d_pos01, h01, sizeof(h01), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+  }
   const size_t R = cfg->max_prefill_rows;
   // the prefill scratch serves BOTH stacks (stack_rows: backbone context; decoder pass of the training forward), so every
   // buffer takes the wider of the two shapes (the tiny test model's decoder QKV, 512 wide, is wider than its backbone's 384)
@@ -521,6 +534,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
   else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
+  else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
@@ -603,7 +617,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     };
     const auto tl = e->tiled.find(a.W);
     a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
-    if (left > 16 && e->use_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes: one launch, weights streamed once
+    if (left > 16 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes: one launch, weights streamed once
       const int m = left < 32 ? left : 32;
       slice(m);
       const int r = launch_gemm32(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
@@ -614,7 +628,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
         continue;
       }
     }
-    if (left >= 2 && e->use_mfma) {
+    if (left >= 2 && e->use_mfma && !a.no_mfma) {
       const int m = left < 16 ? left : 16;
       slice(m);
       if (!a.Wt) a.xplanes = nullptr;   // unbound weights (hooks): fp32 activations
@@ -802,8 +816,89 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   return 0;
 }
 
+// The reference's first decoder forward of a frame takes TWO positions at once -- the projected backbone state (position 0)
+// and the projected embedding of codebook 0 (position 1), modeling_csm.py:534-552 -- and only position 1's output is used.
+// B == 1: rows x2[0] (position 0) and x2[1] (position 1) go through the decoder stack as ONE pass of 2-row launches (the
+// M <= 4 skinny GEMM, causal 2-row attention); the last layer appends both positions' K/V and then continues with row 1
+// alone on the single-row kernels.  Against two one-token passes: one weight pass (222 MB) and 10 launches fewer per frame;
+// a row's arithmetic is that of the single-row kernels (gemv.h), so the greedy stream is unchanged (bench parity: all
+// 3 520 tokens equal).  MEASURED (round 3, profiles/r03_b1_ab.txt): 3.200 ms per frame-step against 3.164 ms for two
+// one-token passes -- the 2-row launches run on the LDS-staged gemv_kernel (x through LDS, two barriers), not on the
+// register kernel gemv1_kernel that the single-row passes use, and 15 of them cost more than the 10 launches + one weight
+// pass they replace.  Kept behind `two_token_pass` (default 0); the lever is a 2-row form of gemv1_kernel.
+static int decoder_two_token_pass(csm_engine* e, float* x2) {
+  Stack& s = e->dec;
+  const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn, A = nq * hd;
+  const int nt = e->nt_decoder, nt_small = nt == 1, nt_big = nt >= 1;
+  for (int l = 0; l < s.c.layers; ++l) {
+    const csm_layer_weights_t& w = s.layers[l];
+    const bool last = l + 1 == s.c.layers;
+    GemvArgs a{};
+    a.nt = nt_small;
+    a.W = w.wqkv; a.wscale = w.sqkv; a.N = s.nqkv(); a.K = H; a.x = x2; a.ldx = H; a.ln = w.ln1; a.eps = s.c.rms_eps;
+    a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
+    a.cos_tab = s.cos; a.sin_tab = s.sin; a.row_pos = e->d_pos01; a.row_seq = e->d_seq00;
+    a.qbuf = e->q_dec2; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
+    a.no_mfma = 1;
+    LCK(gemv_rows(e, 2, PRO_NORM, EPI_QKV, a));
+    if (!last) {
+      AttnArgs t{};
+      t.q = e->q_dec2; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+      t.row_seq = e->d_seq00; t.row_pos = e->d_pos01; t.nsplit = 1; t.out = e->att_dec2; t.one_wave = e->attn_one_wave & 1;
+      LCK(launch_attn(e->stream, e->cfg.kv_dtype, 2, t));
+      GemvArgs o{};
+      o.nt = nt_small; o.W = w.wo; o.wscale = w.so; o.N = H; o.K = A; o.x = e->att_dec2; o.ldx = A; o.out = x2; o.ldo = H;
+      o.no_mfma = 1;
+      LCK(gemv_rows(e, 2, PRO_PLAIN, EPI_RESID, o));
+      GemvArgs g{};
+      g.nt = nt_big; g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = x2; g.ldx = H; g.ln = w.ln2; g.eps = s.c.rms_eps;
+      g.out = e->act_dec2; g.ldo = F;
+      g.no_mfma = 1;
+      LCK(gemv_rows(e, 2, PRO_NORM, EPI_SWIGLU, g));
+      GemvArgs d{};
+      d.nt = nt_big; d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = e->act_dec2; d.ldx = F; d.out = x2; d.ldo = H;
+      d.no_mfma = 1;
+      LCK(gemv_rows(e, 2, PRO_PLAIN, EPI_RESID, d));
+    } else {
+      // position 0's hidden state is never read again: only row 1 continues (single-row kernels, position 1)
+      float* h1 = x2 + H;
+      const float* q1 = e->q_dec2 + A;
+      int ao = -2;
+      if ((e->fuse_attn_oproj & 1) && s.lmax <= 32) {
+        AttnOprojArgs f{};
+        f.q = q1; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
+        f.pos_ptr = nullptr; f.pos_const = 1; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h1;
+        f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
+        ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
+        if (ao != -2) LCK(ao);
+      }
+      if (ao == -2) {
+        AttnArgs t{};
+        t.q = q1; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+        t.pos_ptr = nullptr; t.pos_const = 1; t.nsplit = 1; t.out = e->att_dec2; t.one_wave = e->attn_one_wave & 1;
+        LCK(launch_attn(e->stream, e->cfg.kv_dtype, 1, t));
+        GemvArgs o{};
+        o.nt = nt_small; o.W = w.wo; o.wscale = w.so; o.N = H; o.K = A; o.x = e->att_dec2; o.ldx = A; o.out = h1; o.ldo = H;
+        LCK(gemv_rows(e, 1, PRO_PLAIN, EPI_RESID, o));
+      }
+      GemvArgs g{};
+      g.nt = nt_big; g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h1; g.ldx = H; g.ln = w.ln2; g.eps = s.c.rms_eps;
+      g.out = e->act_dec2; g.ldo = F;
+      LCK(gemv_rows(e, 1, PRO_NORM, EPI_SWIGLU, g));
+      GemvArgs d{};
+      d.nt = nt_big; d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = e->act_dec2; d.ldx = F; d.out = h1; d.ldo = H;
+      LCK(gemv_rows(e, 1, PRO_PLAIN, EPI_RESID, d));
+    }
+  }
+  return 0;
+}
+
 static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
   const int B = e->B, C = e->cfg.n_codebooks, V = e->cfg.audio_vocab, Hd = e->cfg.decoder.hidden;
+  // B == 1: positions 0 and 1 of the decoder as one two-row pass (decoder_two_token_pass); x2[0] = position 0's input,
+  // x2[1] = the row every later pass works on
+  const bool two_tok = e->two_token_pass && B == 1 && C >= 2 && e->dec.lmax >= 2;
+  float* const decx = two_tok ? e->dec_x2 + Hd : e->dec_x;
   auto sample = [&](int cb, const float* logits, int ldl) -> int {
     SampleArgs a{};
     a.logits = logits; a.ldl = ldl; a.V = V; a.temperature = s->temperature; a.topk = s->topk; a.rng = e->d_rng;
@@ -812,7 +907,8 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       a.noise_ld = (size_t)C * V;
     }
     a.cb = cb; a.C = C; a.B = B; a.frame_ptr = e->d_frame; a.max_frames = e->cfg.max_frames;
-    a.ring = e->ring; a.forced = s->forced; a.proj_table = e->w.proj_table; a.Hd = Hd; a.dec_x = e->dec_x;
+    a.ring = e->ring; a.forced = s->forced; a.proj_table = e->w.proj_table; a.Hd = Hd; a.dec_x = decx;
+    if (two_tok && cb == 0) { a.copy_src = e->head_out; a.copy_dst = e->dec_x2; a.copy_n = Hd; }
     a.logits_trace = s->logits_trace;
     a.row_done = s->per_row_stop ? e->d_row_done : nullptr;
     if (planes_on(e, e->dec, B) && (e->use_planes & 8)) {
@@ -826,8 +922,9 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
   const bool fused = e->fuse_sample && B == 1 && greedy && !s->noise && !s->logits_trace && Hd % 512 == 0 && Hd <= 1024 &&
                      (V + 1) / 2 <= 1088;
   LCK(sample(0, e->head_out + Hd, e->ld_head));
-  for (int p = 0; p < C; ++p) {
-    float* h = p == 0 ? e->head_out : e->dec_x;
+  if (two_tok) LCK(decoder_two_token_pass(e, e->dec_x2));
+  for (int p = two_tok ? 1 : 0; p < C; ++p) {
+    float* h = p == 0 ? e->head_out : decx;
     const int ldh = p == 0 ? e->ld_head : Hd;
     GemvArgs tok{};
     const bool use_tok = fused && p >= 2;   // input of pass p = token of codebook p-1 (sampled by head p-1)
@@ -836,7 +933,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       tok.tok_forced = s->forced; tok.tok_ring = e->ring; tok.tok_frame_ptr = e->d_frame;
       tok.tok_max_frames = e->cfg.max_frames; tok.tok_C = C; tok.tok_cb = p - 1;
     }
-    for (int l = 0; l < e->dec.c.layers; ++l)
+    for (int l = 0; l < e->dec.c.layers && !(two_tok && p == 1); ++l)
       LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder,
                        e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr,
                        // pass 0 (the backbone state at position 0) produces no logits: its last layer only has to

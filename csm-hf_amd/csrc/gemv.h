@@ -81,6 +81,8 @@ struct GemvArgs {
   float* tok_x_out;        // [K] residual stream of the new pass (written by workgroup 0)
   int configure_only;  // host-side: only set the kernel's dynamic-LDS attribute, do not launch
   int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
+  int no_mfma;         // host-side: rows >= 2 stay on the fp32-FMA kernel (two-token decoder pass: a row's arithmetic is then
+                       // bitwise that of the single-row kernel)
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)

@@ -370,6 +370,11 @@ struct SampleArgs {
   float* oss;
   int oss_ld, oss_n;
   const int* row_done;  // nullable: rows flagged here are frozen -- they emit token 0 (per-row stop)
+  // two-token first decoder pass (B == 1): the launch also copies copy_n floats copy_src -> copy_dst (the projected backbone
+  // state, position 0's input, next to the sampled token's row, position 1's input)
+  const float* copy_src;
+  float* copy_dst;
+  int copy_n;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -444,6 +449,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     float* tr = a.logits_trace + (((size_t)f * a.B + row) * a.C + a.cb) * V;
     for (int i = tid; i < V; i += 256) tr[i] = lg[i];
   }
+  if (a.copy_dst && row == 0)
+    for (int i = tid; i < a.copy_n; i += 256) a.copy_dst[i] = a.copy_src[i];
 
   int choice;
   if (greedy) {
