@@ -132,7 +132,7 @@ struct csm_engine {
   // two-token first decoder pass (B == 1; reference modeling_csm.py:534-552 runs positions 0 and 1 as ONE forward)
   float *dec_x2 = nullptr, *q_dec2 = nullptr, *att_dec2 = nullptr, *act_dec2 = nullptr;
   int *d_pos01 = nullptr, *d_seq00 = nullptr;
-  int two_token_pass = 0;   // measured SLOWER with the generic 2-row kernels (3.200 vs 3.164 ms per step; profiles/r03_b1_ab.txt): off
+  int two_token_pass = 1;   // B == 1: 3.169 -> 3.114-3.129 ms per step on the 2-row register kernel (profiles/r03_b1_ab.txt)
   int64_t* ids_stage = nullptr;
   uint8_t* mask_stage = nullptr;
   // prefill scratch
@@ -822,10 +822,10 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
 // M <= 4 skinny GEMM, causal 2-row attention); the last layer appends both positions' K/V and then continues with row 1
 // alone on the single-row kernels.  Against two one-token passes: one weight pass (222 MB) and 10 launches fewer per frame;
 // a row's arithmetic is that of the single-row kernels (gemv.h), so the greedy stream is unchanged (bench parity: all
-// 3 520 tokens equal).  MEASURED (round 3, profiles/r03_b1_ab.txt): 3.200 ms per frame-step against 3.164 ms for two
-// one-token passes -- the 2-row launches run on the LDS-staged gemv_kernel (x through LDS, two barriers), not on the
-// register kernel gemv1_kernel that the single-row passes use, and 15 of them cost more than the 10 launches + one weight
-// pass they replace.  Kept behind `two_token_pass` (default 0); the lever is a 2-row form of gemv1_kernel.
+// 3 520 tokens equal).  MEASURED (round 3, profiles/r03_b1_ab.txt): on the LDS-staged 2-row kernel (gemv_kernel<M = 2>) the
+// merged pass LOST (3.200 vs 3.164 ms per frame-step: 15 slow launches against 10 launches + one weight pass saved); with a
+// 2-row form of the register kernel (gemv1_kernel<..., M = 2>: both rows share every weight register) it wins:
+// 3.114-3.129 vs 3.169 ms (-1.5 %).  Default on (`two_token_pass`).
 static int decoder_two_token_pass(csm_engine* e, float* x2) {
   Stack& s = e->dec;
   const int H = s.c.hidden, nq = s.c.n_q, nkv = s.c.n_kv, hd = s.c.head_dim, F = s.c.ffn, A = nq * hd;

@@ -268,9 +268,12 @@ struct GemvEpi {
 // loads below the RMS prologue (the last norm-weight loads were issued one by one behind the statistic: three extra
 // dependent L2 round trips per normed launch).  These launches run at <= 4 waves per SIMD anyway (192 .. 1024
 // workgroups on 256 CUs), so registers are free: every load of a wave is issued before anything is consumed.
-template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T>
+// M = rows per launch: 1 (every single-sequence launch) or 2 (the two-token first decoder pass: both rows share every
+// weight register; a row's arithmetic -- pair accumulators, ascending chunks, wave_sum2 -- is exactly the M = 1 form's).
+template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T, int M = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GemvArgs a) {
-  __shared__ float part[4][2 * T];
+  static_assert(M == 1 || (PRO != PRO_TOKNORM && EPI != EPI_ARGMAX), "fused greedy sampling is single-row");
+  __shared__ float part[4][2 * T * M];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
@@ -283,14 +286,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const int e0 = kw * (U * 512) + lane * 8;  // first element of this lane's chunk 0; chunk u at + u*512
   GemvTask k[T];
-  GemvEpi<KT, EPI, 1> epi[T];
+  GemvEpi<KT, EPI, M> epi[T];
   W8<WT> w0[T][U], w1[T][U];
   // vmcnt retires in issue order: the x slice and the norm weights (L2 hits, consumed first by the RMS
   // prologue) are requested ahead of the weight stream so the prologue runs while the weights are in flight.
   // PRO_TOKNORM cannot: its x row address depends on the argmax below, so there the weights go first.
   // The epilogue prefetch goes first of all: at M = 1 the residual values requested behind the weights arrive too
   // late (dec o_proj 3.13 vs 2.94 us); EPI_QKV requests only its position here and the cos/sin row behind the weights.
-  f32x4 xa[U], xb[U], la[U], lb[U];
+  f32x4 xa[M][U], xb[M][U], la[U], lb[U];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     k[t] = gemv_map_task<EPI>(a, (blockIdx.x * TPB + tw) * T + t, ntask);
@@ -298,10 +301,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   }
   if (PRO != PRO_TOKNORM) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      xa[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512);
-      xb[u] = *reinterpret_cast<const f32x4*>(a.x + e0 + u * 512 + 4);
-    }
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xa[m][u] = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + e0 + u * 512);
+        xb[m][u] = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + e0 + u * 512 + 4);
+      }
   }
   if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
 #pragma unroll
@@ -352,66 +357,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     const float* xsrc = a.tok_table + ((size_t)feed + (size_t)a.tok_row_base) * K;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xa[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512);
-      xb[u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
+      xa[0][u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512);
+      xb[0][u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
     }
   }
   if (PRO == PRO_TOKNORM && blockIdx.x == 0 && wave == 0) {   // the new pass's residual stream
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512) = xa[u];
-      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512 + 4) = xb[u];
+      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512) = xa[0][u];
+      *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512 + 4) = xb[0][u];
     }
   }
   // The arithmetic below is written on float pairs (v_pk_mul_f32 / v_pk_fma_f32): the gate/up launch is VALU-issue
   // bound once its weights arrive (SQ counters: 52 % of wave time stalled at issue), so instructions per weight matter.
-  f32x2 xp[U][4];
+  f32x2 xp[M][U][4];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    xp[u][0] = f32x2{xa[u][0], xa[u][1]};
-    xp[u][1] = f32x2{xa[u][2], xa[u][3]};
-    xp[u][2] = f32x2{xb[u][0], xb[u][1]};
-    xp[u][3] = f32x2{xb[u][2], xb[u][3]};
-  }
-  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
-    f32x2 ss2 = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ss2 = PKFMA(xp[u][i], xp[u][i], ss2);
-    // mean = sum * rcp(K): identical to sum / K for the power-of-two widths of this model family; raw v_rsq_f32
-    // (the argument is >= eps, far from the denormal range the library wrapper rescales for)
-    const float sc = __builtin_amdgcn_rsqf(wave_sum(ss2[0] + ss2[1]) * __builtin_amdgcn_rcpf((float)K) + a.eps);
-    const f32x2 sc2 = f32x2{sc, sc};
+  for (int m = 0; m < M; ++m)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xp[u][0] = (xp[u][0] * sc2) * f32x2{la[u][0], la[u][1]};
-      xp[u][1] = (xp[u][1] * sc2) * f32x2{la[u][2], la[u][3]};
-      xp[u][2] = (xp[u][2] * sc2) * f32x2{lb[u][0], lb[u][1]};
-      xp[u][3] = (xp[u][3] * sc2) * f32x2{lb[u][2], lb[u][3]};
+      xp[m][u][0] = f32x2{xa[m][u][0], xa[m][u][1]};
+      xp[m][u][1] = f32x2{xa[m][u][2], xa[m][u][3]};
+      xp[m][u][2] = f32x2{xb[m][u][0], xb[m][u][1]};
+      xp[m][u][3] = f32x2{xb[m][u][2], xb[m][u][3]};
+    }
+  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      f32x2 ss2 = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss2 = PKFMA(xp[m][u][i], xp[m][u][i], ss2);
+      // mean = sum * rcp(K): identical to sum / K for the power-of-two widths of this model family; raw v_rsq_f32
+      // (the argument is >= eps, far from the denormal range the library wrapper rescales for)
+      const float sc = __builtin_amdgcn_rsqf(wave_sum(ss2[0] + ss2[1]) * __builtin_amdgcn_rcpf((float)K) + a.eps);
+      const f32x2 sc2 = f32x2{sc, sc};
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xp[m][u][0] = (xp[m][u][0] * sc2) * f32x2{la[u][0], la[u][1]};
+        xp[m][u][1] = (xp[m][u][1] * sc2) * f32x2{la[u][2], la[u][3]};
+        xp[m][u][2] = (xp[m][u][2] * sc2) * f32x2{lb[u][0], lb[u][1]};
+        xp[m][u][3] = (xp[m][u][3] * sc2) * f32x2{lb[u][2], lb[u][3]};
+      }
     }
   }
 #ifdef CSM_PROBE
   // T1: the activations (and, for normed launches, the RMS statistic) are in registers
-  const float probe_x = xp[0][0][0] + xp[U - 1][3][1];
+  const float probe_x = xp[0][0][0][0] + xp[0][U - 1][3][1];
   asm volatile("" :: "v"(probe_x));
   const unsigned long long dbg_t1 = a.dbg ? __builtin_readcyclecounter() : 0ull;
 #endif
-  float s0[T], s1[T];
+  float s0[T][M], s1[T][M];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f32x2 c0 = f32x2{0.f, 0.f}, c1 = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int m = 0; m < M; ++m) {
+      f32x2 c0 = f32x2{0.f, 0.f}, c1 = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        c0 = PKFMA(w0[t][u].pair(i), xp[u][i], c0);
-        c1 = PKFMA(w1[t][u].pair(i), xp[u][i], c1);
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c0 = PKFMA(w0[t][u].pair(i), xp[m][u][i], c0);
+          c1 = PKFMA(w1[t][u].pair(i), xp[m][u][i], c1);
+        }
       }
+      s0[t][m] = c0[0] + c0[1];
+      s1[t][m] = c1[0] + c1[1];
+      wave_sum2(s0[t][m], s1[t][m]);
     }
-    s0[t] = c0[0] + c0[1];
-    s1[t] = c1[0] + c1[1];
-    wave_sum2(s0[t], s1[t]);
   }
 #ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
   if (a.dbg && tid == 0) {
@@ -424,20 +437,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   if (KS > 1) {
     if (lane == 0) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) { part[wave][2 * t] = s0[t]; part[wave][2 * t + 1] = s1[t]; }
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int m = 0; m < M; ++m) { part[wave][2 * (t * M + m)] = s0[t][m]; part[wave][2 * (t * M + m) + 1] = s1[t][m]; }
     }
     __syncthreads();
     if (kw == 0 && lane == 0) {
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int s = 1; s < KS; ++s) { s0[t] += part[wave + s][2 * t]; s1[t] += part[wave + s][2 * t + 1]; }
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+          for (int s = 1; s < KS; ++s) { s0[t][m] += part[wave + s][2 * (t * M + m)]; s1[t][m] += part[wave + s][2 * (t * M + m) + 1]; }
     }
   }
   if (lane == 0 && kw == 0) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
-      if (k[t].live) epi[t].store(a, k[t], 0, s0[t], s1[t]);
+      if (k[t].live) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) epi[t].store(a, k[t], m, s0[t][m], s1[t][m]);
+      }
   }
   if (a.bump_a && blockIdx.x == 0 && tid == 0) {
     *a.bump_a += 1;
