@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcsm_hip.so")
-UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "gemm_mx", "attn_prefill", "launchers", "engine", "mimi"]
+UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "gemm_mx", "train", "attn_prefill", "launchers", "engine", "mimi"]
 UNIT_FLAGS = {"attn_prefill": ["-mllvm", "--amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 

@@ -28,6 +28,7 @@
 #include "gemm_mx.h"
 #include "gemv.h"
 #include "misc.h"
+#include "train.h"
 
 int launch_embed(hipStream_t st, int wdtype, int rows, const EmbedArgs& a);
 int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int rows, int H, float eps, float* out,
@@ -157,6 +158,7 @@ struct csm_engine {
   int gemm_dma = 1, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): on for launches of up to 4096 rows
   // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
   // the quantised-activation scratch [max_prefill_rows][widest K] + scales
+  std::unordered_map<const void*, void*> train_wT;   // transposed weight copies of the training backward (train_impl.inc)
   std::vector<csm_mx_layer_t> mx_layers;
   int prefill_mx = 0;
   uint8_t *p_mx_q = nullptr, *p_mx_s = nullptr, *p_mx_q2 = nullptr, *p_mx_s2 = nullptr;   // q2 / s2: the SwiGLU output (down_proj's operand)
@@ -493,6 +495,7 @@ extern "C" int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w) {
   e->w.backbone.layers = e->bb.layers.data();
   e->w.decoder.layers = e->dec.layers.data();
   e->bound = true;
+  e->train_wT.clear();
   drop_graphs(e);
   return build_tiled(e);
 }
@@ -2036,3 +2039,5 @@ extern "C" int csm_bench_gemv(csm_engine_t* e, const void* W, size_t w_stride, i
   drop_tmp();
   return 0;
 }
+
+#include "train_impl.inc"

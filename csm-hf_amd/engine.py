@@ -31,7 +31,7 @@ EXPORTS = [
     "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
     "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
-    "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx",
+    "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx", "csm_forward_backward",
 ]
 
 
@@ -62,6 +62,19 @@ class Weights(C.Structure):
     _fields_ = [("backbone", StackW), ("decoder", StackW), ("text_emb", C.c_void_p), ("audio_emb", C.c_void_p),
                 ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p), ("proj_table", C.c_void_p),
                 ("s_proj_head0", C.c_void_p), ("s_audio_head", C.c_void_p)]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dwqkv", "dwo", "dwgu", "dwd", "dln1", "dln2")]
+
+
+class StackGrads(C.Structure):
+    _fields_ = [("layers", C.POINTER(LayerGrads)), ("final_norm", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("backbone", StackGrads), ("decoder", StackGrads), ("text_emb", C.c_void_p), ("audio_emb", C.c_void_p),
+                ("proj_head0", C.c_void_p), ("audio_head_t", C.c_void_p)]
 
 
 class MxLayer(C.Structure):
@@ -135,6 +148,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_bind_mx_weights.argtypes = [vp, C.POINTER(MxLayer), i32]
     lib.csm_mx_quantize.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.csm_gemm_mx.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
+    lib.csm_forward_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.POINTER(Grads)]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
     lib.csm_set_length.argtypes = [vp, i32, i32]
@@ -502,6 +516,59 @@ class Engine:
         self.length += S
         self.batch = B
         return out, lh, lg
+
+    def forward_backward(self, ids: torch.Tensor, mask: Optional[torch.Tensor], labels: torch.Tensor):
+        """The reference's training objective AND its gradients (csm_forward_backward; reference consumer train.py:308-326):
+        returns (losses [3] fp32 = loss, backbone_loss, decoder_loss; {reference parameter name: fp32 gradient of `loss`}).
+        The library accumulates into buffers in the engine's PACKED layout; they are unpacked here into the checkpoint's
+        key layout (q/k/v rows of wqkv, de-interleaved gate/up rows of wgu, [projection; codebook0_head], audio_head
+        transposed back to [C-1, Hd, V])."""
+        B, S = ids.shape[0], ids.shape[1]
+        ids, m = self._prep_ids(ids, mask)
+        lab = labels.to(device=self.device, dtype=torch.int64).contiguous()
+        if lab.shape != ids.shape:
+            raise ValueError(f"labels {tuple(lab.shape)} must match input_ids {tuple(ids.shape)}")
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        g = Grads()
+        keep, bufs = [], {}
+        for name, dst, lc in (("backbone", g.backbone, self.cfg.backbone_config), ("decoder", g.decoder, self.cfg.decoder_config)):
+            H, F, hd = lc.hidden_size, lc.intermediate_size, lc.head_dim
+            nq, nkv = lc.num_attention_heads, lc.num_key_value_heads
+            arr = (LayerGrads * lc.num_hidden_layers)()
+            for i in range(lc.num_hidden_layers):
+                L = dict(dwqkv=z((nq + 2 * nkv) * hd, H), dwo=z(H, nq * hd), dwgu=z(2 * F, H), dwd=z(H, F), dln1=z(H), dln2=z(H))
+                for k, t in L.items():
+                    setattr(arr[i], k, t.data_ptr())
+                bufs[(name, i)] = L
+            fn = z(H)
+            bufs[(name, "norm")] = fn
+            dst.layers, dst.final_norm = arr, fn.data_ptr()
+            keep.append(arr)
+        bc, dc = self.cfg.backbone_config, self.cfg.decoder_config
+        te, ae = z(self.cfg.text_vocab_size, bc.hidden_size), z(self.C * self.V, bc.hidden_size)
+        ph, ah = z(dc.hidden_size + self.V, bc.hidden_size), z(self.C - 1, self.V, dc.hidden_size)
+        g.text_emb, g.audio_emb, g.proj_head0, g.audio_head_t = te.data_ptr(), ae.data_ptr(), ph.data_ptr(), ah.data_ptr()
+        out = torch.empty(3, dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_forward_backward(self._h, _ptr(ids), _ptr(m), _ptr(lab), B, S, _ptr(out), C.byref(g)))
+        self.sync()
+        grads = {"text_embeddings.weight": te, "audio_embeddings.weight": ae, "projection.weight": ph[: dc.hidden_size],
+                 "codebook0_head.weight": ph[dc.hidden_size:], "audio_head": ah.transpose(1, 2).contiguous()}
+        for name, lc in (("backbone", bc), ("decoder", dc)):
+            nqd, nkd = lc.num_attention_heads * lc.head_dim, lc.num_key_value_heads * lc.head_dim
+            for i in range(lc.num_hidden_layers):
+                L, p = bufs[(name, i)], f"{name}.layers.{i}"
+                grads[f"{p}.self_attn.q_proj.weight"] = L["dwqkv"][:nqd]
+                grads[f"{p}.self_attn.k_proj.weight"] = L["dwqkv"][nqd:nqd + nkd]
+                grads[f"{p}.self_attn.v_proj.weight"] = L["dwqkv"][nqd + nkd:]
+                grads[f"{p}.self_attn.o_proj.weight"] = L["dwo"]
+                grads[f"{p}.mlp.gate_proj.weight"] = L["dwgu"][0::2]
+                grads[f"{p}.mlp.up_proj.weight"] = L["dwgu"][1::2]
+                grads[f"{p}.mlp.down_proj.weight"] = L["dwd"]
+                grads[f"{p}.input_layernorm.weight"] = L["dln1"]
+                grads[f"{p}.post_attention_layernorm.weight"] = L["dln2"]
+            grads[f"{name}.norm.weight"] = bufs[(name, "norm")]
+        return out, grads
 
     def step_ids(self, ids: torch.Tensor, mask: Optional[torch.Tensor], advance_frame: bool):
         B = ids.shape[0]

@@ -152,6 +152,24 @@ def _llama_modules(lc) -> nn.Module:
     return m
 
 
+class _CSMTrainLoss(torch.autograd.Function):
+    """Autograd bridge of the HIP training pass: forward runs csm_forward_backward once (loss AND every gradient), backward
+    hands the stored gradients out scaled by d(loss) -- what `loss.backward()` of the reference's HF-Trainer loop needs."""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, attention_mask, labels, names, *params):
+        out, grads = model.loss_and_grads(input_ids, attention_mask, labels)
+        ctx.grads = [grads[n] for n in names]
+        ctx.dtypes = [p.dtype for p in params]
+        ctx.mark_non_differentiable(out.backbone_loss, out.decoder_loss)
+        return out.loss.clone(), out.backbone_loss.clone(), out.decoder_loss.clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_bl, g_dl):
+        gs = [(g * g_loss).to(dt) for g, dt in zip(ctx.grads, ctx.dtypes)]
+        return (None, None, None, None, None, *gs)
+
+
 class _Norm(nn.Module):
     def __init__(self, n):
         super().__init__()
@@ -335,10 +353,49 @@ class CSMModel(nn.Module):
         return t.to(self.dtype)
 
     # ---- reference API ---------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, temperature=1.0, topk=50,
                 generate_frame=False, labels=None):
+        """reference :292-482.  With `labels`, gradients enabled and parameters that require them (the reference's training
+        call, train.py:308-326) the returned `loss` carries an autograd node: `out.loss.backward()` fills `.grad` of every
+        parameter from the HIP backward pass (csm_forward_backward).  Everything else runs without autograd."""
+        if labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(input_ids, attention_mask, labels, position_ids, past_key_values, return_dict)
+        return self._forward_nograd(input_ids, attention_mask, position_ids, past_key_values, use_cache, output_attentions,
+                                    output_hidden_states, return_dict, temperature, topk, generate_frame, labels)
+
+    @torch.no_grad()
+    def loss_and_grads(self, input_ids, attention_mask, labels):
+        """(CSMOutput with loss / backbone_loss / decoder_loss, {parameter name: fp32 gradient of `loss`}) -- the HIP training
+        pass without the autograd bridge (reference objective modeling_csm.py:367-465 and its derivative)."""
+        B, S = input_ids.shape[0], input_ids.shape[1]
+        if tuple(labels.shape) != tuple(input_ids.shape):
+            raise ValueError(f"labels {tuple(labels.shape)} must match input_ids {tuple(input_ids.shape)}")
+        if self.weight_format == "fp8":
+            raise ValueError("the training pass needs native (fp32 / bf16) weights")
+        eng = self._ensure_engine(B, S + 1, 1, 32)
+        eng.reset()
+        self._epoch += 1
+        self._frame_pending = False
+        eng.set_kv_start(self._kv_starts(attention_mask, B, S))
+        losses, grads = eng.forward_backward(input_ids, attention_mask, labels)
+        return CSMOutput(loss=losses[0], backbone_loss=losses[1], decoder_loss=losses[2]), grads
+
+    def _forward_train(self, input_ids, attention_mask, labels, position_ids, past_key_values, return_dict):
+        if past_key_values is not None or position_ids is not None:
+            raise NotImplementedError("forward(labels=...) takes a fresh context: no past_key_values / position_ids")
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        loss, bl, dl = _CSMTrainLoss.apply(self, input_ids, attention_mask, labels, names, *params)
+        if not return_dict:
+            return (loss,)
+        return CSMOutput(loss=loss, backbone_loss=bl.detach(), decoder_loss=dl.detach())
+
+    @torch.no_grad()
+    def _forward_nograd(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, use_cache=None,
+                        output_attentions=None, output_hidden_states=None, return_dict=None, temperature=1.0, topk=50,
+                        generate_frame=False, labels=None):
         """reference :292-482, inference branch.  `temperature/topk/generate_frame` accepted and ignored
         as in the reference."""
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict

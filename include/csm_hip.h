@@ -238,6 +238,28 @@ int csm_gemm_mx(csm_engine_t* e, const uint8_t* Wq, const uint8_t* Ws, int N, in
  * like csm_prefill does (last_h_out / c0_logits_out as there, nullable).  No backward pass is provided. */
 int csm_forward_loss(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, const int64_t* labels, int B, int S,
                      float* out3, float* last_h_out, float* c0_logits_out);
+/* ---- the same objective WITH its gradients (reference consumer: train.py:308-326, CSMTrainer.compute_loss -> loss.backward()).
+ * Gradients of `loss` w.r.t. every parameter are ACCUMULATED (+=) into caller-owned fp32 device buffers laid out like the
+ * engine's packed weights (csm_layer_weights_t): wqkv [(n_q + 2 n_kv) hd][H] = [q; k; v] rows, wgu [2 F][H] with gate / up
+ * rows interleaved, proj_head0 [Hd + V][Hb] = [projection; codebook0_head], audio_head_t [C-1][V][Hd] (the transposed
+ * slices); norm weights [H]; embedding tables in their own shapes.  fp32 or bf16 weights; fp32 arithmetic throughout
+ * (csrc/train.h).  Starts from scratch: the KV cache is neither read nor written; csm_set_kv_start gives the left padding. */
+typedef struct {
+  float *dwqkv, *dwo, *dwgu, *dwd, *dln1, *dln2;
+} csm_layer_grads_t;
+typedef struct {
+  const csm_layer_grads_t* layers;   /* host array [cfg.layers] */
+  float* final_norm;
+} csm_stack_grads_t;
+typedef struct {
+  csm_stack_grads_t backbone, decoder;
+  float* text_emb;       /* [text_vocab, Hb] */
+  float* audio_emb;      /* [n_codebooks * audio_vocab, Hb] */
+  float* proj_head0;     /* [Hd + audio_vocab, Hb] */
+  float* audio_head_t;   /* [n_codebooks - 1, audio_vocab, Hd] */
+} csm_grads_t;
+int csm_forward_backward(csm_engine_t* e, const int64_t* ids, const uint8_t* mask, const int64_t* labels, int B, int S,
+                         float* out3, const csm_grads_t* grads);
 /* backbone KV cache <-> the HF layout of `past_key_values` (transformers DynamicCache: per layer keys / values
  * [B, n_kv, len, head_dim]; reference modeling_csm.py:355-358 returns it, :349 takes it back), fp32 on the device.
  * Export reads the resident batch; import + csm_set_length continue a context the caller built, forked or edited. */

@@ -3,7 +3,7 @@
 Runs only in the build container (needs /root/reference and `transformers`); the reference never
 travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
 
-    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss] [--frames2 200]
+    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss,grad] [--frames2 200]
 
 What it does
   * imports /root/reference/modeling_csm.py unmodified;
@@ -356,6 +356,52 @@ def gen_loss():
               f"{float(out.decoder_loss):.6f}  ({time.time() - t0:.1f}s)", flush=True)
 
 
+GRAD_KEYS = ["backbone.layers.0.self_attn.q_proj.weight", "backbone.layers.0.self_attn.k_proj.weight",
+             "backbone.layers.1.self_attn.v_proj.weight", "backbone.layers.1.self_attn.o_proj.weight",
+             "backbone.layers.0.mlp.gate_proj.weight", "backbone.layers.1.mlp.down_proj.weight",
+             "backbone.layers.0.input_layernorm.weight", "backbone.layers.1.post_attention_layernorm.weight", "backbone.norm.weight",
+             "decoder.layers.0.self_attn.q_proj.weight", "decoder.layers.1.self_attn.k_proj.weight", "decoder.layers.0.self_attn.o_proj.weight",
+             "decoder.layers.1.mlp.up_proj.weight", "decoder.layers.1.input_layernorm.weight",
+             "decoder.norm.weight", "projection.weight", "codebook0_head.weight"]
+
+
+def gen_grad():
+    """Training BACKWARD (consumer train.py:308-326): gradients the REFERENCE's `loss.backward()` leaves in `.grad`, tiny
+    configuration, fp32, the committed `tiny_loss` inputs.  Stored: a selection of whole matrices (GRAD_KEYS), one slice of
+    `audio_head`, the touched rows of the two embedding tables, and the gradient NORM of every parameter.  The oracle's own
+    autograd (torch.autograd through oracle/csm_oracle.py: forward_loss) is checked against all of it here."""
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    model = build_ref(cfg, {k: v.float() for k, v in sd.items()}, torch.float32)
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    ids, mask, labels = loss_inputs(cfg, 2, 4, 10, seed=41)
+    out = model(input_ids=ids, attention_mask=mask, labels=labels, return_dict=True)
+    out.loss.backward()
+    ref = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+    osd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        O.forward_loss(osd, cfg, ids, mask, labels)[0].backward()
+    worst = 0.0
+    for k, gr in ref.items():
+        err = float((osd[k].grad - gr).norm() / gr.norm().clamp_min(1e-20))
+        worst = max(worst, err)
+    assert set(ref) == set(osd) and worst < 1e-4, worst
+    store = {"loss": np.float32(out.loss.detach())}
+    for k in GRAD_KEYS:
+        store["g." + k] = ref[k].numpy()
+    store["g.audio_head.5"] = ref["audio_head"][5].numpy()
+    for k in ("text_embeddings.weight", "audio_embeddings.weight"):
+        rows = (ref[k].abs().sum(1) > 0).nonzero()[:, 0]
+        store["rows." + k] = rows.numpy()
+        store["g." + k] = ref[k][rows].numpy()
+    names = sorted(ref)
+    store["norm_names"] = np.array(names)
+    store["norms"] = np.array([float(ref[k].norm()) for k in names], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "tiny_grad.npz"), **store)
+    print(f"[golden] tiny_grad written: {len(ref)} parameters, oracle autograd vs reference worst rel err {worst:.2e}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss")
@@ -373,6 +419,8 @@ def main():
         gen_1b(which, a.frames2)
     if "loss" in which:
         gen_loss()
+    if "grad" in which:
+        gen_grad()
 
 
 if __name__ == "__main__":

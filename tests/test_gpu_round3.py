@@ -356,3 +356,100 @@ def test_lds_dma_bf16_gemm_is_bitwise_the_square_tile():
     split = run(dict(gemm_dma=2, gemm_wide=1, prefill_splitk=1))
     assert float((split[0] - base[0]).norm() / base[0].norm()) < 5e-2     # bf16 mode: a last-bit change re-rounds downstream
     m._drop_engine()
+
+
+# ---------------------------------------------------------------------------------------------------
+# row f-3: the training BACKWARD pass (csm_forward_backward)
+# ---------------------------------------------------------------------------------------------------
+def _grad_err(got, want):
+    return float((got.double().cpu() - want.double()).norm() / want.double().norm().clamp_min(1e-30))
+
+
+def test_training_backward_vs_reference_gradients():
+    """Gradients of the reference's `loss.backward()` (fixture tiny_grad, oracle/make_golden.py --only grad: the reference
+    model itself, fp32) against the HIP backward pass: every stored matrix, the audio_head slice, the touched embedding
+    rows, and the gradient NORM of all 43 parameters.  fp32 arithmetic on both sides: tolerance 1e-4 relative (summation
+    order; the embedding scatter-add uses fp32 atomics)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tiny_grad.npz"))
+    gl = np.load(os.path.join(ROOT, "tests", "golden", "tiny_loss.npz"))
+    cfg, sd, m = tiny_model()
+    ids, mask, labels = (torch.from_numpy(gl[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
+    out, grads = m.loss_and_grads(ids, mask, labels)
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert set(grads) == set(sd)
+    for k in [k[2:] for k in g.files if k.startswith("g.") and k[2:] in sd and not k.endswith("embeddings.weight")]:
+        assert _grad_err(grads[k], torch.from_numpy(g["g." + k])) < 1e-4, k
+    assert _grad_err(grads["audio_head"][5], torch.from_numpy(g["g.audio_head.5"])) < 1e-4
+    for k in ("text_embeddings.weight", "audio_embeddings.weight"):
+        rows = torch.from_numpy(g["rows." + k])
+        assert _grad_err(grads[k][rows.to(DEV)], torch.from_numpy(g["g." + k])) < 1e-4, k
+        other = torch.ones(grads[k].shape[0], dtype=torch.bool)
+        other[rows] = False
+        assert float(grads[k][other.to(DEV)].abs().max()) == 0.0            # untouched rows get no gradient
+    for name, want in zip(g["norm_names"], g["norms"]):
+        got = float(grads[str(name)].double().norm())
+        assert abs(got - float(want)) < 1e-4 * float(want), (name, got, want)
+    m._drop_engine()
+
+
+def test_training_backward_vs_oracle_autograd_padded_batch_and_autograd_bridge():
+    """Other shapes against torch.autograd THROUGH the oracle (oracle/csm_oracle.py: forward_loss; pinned bitwise to the
+    reference's gradients by make_golden.py): a left-padded batch, frames without a full label set, more frames than one
+    sequence; then the bridge: `model(..., labels=...).loss.backward()` fills `.grad` like the reference's training loop
+    (train.py:308-326), scaled by the upstream gradient, and accumulates over two calls."""
+    cfg, sd, m = tiny_model(seed=3)
+    ids, mask = synth_context(cfg, 3, 4, 13, seed=90)
+    labels = torch.full_like(ids, -100)
+    labels[:, 4:, :32] = ids[:, 4:, :32]
+    labels[1, 7, 9] = -100                                   # not a decoder frame
+    labels[2, 10:, :] = -100
+    ids[1, :5], mask[1, :5], labels[1, :5] = 0, 0, -100      # left padding (the processor pads on the left)
+    osd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        want = O.forward_loss(osd, cfg, ids, mask, labels)
+        want[0].backward()
+    out, grads = m.loss_and_grads(ids.to(DEV), mask.to(DEV), labels.to(DEV))
+    assert abs(float(out.loss) - float(want[0])) < 2e-5 * float(want[0])
+    worst = max(_grad_err(grads[k], osd[k].grad) for k in sd)
+    assert worst < 1e-4, worst
+    # autograd bridge
+    m.requires_grad_(True)
+    o1 = m(ids.to(DEV), mask.to(DEV), labels=labels.to(DEV))
+    assert o1.loss.requires_grad and not o1.backbone_loss.requires_grad
+    (2.0 * o1.loss).backward()
+    p = dict(m.named_parameters())
+    k = "decoder.layers.1.mlp.down_proj.weight"
+    assert _grad_err(p[k].grad, 2.0 * osd[k].grad) < 1e-4
+    m(ids.to(DEV), mask.to(DEV), labels=labels.to(DEV)).loss.backward()
+    assert _grad_err(p[k].grad, 3.0 * osd[k].grad) < 1e-4      # .grad accumulates, as torch's does
+    assert all(q.grad is not None for q in p.values())
+    with torch.no_grad():                                      # no autograd requested: the forward-only path, same loss
+        o2 = m(ids.to(DEV), mask.to(DEV), labels=labels.to(DEV))
+    assert not o2.loss.requires_grad and abs(float(o2.loss) - float(o1.loss)) < 1e-5 * float(o1.loss)
+    m.requires_grad_(False)
+    m._drop_engine()
+
+
+def test_training_backward_bf16_checkpoint_mid_size():
+    """A bf16 checkpoint with csm-1b's head shapes (hd 64 / 128, GQA 4:1, FFN 4x) at a reduced width: gradients against
+    torch.autograd through the oracle in fp32 arithmetic on the same (bf16-representable) weights."""
+    cfg = CSMConfig.tiny(backbone_config=dict(hidden_size=512, intermediate_size=2048, num_hidden_layers=3, num_attention_heads=8,
+                                              num_key_value_heads=2), 
+                         decoder_config=dict(hidden_size=256, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=2,
+                                             num_key_value_heads=1))
+    sd = synth_state_dict(cfg, seed=1, std=0.05, dtype=torch.bfloat16, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    ids, mask = synth_context(cfg, 2, 6, 40, seed=91)
+    labels = torch.full_like(ids, -100)
+    labels[:, 6:, :32] = ids[:, 6:, :32]
+    osd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        want = O.forward_loss(osd, cfg, ids, mask, labels)
+        want[0].backward()
+    out, grads = m.loss_and_grads(ids.to(DEV), mask.to(DEV), labels.to(DEV))
+    assert abs(float(out.loss) - float(want[0])) < 1e-4 * float(want[0])
+    worst = max((_grad_err(grads[k], osd[k].grad), k) for k in sd)
+    assert worst[0] < 2e-4, worst
+    m._drop_engine()
