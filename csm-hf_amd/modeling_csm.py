@@ -12,8 +12,9 @@ Deviations from the reference, all deliberate (DESIGN.md "Deviations"):
   * left-padded rows mask their pads at every step, so a padded row equals its solo run (the reference
     forgets the pad mask on decode steps).
   * `past_key_values` is an opaque handle onto the engine-resident KV cache, not a `DynamicCache`.
-  * the training branch (`labels=`, :367-465) is built FORWARD ONLY: `forward(labels=...)` returns the reference's loss,
-    backbone_loss and decoder_loss (tensors without autograd history); there is no backward pass.
+  * the training branch (`labels=`, :367-465): `forward(labels=...)` returns the reference's loss, backbone_loss and
+    decoder_loss; with gradients enabled and parameters that require them the loss carries an autograd node backed by the
+    HIP backward pass (csm_forward_backward), so `loss.backward()` fills `.grad` like the reference's training loop.
 """
 from __future__ import annotations
 

@@ -402,6 +402,31 @@ def gen_grad():
     print(f"[golden] tiny_grad written: {len(ref)} parameters, oracle autograd vs reference worst rel err {worst:.2e}", flush=True)
 
 
+def gen_grad_1b():
+    """csm-1b (bf16-representable weights, fp32 arithmetic), the committed `csm1b_loss` inputs: the gradient NORM of every
+    parameter after the reference's `loss.backward()` and the leading 64 x 64 block of a few matrices (12 GB of gradients
+    do not fit a fixture)."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, bf16_representable=True)
+    model = build_ref(cfg, {k: v.float() for k, v in sd.items()}, torch.float32)
+    del sd
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    ids, mask, labels = loss_inputs(cfg, 2, 6, 18, seed=41)
+    out = model(input_ids=ids, attention_mask=mask, labels=labels, return_dict=True)
+    out.loss.backward()
+    ref = {k: p_.grad for k, p_ in model.named_parameters() if p_.grad is not None}
+    names = sorted(ref)
+    store = {"loss": np.float32(out.loss.detach()), "norm_names": np.array(names),
+             "norms": np.array([float(ref[k].double().norm()) for k in names], dtype=np.float64)}
+    for k in ("backbone.layers.0.self_attn.q_proj.weight", "backbone.layers.15.mlp.down_proj.weight", "backbone.layers.7.mlp.gate_proj.weight",
+              "decoder.layers.0.self_attn.v_proj.weight", "decoder.layers.3.mlp.up_proj.weight", "projection.weight", "codebook0_head.weight"):
+        store["blk." + k] = ref[k][:64, :64].numpy().copy()
+    store["blk.audio_head.7"] = ref["audio_head"][7, :64, :64].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "csm1b_grad.npz"), **store)
+    print(f"[golden] csm1b_grad written: {len(ref)} parameters, loss {float(out.loss):.6f}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss")
@@ -421,6 +446,8 @@ def main():
         gen_loss()
     if "grad" in which:
         gen_grad()
+    if "grad1b" in which:
+        gen_grad_1b()
 
 
 if __name__ == "__main__":

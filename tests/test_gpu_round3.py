@@ -453,3 +453,33 @@ def test_training_backward_bf16_checkpoint_mid_size():
     worst = max((_grad_err(grads[k], osd[k].grad), k) for k in sd)
     assert worst[0] < 2e-4, worst
     m._drop_engine()
+
+
+def test_training_backward_csm1b_vs_reference_gradient_norms():
+    """csm-1b at full size (bf16-representable weights, committed `csm1b_loss` inputs): the gradient norm of each of the
+    187 parameters and the leading 64 x 64 block of seven matrices + one audio_head slice against what the REFERENCE's
+    `loss.backward()` produced (fixture csm1b_grad; fp32 arithmetic both sides).  Tolerance 1e-3 relative: 16 layers of
+    fp32 summation-order differences on gradients that span five orders of magnitude."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "csm1b_grad.npz"))
+    gl = np.load(os.path.join(ROOT, "tests", "golden", "csm1b_loss.npz"))
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    ids, mask, labels = (torch.from_numpy(gl[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
+    out, grads = m.loss_and_grads(ids, mask, labels)
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-4 * float(g["loss"])
+    worst = ("", 0.0)
+    for name, want in zip(g["norm_names"], g["norms"]):
+        got = float(grads[str(name)].double().norm())
+        err = abs(got - float(want)) / float(want)
+        worst = max(worst, (str(name), err), key=lambda t: t[1])
+    assert worst[1] < 1e-3, worst
+    for k in [k[4:] for k in g.files if k.startswith("blk.")]:
+        want = torch.from_numpy(g["blk." + k])
+        got = grads["audio_head"][7, :64, :64] if k == "audio_head.7" else grads[k][:64, :64]
+        assert _grad_err(got, want) < 1e-3, k
+    m._drop_engine()
+    del m, grads
+    torch.cuda.empty_cache()
