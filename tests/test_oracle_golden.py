@@ -130,3 +130,25 @@ def test_oracle_training_forward_loss_vs_reference(gold):
     _, bl2, dl2, _, _ = O.forward_loss(sd, cfg, ids, mask, lab2)
     assert float(dl2) == 0.0 and abs(float(bl2) - float(bl)) < 1e-6
 
+
+
+def test_oracle_autograd_vs_reference_gradients(gold):
+    """Row f-3: torch.autograd through the oracle's forward_loss reproduces the gradients the REFERENCE's loss.backward()
+    left in `.grad` (fixture tiny_grad, oracle/make_golden.py --only grad) -- the checker the GPU backward pass is held to."""
+    import torch
+    from csm_hf_amd import CSMConfig
+    from csm_hf_amd.synth import synth_state_dict
+    from oracle import csm_oracle as O
+    g, gl = gold("tiny_grad"), gold("tiny_loss")
+    cfg = CSMConfig.tiny()
+    sd = {k: v.float().clone().requires_grad_(True) for k, v in synth_state_dict(cfg, seed=0, std=0.05).items()}
+    ids, mask, labels = (torch.from_numpy(gl[k]) for k in ("input_ids", "attention_mask", "labels"))
+    with torch.enable_grad():
+        out = O.forward_loss(sd, cfg, ids, mask, labels)
+        out[0].backward()
+    assert abs(float(out[0].detach()) - float(g["loss"])) < 1e-6
+    for k in [k[2:] for k in g if k.startswith("g.") and k[2:] in sd and not k.endswith("embeddings.weight")]:
+        want = torch.from_numpy(g["g." + k])
+        assert float((sd[k].grad - want).norm() / want.norm()) < 1e-5, k
+    for name, want in zip(g["norm_names"], g["norms"]):
+        assert abs(float(sd[str(name)].grad.double().norm()) - float(want)) < 1e-4 * float(want), name   # fixture norms are fp32 sums
