@@ -155,7 +155,7 @@ struct csm_engine {
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
-  int gemm_dma = 1, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): on for launches of up to 4096 rows
+  int gemm_dma = 5, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): bit 0 one plane, bit 2 three planes (exact), launches of up to 4096 rows
   // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
   // the quantised-activation scratch [max_prefill_rows][widest K] + scales
   std::unordered_map<const void*, void*> train_wT;   // transposed weight copies of the training backward (train_impl.inc)

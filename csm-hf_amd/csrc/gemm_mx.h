@@ -272,11 +272,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
 // bitwise that of gemm_bf16x3_kernel<NPL = 1> and gemm_wide_kernel (test_csm1b_prefill_precision_bf16).
 // Both operands arrive by LDS-DMA from ROW-MAJOR memory: no fragment-order weight copy is needed (gemm_wide_kernel's +1.9 GB).
 typedef __attribute__((ext_vector_type(8))) short dma_bf16x8;
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
+// NPL = activation planes: 1 (prefill_precision = bf16) or 3 (exact mode: planes hi | mid | lo a_plane_stride apart, every
+// weight fragment multiplied by lo, mid, hi in that order -- small terms first, like gemm_bf16x3_kernel).  With three planes a
+// stage is 64 KiB (one workgroup per CU), a k-step is 96 MFMAs per wave against 32 KB of operand reads: matrix-pipe bound,
+// where the one-plane form (32 MFMAs, 16 KB) sits at the LDS port's limit.
+template <int EPI, int NPL>
+__global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(GemmArgs a) {
   constexpr int BM = 128, BN = 128, BKB = 128, BKE = 64;   // k-step: 128 bytes = 64 elements
-  constexpr int TILE = BM * BKB, STAGE = 2 * TILE;
-  extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A tile | W tile]
+  constexpr int TILE = BM * BKB, STAGE = (NPL + 1) * TILE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A planes | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int j16 = lane & 15, g = lane >> 4;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
   const int nk = kspan / BKE;
   const uint8_t* Ab = reinterpret_cast<const uint8_t*>(a.Aplanes);
   const uint8_t* Wb = reinterpret_cast<const uint8_t*>(a.W);
-  const size_t rowb = (size_t)a.K * 2;
+  const size_t rowb = (size_t)a.K * 2, psb = a.a_plane_stride * 2;
   const uint8_t* asrc[4];
   const uint8_t* wsrc[4];
 #pragma unroll
@@ -310,13 +314,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
   auto issue = [&](int ks, int st) {
     uint8_t* base = mx_lds + st * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)ks * BKB),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + p * psb + (size_t)ks * BKB),
+                                         (__attribute__((address_space(3))) void*)(base + p * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BKB),
-                                       (__attribute__((address_space(3))) void*)(base + TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + NPL * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
   };
   f32x4 acc[4][4];
 #pragma unroll
@@ -332,28 +338,36 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
     const int st = ks & 1;
     if (ks + 1 < nk) {
       issue(ks + 1, st ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // 8 DMA instructions per wave and stage
+      if (NPL == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // 4 (NPL + 1) DMA instructions per wave and stage stay in flight
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     const uint8_t* At = mx_lds + st * STAGE;
-    const uint8_t* Wt = At + TILE;
-    dma_bf16x8 af[4][2], wf[4][2];
+    const uint8_t* Wt = At + NPL * TILE;
+    dma_bf16x8 wf[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      *reinterpret_cast<u32x4*>(&af[t][0]) = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BKB + c0);
-      *reinterpret_cast<u32x4*>(&af[t][1]) = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BKB + c1);
       *reinterpret_cast<u32x4*>(&wf[t][0]) = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BKB + c0);
       *reinterpret_cast<u32x4*>(&wf[t][1]) = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BKB + c1);
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int ri = 0; ri < 4; ++ri) {
+      dma_bf16x8 af[NPL][2];
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri)
+      for (int p = 0; p < NPL; ++p) {
+        *reinterpret_cast<u32x4*>(&af[p][0]) = *reinterpret_cast<const u32x4*>(At + p * TILE + arow0 + ri * 16 * BKB + c0);
+        *reinterpret_cast<u32x4*>(&af[p][1]) = *reinterpret_cast<const u32x4*>(At + p * TILE + arow0 + ri * 16 * BKB + c1);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[ri][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][s2], af[ri][s2], acc[ri][ni], 0, 0, 0);
+#pragma unroll
+          for (int p = NPL - 1; p >= 0; --p)   // lo, mid, hi: small terms first
+            acc[ri][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][s2], af[p][s2], acc[ri][ni], 0, 0, 0);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -367,8 +381,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_bf16_kernel(GemmArgs a) {
       f32x4 v = acc[ri][ni];
       if (EPI == GEPI_SWIGLU) {
         const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
-        if (a.Cplanes) {   // one bf16 plane (c_plane_stride == 0: checked by the launcher)
+        if (a.Cplanes && NPL == 1) {   // one bf16 plane
           *reinterpret_cast<uint32_t*>(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1)) = (uint32_t)f32_to_bf16(h0) | ((uint32_t)f32_to_bf16(h1) << 16);
+        } else if (a.Cplanes) {        // three exact planes for the down_proj GEMM
+          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1), a.c_plane_stride, h0);
+          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1) + 1, a.c_plane_stride, h1);
         } else {
           *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
         }

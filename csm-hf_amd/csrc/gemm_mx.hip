@@ -41,23 +41,37 @@ int launch_mx_quant(hipStream_t st, const MxQuantArgs& a) {
   return (int)hipGetLastError();
 }
 
-template <int EPI>
+template <int EPI, int NPL>
 static int launch_dma_epi(hipStream_t st, const dim3& grid, const GemmArgs& a) {
-  constexpr size_t lds = 2 * (2 * 128 * 128);   // two stages of (A tile | W tile) = 64 KiB
-  hipLaunchKernelGGL(gemm_dma_bf16_kernel<EPI>, grid, dim3(256), lds, st, a);
+  constexpr size_t lds = 2 * ((NPL + 1) * 128 * 128);   // two stages of (A planes | W tile): 64 KiB (one plane) / 128 KiB (three)
+  auto fn = gemm_dma_bf16_kernel<EPI, NPL>;
+  if (lds > 64 * 1024) {   // raise the dynamic-LDS limit once per DEVICE
+    static unsigned long long configured = 0ull;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      configured |= bit;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
 int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
-  if (!a.Aplanes || a.a_plane_stride != 0 || !a.W || a.wscale || a.R < 1 || a.N % 128 || a.K % 64 || a.ldc % 4) return -2;
-  if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return -2;
+  if (!a.Aplanes || !a.W || a.wscale || a.R < 1 || a.N % 128 || a.K % 64 || a.ldc % 4) return -2;
+  const bool exact = a.a_plane_stride != 0;
+  if (epi == GEPI_SWIGLU && a.Cplanes && (a.c_plane_stride != 0) != exact) return -2;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (ks < 1 || a.K % (64 * ks) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
   const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
+#define DMA_EPI(E) return exact ? launch_dma_epi<E, 3>(st, grid, a) : launch_dma_epi<E, 1>(st, grid, a)
   switch (epi) {
-    case GEPI_STORE: return launch_dma_epi<GEPI_STORE>(st, grid, a);
-    case GEPI_RESID: return launch_dma_epi<GEPI_RESID>(st, grid, a);
-    case GEPI_SWIGLU: return launch_dma_epi<GEPI_SWIGLU>(st, grid, a);
-    case GEPI_PARTIAL: return launch_dma_epi<GEPI_PARTIAL>(st, grid, a);
+    case GEPI_STORE: DMA_EPI(GEPI_STORE);
+    case GEPI_RESID: DMA_EPI(GEPI_RESID);
+    case GEPI_SWIGLU: DMA_EPI(GEPI_SWIGLU);
+    case GEPI_PARTIAL: DMA_EPI(GEPI_PARTIAL);
     default: return -1;
   }
+#undef DMA_EPI
 }
