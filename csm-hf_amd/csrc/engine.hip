@@ -464,7 +464,10 @@ static int build_tiled(csm_engine* e) {
   if (!e->tile_weights || e->cfg.weight_dtype == CSM_DTYPE_F32) return 0;
   // the batched decode kernels (gemm16 / gemm32) stream every matrix from its copy; a one-sequence engine only needs the
   // backbone's, for the wide prefill GEMM (gemm_wide_kernel), and only when its prefills can be large enough to use it
-  const bool decode_tiles = e->cfg.max_batch >= 2, prefill_tiles = e->cfg.max_prefill_rows >= 512;
+  // (round 3: bf16 prefills of up to gemm_dma_max_rows rows run on the LDS-DMA GEMM, which reads the ROW-MAJOR weights -- a
+  // one-sequence bf16 engine then needs no copy at all: -1.9 GB for csm-1b; fp8 weights still take the wide tile)
+  const bool dma_covers = e->cfg.weight_dtype == CSM_DTYPE_BF16 && (e->gemm_dma & 1) && e->cfg.max_prefill_rows <= e->gemm_dma_max_rows;
+  const bool decode_tiles = e->cfg.max_batch >= 2, prefill_tiles = e->cfg.max_prefill_rows >= 512 && !dma_covers;
   if (!decode_tiles && !prefill_tiles) return 0;
   for (Stack* s : {&e->bb, &e->dec}) {
     if (s == &e->dec && !decode_tiles) continue;

@@ -146,7 +146,28 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
   float* o = out + (size_t)row * ldo;
   if (frame_ptr) o += (size_t)(*frame_ptr + frame_add) * frame_stride;
   float ss = 0.f;
-  for (int k = tid * 4; k < H; k += 1024) {
+  // the row stays in registers between the two passes (round 3: one read of x instead of two; rows wider than 8192 re-read)
+  constexpr int KEEP = 8;
+  f32x4 keep[KEEP];
+#pragma unroll
+  for (int it = 0; it < KEEP; ++it) {
+    const int k = tid * 4 + it * 1024;
+    keep[it] = (f32x4)(0.f);
+    if (k < H) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+      if (part) {
+        const float* pr = part + (size_t)row * ldp + k;
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(pr + (size_t)sp * part_stride);
+          v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        }
+        *reinterpret_cast<f32x4*>(const_cast<float*>(xr) + k) = v;
+      }
+      keep[it] = v;
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+  }
+  for (int k = tid * 4 + KEEP * 1024; k < H; k += 1024) {
     f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
     if (part) {
       const float* pr = part + (size_t)row * ldp + k;
@@ -162,8 +183,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   const float sc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
-  for (int k = tid * 4; k < H; k += 1024) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
+  auto emit = [&](int k, f32x4 v) {
     const f32x4 g = *reinterpret_cast<const f32x4*>(w + k);
     v[0] = (v[0] * sc) * g[0];
     v[1] = (v[1] * sc) * g[1];
@@ -184,7 +204,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
       if ((tid & 7) == 0) mxs[(size_t)row * (H >> 5) + (k >> 5)] = (uint8_t)eb;
     } else if (planes) store_rowplanes4(planes + (size_t)row * H + k, plane_stride, v);
     else *reinterpret_cast<f32x4*>(o + k) = v;
+  };
+#pragma unroll
+  for (int it = 0; it < KEEP; ++it) {
+    const int k = tid * 4 + it * 1024;
+    if (k < H) emit(k, keep[it]);
   }
+  for (int k = tid * 4 + KEEP * 1024; k < H; k += 1024) emit(k, *reinterpret_cast<const f32x4*>(xr + k));
 }
 
 #endif  // CSM_ARGS_ONLY
