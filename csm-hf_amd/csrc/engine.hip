@@ -229,6 +229,8 @@ struct csm_engine {
   float* pl_ss = nullptr;
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
+  int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
+  int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
@@ -562,6 +564,8 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
+  else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
+  else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
@@ -691,6 +695,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   // nt: 0 = plain loads, 1 = every matrix non-temporal, 2 = only the large streams (gate/up, down) non-temporal so
   // that the small per-pass matrices (qkv, o) can stay in the XCD-local L2 between decoder passes
   const int nt_small = nt == 1, nt_big = nt >= 1;
+  const int sk = (&s == &e->dec) ? e->dbg_skip & 0xff : (e->dbg_skip >> 8) & 0xff;
   GemvArgs a{};
   a.nt = nt_small;
   a.W = w.wqkv; a.wscale = w.sqkv; a.N = s.nqkv(); a.K = H; a.x = h; a.ldx = ldh; a.ln = w.ln1; a.eps = s.c.rms_eps;
@@ -703,7 +708,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     a.tok_forced = tok->tok_forced; a.tok_ring = tok->tok_ring; a.tok_frame_ptr = tok->tok_frame_ptr;
     a.tok_max_frames = tok->tok_max_frames; a.tok_C = tok->tok_C; a.tok_cb = tok->tok_cb; a.tok_x_out = h;
     LCK(gemv_rows(e, M, PRO_TOKNORM, EPI_QKV, a));
-  } else {
+  } else if (!(sk & 1)) {
     LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
   }
   if (kv_only) return 0;  // this position's hidden state is never read again: only its K/V had to be appended
@@ -745,11 +750,11 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)
     const bool att_planes = planes && (e->use_planes & 4);
     t.oplanes = att_planes ? e->pl_act : nullptr;
-    LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
+    if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
     if (att_planes) o.xplanes = e->pl_act;
     if (planes) { o.oplanes = e->pl_h; o.oln = w.ln2; o.oss = e->pl_ss; o.oss_ld = PL_SS_LD; }
-    LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
+    if (!(sk & 4)) LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, o));
   }
 
   GemvArgs g{};
@@ -761,14 +766,15 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   }
   const bool act_planes = planes && (e->use_planes & 2);   // A/B: bit 1 = SwiGLU output handed over as planes too
   if (planes) { g.xplanes = e->pl_h; g.xss = e->pl_ss; g.xss_n = H / 16; g.xss_ld = PL_SS_LD; g.oplanes = act_planes ? e->pl_act : nullptr; }
-  LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
+  if (!(sk & 8)) LCK(gemv_rows(e, M, PRO_NORM, EPI_SWIGLU, g));
 
   GemvArgs d{};
   d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
   if (e->g16_down) { d.g16_nw = e->g16_down & 0xff; d.g16_kb = (e->g16_down >> 8) & 0xff; d.g16_pt = (e->g16_down >> 16) & 0xff; }
+  d.g16_slab = e->g16_slab;
   if (planes) { d.xplanes = act_planes ? e->pl_act : nullptr; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
-  LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
+  if (!(sk & 16)) LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
 }
 

@@ -86,6 +86,7 @@ struct GemvArgs {
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
+  int g16_slab;  // split-K slab exchange of the MFMA kernel: 0 = write-through (sc1) stores + sc1 loads, 1 = plain stores + sc1 loads, 2 = plain both (A/B)
   // weight streamer (prefetch.h): launches-started counter bumped by workgroup 0 (nullable), and a host-side slot
   // the launcher fills with this launch's workgroup -> rows geometry
   unsigned* prog;

@@ -479,10 +479,12 @@ class CSMModel(nn.Module):
     @torch.no_grad()
     def generate_frame(self, input_ids, attention_mask, position_ids=None, temperature=1.0, topk=50,
                        past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
-                       return_dict=None, *, noise: Optional[torch.Tensor] = None):
+                       return_dict=None, *, noise: Optional[torch.Tensor] = None, rng: Optional[str] = None):
         """reference :484-589.  `noise` (extension) `[B, 32, V]`: explicit Exp(1) draws that replace the device RNG -- the
         reference's `torch.empty_like(probs).exponential_(1)` (:175) made reproducible: with the reference's own draws the
-        sampled tokens are the reference's."""
+        sampled tokens are the reference's.  `rng="torch"` (extension): the draws are taken from torch's GLOBAL generator
+        exactly as the reference takes them (`_torch_rng_noise`), so `torch.manual_seed(s)` reproduces the reference's
+        sampled frames."""
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         use_cache = use_cache if use_cache is not None else self._using_kv_cache
         out = self.forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
@@ -492,6 +494,8 @@ class CSMModel(nn.Module):
             # every frame of this path has already been handed to the caller (the reference keeps none either,
             # :578-589): restart the on-device ring instead of limiting a stream to max_frames frames
             eng.rewind_frames()
+        if noise is None and rng is not None:
+            noise = self._torch_rng_noise(rng, eng.batch)
         nz = None if noise is None else self._check_noise(noise, eng.batch).to(eng.device, torch.float32).contiguous()
         s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed(), row_offset=self.row_offset, noise=nz)
         eng.decode_frame(s)
@@ -503,6 +507,19 @@ class CSMModel(nn.Module):
         if not return_dict:
             return tokens
         return CSMOutput(last_hidden_state=out.last_hidden_state, logits=out.logits, past_key_values=pkv, samples=tokens)
+
+    def _torch_rng_noise(self, rng: str, B: int) -> torch.Tensor:
+        """One frame's Exp(1) draws `[B, 32, V]` consumed from torch's global generator the way the reference consumes it:
+        32 calls of `torch.empty_like(probs).exponential_(1)` on a `[B, V]` tensor in codebook order
+        (/root/reference/modeling_csm.py:170-176, called from :531 and :558-576).  `self.rng_device` ("cpu" by default: the
+        generator a CPU run of the reference uses; set it to the model's device for the reference's GPU stream) and
+        `self.rng_dtype` (the dtype of the reference's `probs`: its compute dtype) select the generator and the draw type."""
+        if rng != "torch":
+            raise ValueError("rng must be None (device Philox stream) or 'torch' (torch's global generator, as the reference)")
+        C, V = self.config.audio_num_codebooks, self.config.audio_vocab_size
+        dev = getattr(self, "rng_device", "cpu")
+        dt = getattr(self, "rng_dtype", torch.float32)
+        return torch.stack([torch.empty(B, V, dtype=dt, device=dev).exponential_(1) for _ in range(C)], 1).float()
 
     def _check_noise(self, noise: torch.Tensor, B: int) -> torch.Tensor:
         want = (B, self.config.audio_num_codebooks, self.config.audio_vocab_size)
@@ -517,13 +534,16 @@ class CSMModel(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: int = 100,
                  temperature: float = 1.0, topk: int = 50, use_cache: bool = True, stop_on_all_zeros: bool = True,
-                 *, seed: Optional[int] = None, per_row_stop: bool = False, noise: Optional[torch.Tensor] = None):
+                 *, seed: Optional[int] = None, per_row_stop: bool = False, noise: Optional[torch.Tensor] = None,
+                 rng: Optional[str] = None):
         """reference :591-702.  Returns LongTensor `[B, n, 32]` on `input_ids.device`.  `seed` (extension, default: drawn
         from torch's seed and a call counter) keys the device Philox stream of the sampler.  `per_row_stop` (extension,
         SURVEY.md section 8 f-4): a row that has emitted an all-zero frame is frozen (emits zeros from then on), generation
         ends when the last row has finished, `self.last_row_lengths` holds every row's own frame count; the default keeps
         the reference's global rule (:662: stop when ALL rows emit an all-zero frame in the same step).  `noise`
         (extension) `[max_new_frames, B, 32, V]`: explicit Exp(1) draws instead of the device RNG (see generate_frame).
+        `rng="torch"` (extension): every frame's draws come from torch's global generator in the reference's order and
+        shapes, so the sampled frames are the reference's under the same `torch.manual_seed` (one launch per frame).
 
         One prefill, then per frame one replay of the captured hipGraph (31-step decoder loop + next
         backbone step).  With `stop_on_all_zeros` the host checks each frame (one sync per frame, like the
@@ -541,12 +561,14 @@ class CSMModel(nn.Module):
         s = eng.sampling(temperature=temperature, topk=topk, seed=self._next_seed() if seed is None else int(seed),
                          row_offset=self.row_offset, per_row_stop=per_row_stop and stop_on_all_zeros)
         n = 0
-        if noise is not None:
+        if noise is not None or rng is not None:
             # one frame per launch: the engine takes one [B, 32, V] block of draws per call
-            if noise.shape[0] < max_new_frames:
+            if noise is not None and noise.shape[0] < max_new_frames:
                 raise ValueError("noise holds fewer frames than max_new_frames")
             while n < max_new_frames:
-                nz = self._check_noise(noise[n], B).to(eng.device, torch.float32).contiguous()
+                # rng: drawn frame by frame, so a run that stops early has consumed what the reference has consumed
+                fr = noise[n] if noise is not None else self._torch_rng_noise(rng, B)
+                nz = self._check_noise(fr, B).to(eng.device, torch.float32).contiguous()
                 s.noise = nz.data_ptr()
                 eng.generate(s, 1, self.use_graph)
                 eng.sync()

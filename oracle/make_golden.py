@@ -3,7 +3,7 @@
 Runs only in the build container (needs /root/reference and `transformers`); the reference never
 travels to the GPU box -- only the small .npz fixtures written here do.  Usage:
 
-    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss,grad] [--frames2 200]
+    python oracle/make_golden.py [--only tiny,sampler,processor,cfg1,prefill512,cfg2,b4,b4noise,loss,grad,grad1b,rng,rng1b] [--frames2 200]
 
 What it does
   * imports /root/reference/modeling_csm.py unmodified;
@@ -218,6 +218,24 @@ def gen_tiny():
                             attention_mask=mask_p.numpy(), tokens=torch.cat(solo, 0).numpy(),
                             pad=np.int32(pad))
         print("[golden] tiny_padded, tiny_fp32_hidden written", flush=True)
+
+
+def gen_rng():
+    """Top-k sampling from torch's GLOBAL generator, exactly as the unmodified reference draws (modeling_csm.py:170-176):
+    `run_case` seeds it (torch.manual_seed(1234)) right before `generate`; the fixture pins the sampled frames."""
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    ids, mask = synth_context(cfg, 2, 4, 6, seed=5)
+    run_case("tiny_rng_topk5", cfg, sd, torch.float32, ids, mask, 6, full_logits=True, topk=5, temperature=0.9,
+             extra=dict(torch_seed=np.int64(1234), topk=np.int32(5), temperature=np.float32(0.9)))
+
+
+def gen_rng_1b():
+    cfg = CSMConfig()
+    sdb = synth_state_dict(cfg, seed=0, bf16_representable=True)
+    ids, mask = synth_context(cfg, 1, 16, 48, seed=1)
+    run_case("csm1b_rng_topk50_bf16w_fp32", cfg, sdb, torch.float32, ids, mask, 3, topn_keep=2, topk=50, temperature=0.9,
+             extra=dict(torch_seed=np.int64(1234), topk=np.int32(50), temperature=np.float32(0.9)))
 
 
 def gen_sampler():
@@ -448,6 +466,10 @@ def main():
         gen_grad()
     if "grad1b" in which:
         gen_grad_1b()
+    if "rng" in which:
+        gen_rng()
+    if "rng1b" in which:
+        gen_rng_1b()
 
 
 if __name__ == "__main__":

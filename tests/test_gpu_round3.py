@@ -483,3 +483,90 @@ def test_training_backward_csm1b_vs_reference_gradient_norms():
     m._drop_engine()
     del m, grads
     torch.cuda.empty_cache()
+
+
+# ---- torch-generator-compatible sampling (VERDICT r2 "missing 5"; reference modeling_csm.py:170-176) ----------------------
+def _race_margins(g, n, B, C, V, topk, T, seed):
+    """relative margin of every exponential race of the fixture (reference logits + the same draws): a draw whose two best
+    candidates are closer than the engine's fp32 summation-order noise may legitimately resolve the other way"""
+    torch.manual_seed(seed)
+    lg = torch.from_numpy(g["logits"])                              # [n, B, C, V]
+    out = torch.zeros(n, B, C)
+    for f in range(n):
+        for c in range(C):
+            x = lg[f, :, c] / T
+            kth = torch.topk(x, topk)[0][..., -1, None]
+            p = torch.softmax(torch.log_softmax(x.masked_fill(x < kth, -float("inf")), -1), -1)
+            r = p / torch.empty_like(p).exponential_(1)
+            t2 = torch.topk(r, 2, -1)[0]
+            out[f, :, c] = (t2[:, 0] - t2[:, 1]) / t2[:, 0]
+    return out.permute(1, 0, 2)                                      # [B, n, C]
+
+
+def test_sampling_from_torchs_global_generator_matches_the_reference(gold):
+    """`generate(rng="torch")` / `generate_frame(rng="torch")`: the Exp(1) draws come from torch's global (CPU) generator in the
+    reference's order and shapes, so after the same torch.manual_seed the SAMPLED frames are the unmodified reference's
+    (fixture tiny_rng_topk5: top-k 5, T = 0.9, two rows, six frames).  The device Philox stream stays the default."""
+    cfg, sd, model = tiny_model()
+    g = gold("tiny_rng_topk5")
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    seed, topk, T = int(g["torch_seed"]), int(g["topk"]), float(g["temperature"])
+    want = torch.from_numpy(g["tokens"])
+    B, n, C = want.shape
+    margins = _race_margins(g, n, B, C, cfg.audio_vocab_size, topk, T, seed)
+    torch.manual_seed(seed)
+    got = model.generate(ids.to(DEV), mask.to(DEV), max_new_frames=n, temperature=T, topk=topk, stop_on_all_zeros=False,
+                         rng="torch").cpu()
+    for b in range(B):
+        assert_margin_equal(got[b].reshape(-1), want[b].reshape(-1), margins[b].reshape(-1), 1e-4, f"row {b}")
+    assert float(margins.min()) > 1e-4 and torch.equal(got, want)    # this fixture has no close race: all 384 draws equal
+    # the frame-by-frame API consumes the generator the same way (reference :484-589 called in a loop, as generate does)
+    torch.manual_seed(seed)
+    model.setup_caches(B)
+    fi, fm, pkv, frames = ids.to(DEV), mask.to(DEV), None, []
+    for _ in range(n):
+        o = model.generate_frame(fi, fm, temperature=T, topk=topk, past_key_values=pkv, use_cache=True, return_dict=True,
+                                 rng="torch")
+        frames.append(o.samples.cpu())
+        pkv = o.past_key_values
+        row = torch.cat([o.samples, torch.zeros(B, 1, dtype=torch.long, device=DEV)], 1).unsqueeze(1)
+        m1 = torch.zeros(B, 1, C + 1, dtype=fm.dtype, device=DEV)
+        m1[:, :, :C] = 1
+        fi, fm = row, m1
+    assert torch.equal(torch.stack(frames, 1), want)
+    # a different seed gives different frames; the default (device Philox) does not touch torch's generator
+    torch.manual_seed(seed + 1)
+    other = model.generate(ids.to(DEV), mask.to(DEV), max_new_frames=n, temperature=T, topk=topk, stop_on_all_zeros=False,
+                           rng="torch").cpu()
+    assert not torch.equal(other, want)
+    torch.manual_seed(seed)
+    a = torch.rand(4)
+    torch.manual_seed(seed)
+    model.generate(ids.to(DEV), mask.to(DEV), max_new_frames=2, temperature=T, topk=topk, stop_on_all_zeros=False, seed=3)
+    assert torch.equal(torch.rand(4), a)
+    with pytest.raises(ValueError):
+        model.generate(ids.to(DEV), mask.to(DEV), max_new_frames=1, rng="numpy")
+
+
+def test_sampling_from_torchs_global_generator_csm1b(gold):
+    """the same at full size: csm-1b (bf16-representable weights, the reference computing in fp32), 64-frame context, top-k 50,
+    T = 0.9, three frames under torch.manual_seed(1234) -- fixture csm1b_rng_topk50_bf16w_fp32."""
+    g = gold("csm1b_rng_topk50_bf16w_fp32")
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, bf16_representable=True)
+    model = CSMModel(cfg)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()})
+    del sd
+    model = model.to(DEV).eval()
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    want = torch.from_numpy(g["tokens"])
+    n = want.shape[1]
+    torch.manual_seed(int(g["torch_seed"]))
+    got = model.generate(ids.to(DEV), mask.to(DEV), max_new_frames=n, temperature=float(g["temperature"]),
+                         topk=int(g["topk"]), stop_on_all_zeros=False, rng="torch").cpu()
+    # 96 races; the engine's logits sit ~1e-5 from the reference's, so a flip needs a race closer than that: equal up to the
+    # first differing draw is required to cover at least the first frame, and in practice everything is equal
+    diff = (got != want).reshape(-1).nonzero()
+    first = int(diff[0]) if diff.numel() else got.numel()
+    assert first >= 32, f"first differing draw at {first}"
+    assert first == got.numel(), f"draw {first} differs (a race closer than the fp32 noise?)"

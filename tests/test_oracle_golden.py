@@ -152,3 +152,20 @@ def test_oracle_autograd_vs_reference_gradients(gold):
         assert float((sd[k].grad - want).norm() / want.norm()) < 1e-5, k
     for name, want in zip(g["norm_names"], g["norms"]):
         assert abs(float(sd[str(name)].grad.double().norm()) - float(want)) < 1e-4 * float(want), name   # fixture norms are fp32 sums
+
+
+def test_oracle_topk_sampling_from_the_global_torch_generator(gold):
+    """VERDICT r2 'missing 5': the reference draws its Exp(1) race noise from torch's GLOBAL generator
+    (/root/reference/modeling_csm.py:170-176).  Fixture `tiny_rng_topk5` = the unmodified reference's generate() at
+    top-k 5, T = 0.9 after torch.manual_seed(1234); the oracle under the same seed gives the same frames, bit for bit."""
+    cfg = CSMConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0, std=0.05)
+    g = gold("tiny_rng_topk5")
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    torch.manual_seed(int(g["torch_seed"]))
+    toks = O.generate(sd, cfg, ids, mask, max_new_frames=6, temperature=float(g["temperature"]), topk=int(g["topk"]),
+                      stop_on_all_zeros=False)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    # the draws really decide: greedy frames differ from the sampled ones
+    greedy = O.generate(sd, cfg, ids, mask, max_new_frames=6, temperature=1.0, topk=1, stop_on_all_zeros=False)
+    assert not np.array_equal(greedy.numpy(), g["tokens"])

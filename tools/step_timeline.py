@@ -40,3 +40,14 @@ if "--dump" in sys.argv:
     t0 = step[0][0]
     for s, e, name, gx, gyv, wgx in step[:n]:
         print(f"{(s - t0)/1e3:9.2f} {(e - s)/1e3:7.2f}  {name.split('(')[0][:60]}  {gx},{gyv}/{wgx}")
+if "--gaps" in sys.argv:
+    # every boundary of the LAST FOUR steps whose end -> next-start gap exceeds T us: position in the step, the two kernels
+    thr = float(sys.argv[sys.argv.index("--gaps") + 1])
+    print(f"\nboundaries with a gap above {thr} us (step, index in step, gap us, kernel that ended -> kernel that started):\n")
+    for si in range(max(0, len(idx) - 5), len(idx) - 1):
+        st = ks[idx[si]:idx[si + 1] + 1]
+        for i in range(len(st) - 1):
+            g = (st[i + 1][0] - st[i][1]) / 1e3
+            if g > thr:
+                print(f"step {si:3d} #{i:4d} gap {g:8.2f}  {st[i][2].split('(')[0][:58]} {st[i][3]}/{st[i][5]} -> "
+                      f"{st[i + 1][2].split('(')[0][:58]} {st[i + 1][3]}/{st[i + 1][5]}")
