@@ -32,13 +32,15 @@ struct AttnArgs {
   float* out;   // [rows][n_q*hd]                  (nsplit == 1)
   float* part;  // [rows][n_q][nsplit][hd+4]       (nsplit > 1): acc[hd], m, l, pad
   bf16_t* oplanes;  // nullable: the output also as MFMA B-operand planes for a batched o_proj (rows <= 16)
+  int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
 };
 
 #ifndef CSM_ARGS_ONLY
 #include "attn_tile.h"
 
 // HD = head_dim (64 or 128).  One workgroup = (row, kv-head, split); wave g handles query head j*G+g.
-template <typename KT, int HD>
+// PF = second register set: the next tile is in flight while the current one is consumed.
+template <typename KT, int HD, bool PF = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   using Tile = AttnTile32<KT, HD>;
   __shared__ __attribute__((aligned(16))) float qs[16 * HD];  // up to 16 q-heads per kv-head
@@ -79,10 +81,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     __builtin_amdgcn_wave_barrier();
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 acc = (f32x4)(0.f);
-    for (int t0 = t_lo; t0 < t_hi; t0 += 32) {
-      const int cnt = min(32, t_hi - t0);
-      if (t0 != t_lo || g != g0) tile.load(kc, vc, a.lmax, t0, cnt, lane);
-      tile.accumulate(qs + g * HD, pb[wave], cnt, lane, m_run, l_run, acc);
+    if constexpr (PF) {
+      // the NEXT tile is requested before this one is consumed (second register set): a workgroup that walks several
+      // tiles pays one memory latency, not one per tile (B = 16 backbone, 3 tiles per split: DESIGN.md section 5)
+      if (g != g0 && t_lo < t_hi) tile.load(kc, vc, a.lmax, t_lo, min(32, t_hi - t_lo), lane);
+      for (int t0 = t_lo; t0 < t_hi; t0 += 32) {
+        const int cnt = min(32, t_hi - t0);
+        Tile nxt;
+        const bool more = t0 + 32 < t_hi;
+        if (more) nxt.load(kc, vc, a.lmax, t0 + 32, min(32, t_hi - t0 - 32), lane);
+        tile.accumulate(qs + g * HD, pb[wave], cnt, lane, m_run, l_run, acc);
+        if (more) tile = nxt;
+      }
+    } else {
+      for (int t0 = t_lo; t0 < t_hi; t0 += 32) {
+        const int cnt = min(32, t_hi - t0);
+        if (t0 != t_lo || g != g0) tile.load(kc, vc, a.lmax, t0, cnt, lane);
+        tile.accumulate(qs + g * HD, pb[wave], cnt, lane, m_run, l_run, acc);
+      }
     }
     acc = Tile::reduce(acc);
     const int h = j * G + g;

@@ -155,6 +155,9 @@ struct csm_engine {
   int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
   int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
+  int gemm_256 = 256;   // gemm256_kernel (256 x 256 tile): minimum workgroup count (tiles x K splits) of a launch it takes (one per CU); 0 = off;
+                        // bits 24-25 select a schedule variant (A/B).  csm-1b prefill, bf16 / mxfp8: 2048 frames 6.50 / 5.07 -> 5.86 / 4.71 ms,
+                        // 16 x 512 frames 19.7 / 16.0 -> 18.8 / 13.6 ms (profiles/r03_gemm256.txt)
   int gemm_dma = 5, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): bit 0 one plane, bit 2 three planes (exact), launches of up to 4096 rows
   // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
   // the quantised-activation scratch [max_prefill_rows][widest K] + scales
@@ -229,6 +232,7 @@ struct csm_engine {
   float* pl_ss = nullptr;
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
+  int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
   int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
@@ -553,6 +557,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
   else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "gemm_dma")) e->gemm_dma = value;
+  else if (!strcmp(name, "gemm_256")) e->gemm_256 = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_max_rows")) e->gemm_dma_max_rows = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "mx_fuse_swiglu")) e->mx_fuse_swiglu = value;
@@ -566,6 +571,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
   else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
+  else if (!strcmp(name, "attn_prefetch")) e->attn_prefetch = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
@@ -747,6 +753,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
     t.nsplit = nsplit; t.out = att; t.part = part;
     t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
+    t.tile_prefetch = (M == 1 ? e->attn_prefetch & 1 : (e->attn_prefetch >> 1) & 1);
     // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)
     const bool att_planes = planes && (e->use_planes & 4);
     t.oplanes = att_planes ? e->pl_act : nullptr;
@@ -1065,6 +1072,16 @@ static const void* tiled_of(const csm_engine* e, const void* W) {
 }
 
 // K splits of an MX-fp8 prefill GEMM with too few 128 x 128 tiles to fill the chip (k-steps of 128, >= 4 per split)
+// K splits that let the 256 x 256 tile (gemm256.h) take a down_proj launch: enough splits for `min_wgs` workgroups, each split
+// at least 2048 of K; 0 = leave the choice as it is
+static inline int ksplit_256(int R, int N, int K, int cap, int min_wgs, int kstep) {
+  if (min_wgs <= 0 || R % 256 || N % 256 || K < 4096) return 0;
+  const long tiles = (long)(R / 256) * (N / 256);
+  if (tiles >= min_wgs) return 1;
+  const int ks = (int)((min_wgs + tiles - 1) / tiles);
+  return (ks <= cap && K % (kstep * ks) == 0 && K / ks >= 2048) ? ks : 0;
+}
+
 static inline int mx_ksplit(int R, int N, int K, int cap) {
   const long tiles = (long)((R + 127) / 128) * (N / 128);
   if (tiles >= 384) return 1;
@@ -1090,7 +1107,9 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
   }
   const bool can_split = allow_split && e->prefill_splitk && e->p_part && R <= 4096;
   const int cap = (int)std::min<size_t>((size_t)e->prefill_splitk_max, 4 * (size_t)e->cfg.max_prefill_rows / R);
-  const int ks_o = can_split ? mx_ksplit((int)R, H, A, cap) : 1, ks_d = can_split ? mx_ksplit((int)R, H, F, cap) : 1;
+  const int ks_o = can_split ? mx_ksplit((int)R, H, A, cap) : 1;
+  int ks_d = can_split ? mx_ksplit((int)R, H, F, cap) : 1;
+  if (can_split) { const int k256 = ksplit_256((int)R, H, F, cap, e->gemm_256 & 0xffffff, 128); if (k256) ks_d = k256; }
   int ks_q = 1;
   if (can_split && e->prefill_splitk_qkv) {
     const size_t room = 4 * (size_t)e->cfg.max_prefill_rows * (size_t)e->p_part_h / (R * (size_t)NQKV);
@@ -1105,7 +1124,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
   auto gemm = [&](int epi, const uint8_t* Wq, const uint8_t* Ws, int N, int K, float* C, int ldc, int ks, size_t pstride) {
     GemmMxArgs g{};
     g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = Wq; g.Ws = Ws; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
-    g.ksplit = ks; g.Cpart = e->p_part; g.part_stride = pstride;
+    g.ksplit = ks; g.Cpart = e->p_part; g.part_stride = pstride; g.big = e->gemm_256;
     return launch_gemm_mx(e->stream, epi, g);
   };
   int pending = 0;
@@ -1152,13 +1171,14 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
       GemmMxArgs g{};
       g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H; g.C = e->p_act; g.ldc = F;
       if (fq) { g.Cq = e->p_mx_q2; g.Cs = e->p_mx_s2; }
+      g.big = e->gemm_256;
       LCK(launch_gemm_mx(e->stream, GEPI_SWIGLU, g));
     }
     if (!fq) LCK(quant(e->p_act, F));
     {
       GemmMxArgs g{};
       g.Aq = fq ? e->p_mx_q2 : e->p_mx_q; g.As = fq ? e->p_mx_s2 : e->p_mx_s; g.Wq = m.d; g.Ws = m.d_s; g.R = (int)R; g.N = H; g.K = F;
-      g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride;
+      g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride; g.big = e->gemm_256;
       LCK(launch_gemm_mx(e->stream, ks_d > 1 ? GEPI_PARTIAL : GEPI_RESID, g));
       if (ks_d > 1) pending = ks_d;
     }
@@ -1206,6 +1226,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     ks_o = wide_split(nq * hd, ks_o);
     ks_d = wide_split(F, ks_d);
   }
+  if (one && can_split) { const int k256 = ksplit_256((int)R, H, F, ks_cap, e->gemm_256 & 0xffffff, 64); if (k256) ks_d = k256; }
   // QKV: the same K split, its partials summed by the RoPE / cache-append launch that reads the result anyway.  p_part is
   // free between the RMSNorm that folded the previous layer's partials and this layer's o_proj
   int ks_q = 1;
@@ -1223,7 +1244,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows;
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256;
     RopeArgs ra{};
     if (ks_q > 1) {
       g.ksplit = ks_q; g.Cpart = e->p_part; g.part_stride = R * (size_t)s.nqkv();
@@ -1251,7 +1272,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows;
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
     if (att_pl && ks_o > 1) {
       o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
@@ -1265,12 +1286,12 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows;
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256;
     gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows;
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
     if (pl && ks_d > 1) {
       d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
@@ -1974,7 +1995,7 @@ extern "C" int csm_gemm_mx(csm_engine_t* e, const uint8_t* Wq, const uint8_t* Ws
                            int R, float* C) {
   if (!e || !C) return fail(CSM_ERR_ARG, "null argument");
   GemmMxArgs g{};
-  g.Aq = Aq; g.As = As; g.Wq = Wq; g.Ws = Ws; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
+  g.Aq = Aq; g.As = As; g.Wq = Wq; g.Ws = Ws; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N; g.big = e->gemm_256;
   const int r = launch_gemm_mx(e->stream, GEPI_STORE, g);
   if (r == -2) return fail(CSM_ERR_ARG, "csm_gemm_mx covers N %% 128 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
   LCK(r);

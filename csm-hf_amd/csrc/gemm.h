@@ -48,6 +48,9 @@ struct GemmArgs {
   // profiles/r03_prefill.txt): one plane 64 / 512 / 2048 rows 1.68 / 2.78 / 6.80 -> 1.53 / 2.29 / 6.31 ms, 8192 rows 19.6 ->
   // 22.3 ms (gemm_wide_kernel's 128 x 256 tile wins there); three planes 512 / 2048 rows 5.03 / 17.2 -> 4.52 / 16.1 ms
   int dma, dma_max_rows;
+  // gemm256_kernel (gemm256.h: the same staging, 256 x 256 tile, 8 waves): one-plane bf16 launches whose 256 x 256 tiles (x K
+  // splits) number at least big256 (0 = never)
+  int big256;
 };
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64

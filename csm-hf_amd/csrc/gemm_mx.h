@@ -42,6 +42,7 @@ struct GemmMxArgs {
   // quantiser launch.  C is then not written.
   uint8_t* Cq;
   uint8_t* Cs;
+  int big;             // host-side: workgroup count from which the 256 x 256 tile (gemm256.h) takes the launch (0 = never)
 };
 
 // fp32 rows -> MX-fp8: q [rows][K] e4m3 + s [rows][K/32] E8M0, the OCP MX recipe (shared scale 2^(floor(log2(amax)) - 8),

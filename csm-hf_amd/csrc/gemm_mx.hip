@@ -1,7 +1,7 @@
 // Instantiations + launchers of the MX-fp8 prefill GEMM and the row quantiser (gemm_mx.h).
 #include <hip/hip_runtime.h>
 
-#include "gemm_mx.h"
+#include "gemm256.h"
 
 template <int EPI>
 static int launch_mx_epi(hipStream_t st, const dim3& grid, const GemmMxArgs& a) {
@@ -22,6 +22,10 @@ static int launch_mx_epi(hipStream_t st, const dim3& grid, const GemmMxArgs& a) 
 
 int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a) {
   if (a.R < 1 || a.N % 128 || a.K % 128 || !a.Aq || !a.As || !a.Wq || !a.Ws) return -2;
+  if (a.big > 0) {
+    const int r = launch_gemm256_mx(st, epi, a, a.big);
+    if (r != -2) return r;
+  }
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (ks < 1 || a.K % (128 * ks)) return -2;
   const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
@@ -74,4 +78,69 @@ int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
     default: return -1;
   }
 #undef DMA_EPI
+}
+
+// ---- 256 x 256 tile (gemm256.h) ----------------------------------------------------------------------------------------
+template <int EPI, bool MX, int VAR, typename ARGS>
+static int launch_256_var(hipStream_t st, const dim3& grid, const ARGS& a) {
+  constexpr size_t lds = 2 * (2 * 256 * 128 + (MX ? 2 * 256 * 4 : 0));   // two stages: 128 KiB (+ 4 KiB of scales)
+  auto fn = gemm256_kernel<EPI, MX, VAR, ARGS>;
+  static unsigned long long configured = 0ull;   // the dynamic-LDS limit is a per-DEVICE attribute of the function
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(configured & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    configured |= bit;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+// min_wgs: low 24 bits = workgroups (tiles x K splits) a launch must have, bits 24-25 = schedule variant (gemm256.h VAR, A/B).
+// Measured (profiles/r03_gemm256.txt): VAR 1 (weight fragments in halves) is 1-3 % ahead of VAR 0; VAR 2 (DMA pieces spread over
+// the phases, buffer form) wins 5-10 % on single 2048-row GEMMs and LOSES 3-6 % on whole prefills and at 8192 rows.
+static int g256_var = 0;
+template <int EPI, bool MX, typename ARGS>
+static int launch_256_epi(hipStream_t st, const dim3& grid, const ARGS& a) {
+  if (g256_var == 0) return launch_256_var<EPI, MX, 0, ARGS>(st, grid, a);
+  if (g256_var == 1) return launch_256_var<EPI, MX, 1, ARGS>(st, grid, a);
+  return launch_256_var<EPI, MX, 2, ARGS>(st, grid, a);
+}
+
+int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs) {
+  { const int sel = (min_wgs >> 24) & 3; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : 2); }   // bits 24-25: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2 (A/B)
+  min_wgs &= 0xffffff;
+  if (!a.Aplanes || a.a_plane_stride != 0 || !a.W || a.wscale || a.R < 256 || a.R % 256 || a.N % 256 || a.K % 64 || a.ldc % 4) return -2;
+  if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return -2;
+  const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
+  if (ks < 1 || a.K % (64 * ks) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
+  const long tiles = (long)((a.R + 255) / 256) * (a.N / 256);
+  if (tiles * ks < min_wgs) return -2;
+  const dim3 grid((unsigned)tiles, ks);
+  switch (epi) {
+    case GEPI_STORE: return launch_256_epi<GEPI_STORE, false, GemmArgs>(st, grid, a);
+    case GEPI_RESID: return launch_256_epi<GEPI_RESID, false, GemmArgs>(st, grid, a);
+    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, false, GemmArgs>(st, grid, a);
+    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, false, GemmArgs>(st, grid, a);
+    default: return -1;
+  }
+}
+
+int launch_gemm256_mx(hipStream_t st, int epi, const GemmMxArgs& a, int min_wgs) {
+  { const int sel = (min_wgs >> 24) & 3; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : 2); }   // bits 24-25: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2 (A/B)
+  min_wgs &= 0xffffff;
+  if (a.R < 256 || a.R % 256 || a.N % 256 || a.K % 128 || !a.Aq || !a.As || !a.Wq || !a.Ws) return -2;
+  const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
+  if (ks < 1 || a.K % (128 * ks)) return -2;
+  const long tiles = (long)((a.R + 255) / 256) * (a.N / 256);
+  if (tiles * ks < min_wgs) return -2;
+  const dim3 grid((unsigned)tiles, ks);
+  switch (epi) {
+    case GEPI_STORE: return launch_256_epi<GEPI_STORE, true, GemmMxArgs>(st, grid, a);
+    case GEPI_RESID: return launch_256_epi<GEPI_RESID, true, GemmMxArgs>(st, grid, a);
+    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, true, GemmMxArgs>(st, grid, a);
+    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, true, GemmMxArgs>(st, grid, a);
+    default: return -1;
+  }
 }

@@ -16,7 +16,10 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
   const int bd = a.one_wave ? 64 : 256;
   if (a.hd == 64) {
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(bd), 0, st, a);
+    if (a.tile_prefetch) {
+      if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64, true>), dim3(grid), dim3(bd), 0, st, a);
+      else hipLaunchKernelGGL((attn_decode_kernel<float, 64, true>), dim3(grid), dim3(bd), 0, st, a);
+    } else if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(bd), 0, st, a);
     else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(bd), 0, st, a);
   } else if (a.hd == 128) {
     if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(bd), 0, st, a);
@@ -135,8 +138,13 @@ static bool gemm_wide_ok(int epi, const GemmArgs& a) {
 }
 
 int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a);   // gemm_mx.hip
+int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs);   // gemm_mx.hip (gemm256.h)
 template <typename WT>
 static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
+  if (a.big256 > 0 && sizeof(WT) == 2 && a.Aplanes && a.a_plane_stride == 0) {   // enough 256 x 256 tiles to fill the chip
+    const int r = launch_gemm256_bf16(st, epi, a, a.big256);
+    if (r != -2) return r;
+  }
   if (a.dma && sizeof(WT) == 2) {   // bf16 weights, one activation plane: the LDS-DMA tile
     const bool exact = a.a_plane_stride != 0;   // three planes: dma bit 2 (value 4) enables, bit 3 (8) forces
     // (three planes: one 4-wave workgroup per CU -- below ~256 rows the 64 x 64 square tile's many small workgroups win:

@@ -358,6 +358,60 @@ def test_lds_dma_bf16_gemm_is_bitwise_the_square_tile():
     m._drop_engine()
 
 
+def test_gemm256_tile_is_bitwise_the_128_tile_kernels():
+    """gemm256_kernel (csrc/gemm256.h: the LDS-DMA prefill GEMM on a 256 x 256 tile, 8 waves, one barrier per k-step) for
+    `prefill_precision = "bf16"` and "mxfp8".  Both matrix instructions sum their products in ascending k and both tiles
+    walk k in the same steps, so WITHOUT a K split the results are bitwise those of the 128 x 128 kernels -- a staging race
+    (a fragment read before its DMA landed, a stage overwritten too early) shows up as a bit difference.  Checked on the MX
+    kernel alone (STORE epilogue, several shapes, repeated) and through whole csm-1b prefills, which run the STORE (QKV),
+    RESID (o_proj, down_proj), SWIGLU (gate/up: bf16-plane and MX-quantised outputs) and, with the K split on, PARTIAL
+    epilogues."""
+    from csm_hf_amd.engine import Engine
+    from oracle import mx_sim as MX
+    cfg_t = CSMConfig.tiny()
+    eng = Engine(cfg_t, synth_state_dict(cfg_t), DEV, torch.float32, max_batch=1, max_len=64, max_frames=4, max_prefill_rows=128)
+    g = torch.Generator().manual_seed(1)
+    for R, N, K in ((256, 256, 128), (256, 512, 256), (512, 256, 1024), (1024, 768, 2048), (768, 1024, 8192)):
+        A = torch.randn(R, K, generator=g) * torch.exp2(torch.randint(-3, 4, (R, 1), generator=g).float())
+        W = torch.randn(N, K, generator=g) * 0.05
+        aq, as_ = MX.mx_quantize(A)
+        wq, ws = MX.mx_quantize(W)
+        eng.set_option("gemm_256", 0)
+        small = eng.k_gemm_mx(wq, ws, aq, as_).cpu()
+        eng.set_option("gemm_256", 1)
+        for rep in range(3):
+            big = eng.k_gemm_mx(wq, ws, aq, as_).cpu()
+            assert torch.equal(big, small), (R, N, K, rep, float((big - small).abs().max()))
+    eng.close()
+
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
+
+    def run(precision, opts):
+        m.prefill_precision = precision
+        eng = m._ensure_engine(1, 600, 4, 512)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.reset()
+        eng.set_kv_start([0])
+        lh, lg = eng.prefill(ids, mask)
+        return lh.cpu(), lg.cpu()
+    for precision in ("bf16", "mxfp8"):
+        base = run(precision, dict(gemm_256=0, gemm_dma=2, gemm_wide=0, prefill_splitk=0))
+        for rep in range(2):
+            big = run(precision, dict(gemm_256=1, gemm_dma=2, gemm_wide=0, prefill_splitk=0))
+            assert torch.equal(base[0], big[0]) and torch.equal(base[1], big[1]), (precision, rep, float((base[0] - big[0]).abs().max()))
+        split = run(precision, dict(gemm_256=1, gemm_dma=2, gemm_wide=0, prefill_splitk=1))       # PARTIAL epilogue: summation order only
+        ref = run(precision, dict(gemm_256=0, gemm_dma=2, gemm_wide=0, prefill_splitk=1))
+        tol = 5e-2 if precision == "bf16" else 0.3     # a last-bit change re-rounds downstream (bf16) / re-quantises (e4m3)
+        assert float((split[0] - ref[0]).norm() / ref[0].norm()) < tol, precision
+    m._engine.set_option("gemm_256", 0)
+    m._drop_engine()
+
+
 # ---------------------------------------------------------------------------------------------------
 # row f-3: the training BACKWARD pass (csm_forward_backward)
 # ---------------------------------------------------------------------------------------------------
