@@ -233,6 +233,7 @@ struct csm_engine {
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
   int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
+  int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
   int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
@@ -571,6 +572,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
   else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
+  else if (!strcmp(name, "rows64")) e->rows64 = value ? 1 : 0;
   else if (!strcmp(name, "attn_prefetch")) e->attn_prefetch = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
@@ -633,8 +635,9 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     };
     const auto tl = e->tiled.find(a.W);
     a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
-    if (left > 16 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes: one launch, weights streamed once
-      const int m = left < 32 ? left : 32;
+    if (left > 16 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes (33..64 with rows64): one launch, weights streamed once
+      const int cap = (e->rows64 && m0 % 64 == 0 && left > 32) ? 64 : 32;
+      const int m = left < cap ? left : cap;
       slice(m);
       const int r = launch_gemm32(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);

@@ -9,10 +9,14 @@
 #include "gemm16.h"
 
 #ifndef CSM_ARGS_ONLY
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
+// MT = 16-row batch tiles per weight fragment: 2 (17..32 rows) or, round 3, 4 (33..64 rows: one launch and ONE pass over the
+// weights for a 64-row batch instead of two 32-row launches -- B = 64 is launch-bound like every other batch size, so halving
+// its launches is what counts).  With four tiles the B operands of tile mt+1 are requested while tile mt multiplies (two
+// register sets) instead of all up front.
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2>
 __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
-  constexpr int MT = 2, U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][U][256] | panel[U][256] | flag[16] | stat[32]
+  constexpr int U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][U][256] | panel[U][256] | flag[16] | stat[16 MT]
   float* red = lds;
   float* panel = lds + NW * U * 256;
   int* flag = reinterpret_cast<int*>(panel + U * 256);
@@ -50,21 +54,22 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       }
     }
   }
-  // ---- B operands: ready-made planes of both batch tiles, then the weight fragments ------------------------
-  bf16x8 xh[MT][4], xm[MT][4], xl[MT][4];
-  {
-    const size_t ps = (size_t)K * 16;
+  // ---- B operands: ready-made planes (two batch tiles up front; with four: two register sets, tile mt+1 behind tile mt),
+  // then the weight fragments --------------------------------------------------------------------------------
+  constexpr int NB = MT < 2 ? MT : 2;
+  bf16x8 xh[NB][4], xm[NB][4], xl[NB][4];
+  const size_t ps = (size_t)K * 16;
+  auto load_planes = [&](int mt, int buf) {
+    const bf16_t* pp = a.xplanes + (size_t)mt * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const bf16_t* pp = a.xplanes + (size_t)mt * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xh[mt][j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
-        xm[mt][j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
-        xl[mt][j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
-      }
+    for (int j = 0; j < 4; ++j) {
+      xh[buf][j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
+      xm[buf][j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
+      xl[buf][j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
     }
-  }
+  };
+  load_planes(0, 0);
+  if (MT == 2) load_planes(1, 1);
   AFrag<WT> wf[PT][4];
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
@@ -104,16 +109,35 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   for (int t = 0; t < PT; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4)(0.f);
+  if (MT == 2) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      const bf16x8 af = wf[t][j].get();
+      for (int t = 0; t < PT; ++t) {
+        const bf16x8 af = wf[t][j].get();
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt][j], acc[t][mt], 0, 0, 0);  // small terms first
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt][j], acc[t][mt], 0, 0, 0);
-        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt][j], acc[t][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);  // small terms first
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt & 1][j], acc[t][mt], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // per accumulator the same k order as above (j ascending; lo, mid, hi inside a step): a row's result does not depend on
+    // the batch size
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt + 1 < MT) load_planes(mt + 1, (mt + 1) & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const bf16x8 af = wf[t][j].get();
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt & 1][j], acc[t][mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -268,6 +292,6 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
 }
 #endif  // CSM_ARGS_ONLY
 
-// 17..32 rows; needs a.xplanes and a.Wt; returns -2 when the shape is not covered
+// 17..64 rows (two or four batch tiles per weight fragment); needs a.xplanes and a.Wt; returns -2 when the shape is not covered
 int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                   size_t slab_floats, int* tickets, int n_tickets);

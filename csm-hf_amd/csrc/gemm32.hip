@@ -1,24 +1,38 @@
 // Instantiations + launcher of the 32-row MFMA skinny GEMM (gemm32.h).
 #include "gemm32.h"
 
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT>
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT>
 static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
                       int n_tickets) {
-  constexpr int U = PT * 2;
+  constexpr int U = PT * MT;
   int gx;
   if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
   if (KB > 1 && ((size_t)gx * KB * U * 256 > slab_floats || gx > n_tickets)) return -2;
-  const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 32) * sizeof(float);
-  auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT>;
+  const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 16 * MT) * sizeof(float);
+  auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT, MT>;
+  if (lds > 64 * 1024) {   // four batch tiles x two weight tiles: 72 KiB -- raise the dynamic-LDS limit once per DEVICE
+    static unsigned long long configured = 0ull;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+      configured |= bit;
+    }
+  }
   hipLaunchKernelGGL(fn, dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 
 template <typename WT, typename KT, int PRO, int EPI, int PT>
 static int launch_nw32(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
-  if (nw == 8) return launch_g32<WT, KT, PRO, EPI, 8, PT>(st, M, KB, a, slabs, sf, tk, nt);
-  return -2;
+  if (nw != 8) return -2;
+  if (M > 32) {   // 33..64 rows: four batch tiles per weight fragment (panels of at most two weight tiles: LDS, one quad per thread)
+    if (PT > 2) return -2;
+    return launch_g32<WT, KT, PRO, EPI, 8, (PT > 2 ? 2 : PT), 4>(st, M, KB, a, slabs, sf, tk, nt);
+  }
+  return launch_g32<WT, KT, PRO, EPI, 8, PT, 2>(st, M, KB, a, slabs, sf, tk, nt);
 }
 
 template <typename WT>
@@ -43,7 +57,8 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
   const int ntiles = (a.N + 15) / 16;
   if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_nw32<WT, float, PRO_NORM, EPI_SWIGLU, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   if (pro == PRO_PLAIN && epi == EPI_RESID) {
-    if (KB > 1 && ntiles >= 128) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    if (KB > 1 && ntiles >= 128 && M <= 32) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    if (KB > 1 && ntiles >= 128) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
     return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
   if (pro == PRO_NORM && epi == EPI_STORE) return launch_nw32<WT, float, PRO_NORM, EPI_STORE, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
@@ -52,7 +67,7 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
 
 int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                   size_t slab_floats, int* tickets, int n_tickets) {
-  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 32 || !a.xplanes || !a.Wt || a.configure_only) return -2;
+  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 64 || !a.xplanes || !a.Wt || a.configure_only) return -2;
   if (wdtype == 2) return launch_gemm32_t<fp8_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
   return launch_gemm32_t<bf16_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
 }

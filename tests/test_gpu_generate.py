@@ -439,11 +439,11 @@ def test_csm1b_continuous_batching_on_the_matrix_core_path(csm1b_bf16):
     assert compared >= total // 2, (compared, total)
 
 
-@pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (32, {}), (40, {}), (70, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
+@pytest.mark.parametrize("B,opts", [(5, {}), (18, {}), (32, {}), (40, {}), (64, {}), (40, {"rows64": 0}), (70, {}), (16, {"use_planes": 0}), (16, {"tile_weights": 0})])
 def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
     """ragged batches (M < 16 on the matrix-core kernel; 18 and 32 rows = one launch of the 32-row kernel on planes,
-    two 16-row groups where the input is fp32; 40 rows = 32 + 8; 70 rows = 16-row groups without planes) and the A/B paths (no
-    activation planes; row-major weights) against solo runs"""
+    two 16-row groups where the input is fp32; 40 and 64 rows = ONE launch of the four-batch-tile form (round 3; `rows64 = 0`: 32 + 8);
+    70 rows = 16-row groups without planes) and the A/B paths (no activation planes; row-major weights) against solo runs"""
     m = csm1b_bf16
     cfg = m.config
     ids, mask = synth_context(cfg, B, 12, 20, seed=43)
@@ -456,12 +456,30 @@ def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
     finally:
         if m._engine is not None:
             for k in opts:
-                m._engine.set_option(k, {"use_planes": 31, "tile_weights": 1}[k])
+                m._engine.set_option(k, {"use_planes": 31, "tile_weights": 1, "rows64": 1}[k])
     compared = total = 0
-    for b in sorted({0, min(17, B - 1), B - 1}):
+    for b in sorted({0, min(17, B - 1), min(33, B - 1), B - 1}):
         c, t = solo_margin_agree(m, ids[b:b + 1], mask[b:b + 1], full[b], 4)
         compared, total = compared + c, total + t
     assert compared >= total // 2, (compared, total)
+
+
+def test_csm1b_64_row_launch_is_bitwise_two_32_row_launches(csm1b_bf16):
+    """33..64 rows on gemm32_kernel<..., MT = 4> (one launch, one pass over the weights) against two 32-row launches
+    (`rows64 = 0`): every accumulator sums its products in the same order in both forms, so the generated frames are equal
+    bit for bit -- 48 rows (a partial fourth tile) and 64."""
+    m = csm1b_bf16
+    cfg = m.config
+    for B in (48, 64):
+        ids, mask = synth_context(cfg, B, 12, 20, seed=47)
+        outs = []
+        for r64 in (1, 0):
+            m.setup_caches(B)
+            eng = m._ensure_engine(B, 64, 8, B * 32)
+            eng.set_option("rows64", r64)
+            outs.append(m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu())
+        m._engine.set_option("rows64", 1)
+        assert torch.equal(outs[0], outs[1]), B
 
 
 def test_csm1b_config3_batch16_voiceclone_rows_vs_reference(gold, csm1b_bf16):
