@@ -9,7 +9,8 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 : > $O/bench_other_configs.jsonl
 for extra in "--opt weight_prefetch=0" "--opt two_token_pass=0" "--batch 16 --steps 100" "--batch 16 --topk 50 --temperature 1.0 --steps 100" \
              "--weights fp8 --steps 300" "--ctx 2048" "--weights fp8 --ctx 2048 --steps 500 --warmup 4" \
-             "--topk 50 --temperature 0.9" "--no-graph --steps 100" "--weights fp8 --batch 16 --steps 100"; do
+             "--topk 50 --temperature 0.9" "--no-graph --steps 100" "--weights fp8 --batch 16 --steps 100" "--batch 32 --steps 50" "--batch 64 --steps 50" \
+             "--batch 64 --steps 50 --opt rows64=0"; do
   timeout 300 python bench.py --no-cpu-baseline --config4 0 $extra >> $O/bench_other_configs.jsonl 2>> $O/bench_other.err
 done
 # context prefill by precision: 0 exact, 1 bf16 activations (LDS-DMA GEMM up to 4096 rows), 2 MX-fp8 weights and activations
@@ -17,6 +18,9 @@ for c in 64 512 1024 2048; do for m in 0 1 2; do timeout 200 python tools/prefil
 timeout 200 python tools/prefill_bench.py 512 16 3 >> $O/prefill.txt 2>&1
 timeout 200 python tools/prefill_bench.py 512 1 8 1 gemm_dma=0 2>&1 | grep "^ctx" >> $O/prefill.txt
 timeout 200 python tools/prefill_bench.py 2048 1 8 1 gemm_dma=0 2>&1 | grep "^ctx" >> $O/prefill.txt
+# the 256 x 256 tile (gemm256.h) off: 2048 frames and 16 x 512 frames, bf16 and mxfp8
+for m in 1 2; do timeout 200 python tools/prefill_bench.py 2048 1 8 $m gemm_256=0 2>&1 | grep "^ctx" >> $O/prefill.txt; done
+for m in 1 2; do timeout 300 python tools/prefill_bench.py 512 16 3 $m 2>&1 | grep "^ctx" >> $O/prefill.txt; timeout 300 python tools/prefill_bench.py 512 16 3 $m gemm_256=0 2>&1 | grep "^ctx" >> $O/prefill.txt; done
 timeout 300 python tools/bench_gemm_mx.py 2>&1 | grep "^|" > $O/gemm_mx_microbench.md
 # kernel-level split of the benchmarked command (streamer off under the profiler) + the launch-by-launch step anatomy
 cd /tmp
