@@ -19,6 +19,7 @@ struct PrefillAttnArgs {
   float* out;           // [B*S][n_q*64]
   bf16_t* oplanes;      // nullable: output as row-major planes [3][B*S][n_q*64] for the o_proj GEMM instead of `out`
   size_t plane_stride;
+  int ksplit_groups;    // host-side A/B: 2 = two key groups per workgroup from 256 visible positions on, 3 = the same at <= 128 VGPRs; else one
 };
 
 #ifdef CSM_ATTN_PREFILL_KERNELS   // defined by attn_prefill.hip only
@@ -212,12 +213,23 @@ __device__ __forceinline__ float ap_max3(float a, float b, float c) {   // no Na
   return r;
 }
 
-template <typename KT>
-__global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
+// NG = key groups per workgroup (round 3, A/B only: measured SLOWER, see attn_prefill.hip).  The idea: the last query tile walks
+// S / 64 key tiles one after the other while the workgroups of the early tiles have long finished (all of them are resident at
+// once), so with NG = 2 a workgroup is two 4-wave groups that take alternate key tiles (group g: tiles g, g + 2, ...) with their own
+// LDS stage and their own running statistics, and group 1 hands (o, m, l) to group 0 through LDS at the end: the chain is
+// half as long, nothing crosses workgroups, no second launch.  The merge is the usual two-part softmax combination.
+// OCC = waves per SIMD the register allocation aims at (A/B: 4 = two 8-wave workgroups per CU at <= 128 VGPRs, which spills the
+// fp32 K/V stage; 1 = unconstrained)
+template <typename KT, int NG = 1, int OCC = 1>
+__global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
   constexpr int HD = 64, LDK = 72;   // 144-byte LDS rows: 16-byte reads of 32 consecutive rows cover all banks evenly
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * LDK];   // [key][d]
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * LDK];   // [d][ap_vperm(key)]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) bf16_t kv_all[2 * NG * 64 * LDK];
+  bf16_t* const Ks_all = kv_all;                      // [group][key][d]
+  bf16_t* const Vt_all = kv_all + NG * 64 * LDK;      // [group][d][ap_vperm(key)]
+  const int grp = NG > 1 ? (int)threadIdx.x >> 8 : 0;
+  bf16_t* const Ks = Ks_all + grp * 64 * LDK;
+  bf16_t* const Vt = Vt_all + grp * 64 * LDK;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int G = a.n_q / a.n_kv;
   const int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
   const int j = blockIdx.y, b = blockIdx.z;
@@ -255,28 +267,33 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   constexpr float L2E = 1.4426950408889634f, SLACK = 8.f;
 
   ApStage<KT> st;
-  int kt0 = kv_lo & ~63;
-  st.load(kc, vc, a.lmax, kt0, tid);
+  int kt0 = (kv_lo & ~63) + 64 * grp;
+  if (kt0 <= kmax) st.load(kc, vc, a.lmax, kt0, tid);
   // where this thread's V share lands: rows d = 16*wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
   const int vkey = tid & 63;
   uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
   // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
   const uint32_t vsel = (vkey & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selector over {theirs, mine}
-  for (; kt0 <= kmax; kt0 += 64) {
+  // (the loop bound is the same for both groups -- every thread meets every barrier; a group whose tile lies past kmax idles)
+  for (int base = kv_lo & ~63; base <= kmax; base += 64 * NG, kt0 += 64 * NG) {
+    const bool live = NG == 1 || kt0 <= kmax;
     // ---- registers -> LDS ------------------------------------------------------------------------------------
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256;
-      *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = st.kword(i);
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = st.kword(i);
+      }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const uint32_t mine = st.vpair(q);
-      const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
-      vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t mine = st.vpair(q);
+        const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
+        vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
+      }
     }
     __syncthreads();
-    if (kt0 + 64 <= kmax) st.load(kc, vc, a.lmax, kt0 + 64, tid);   // next tile in flight behind this tile's math
+    if (!live) { __syncthreads(); continue; }
+    if (kt0 + 64 * NG <= kmax) st.load(kc, vc, a.lmax, kt0 + 64 * NG, tid);   // next tile in flight behind this tile's math
     // ---- S^T[key][row] = sum_d K[key][d] Q[row][d], two 32-key halves ----------------------------------------------
     f32x16 sc0 = (f32x16)(0.f), sc1 = (f32x16)(0.f);
 #pragma unroll
@@ -337,6 +354,30 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
     }
     __syncthreads();   // the tile is rewritten at the top of the next iteration
+  }
+  if (NG > 1) {
+    // group 1 -> group 0: (o0, o1, m, l) of every lane through the (now free) K stage memory, lane-major (conflict-free)
+    float* xch = reinterpret_cast<float*>(kv_all);   // 4 waves x 34 rows x 64 lanes x 4 B = 34 816 B of the 36 864 B of both stages
+    static_assert(NG == 1 || (size_t)4 * 34 * 64 * sizeof(float) <= (size_t)2 * NG * 64 * LDK * sizeof(bf16_t), "exchange area");
+    float* mine_x = xch + (size_t)wave * 34 * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { mine_x[r * 64] = o0[r]; mine_x[(16 + r) * 64] = o1[r]; }
+      mine_x[32 * 64] = m_run;
+      mine_x[33 * 64] = l_run;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = mine_x[32 * 64], l1 = mine_x[33 * 64];
+    const float m = fmaxf(m_run, m1);
+    const float w0 = m_run > -INFINITY ? __builtin_amdgcn_exp2f(m_run - m) : 0.f;
+    const float w1 = m1 > -INFINITY ? __builtin_amdgcn_exp2f(m1 - m) : 0.f;
+    l_run = l_run * w0 + l1 * w1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] = o0[r] * w0 + mine_x[r * 64] * w1;
+      o1[r] = o1[r] * w0 + mine_x[(16 + r) * 64] * w1;
+    }
   }
   if (!row_live) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;

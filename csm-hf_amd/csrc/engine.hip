@@ -233,6 +233,7 @@ struct csm_engine {
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
   int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
+  int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
   int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
@@ -573,6 +574,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
   else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
   else if (!strcmp(name, "rows64")) e->rows64 = value ? 1 : 0;
+  else if (!strcmp(name, "attn_key_groups")) e->attn_key_groups = value;
   else if (!strcmp(name, "attn_prefetch")) e->attn_prefetch = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
@@ -1150,7 +1152,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.out = e->p_att;
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, e->prefill_bf16_attn ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     if (fr == -2) {
       AttnArgs t{};
@@ -1262,7 +1264,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, (one && e->prefill_bf16_attn) ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     bool att_pl = pl && fr != -2;
