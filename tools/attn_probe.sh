@@ -1,3 +1,4 @@
+# context attention with one / two key groups per workgroup -> profiles/r03_attn_key_groups.txt (run through gpurun)
 O=gpurun_out/attn; mkdir -p $O
 {
 timeout 900 python -m pytest tests/test_gpu_generate.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q -k "prefill_precision or bf16 or mxfp8 or gemm256 or lds_dma" 2>&1 | tail -5

@@ -1,3 +1,4 @@
+# batches of 33-64 rows: tests + frame-step with rows64 on / off -> profiles/r03_b64_rows64.txt (run through gpurun)
 O=gpurun_out/b64; mkdir -p $O
 run() { timeout 300 python bench.py --no-cpu-baseline --config4 0 --lean "$@" 2>>$O/err.log | python -c "
 import sys, json

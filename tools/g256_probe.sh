@@ -1,3 +1,4 @@
+# gemm256_kernel (csrc/gemm256.h): parity test + MX GEMM microbenchmark + whole-prefill timings by schedule variant -> profiles/r03_gemm256.txt (run through gpurun)
 O=gpurun_out/g256; mkdir -p $O
 {
 timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -k "gemm256" 2>&1 | tail -5

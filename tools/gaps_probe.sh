@@ -1,3 +1,4 @@
+# kernel traces of the B = 1 and B = 16 bench + tools/step_timeline.py --gaps: which launch boundaries show gaps under the profiler (run through gpurun)
 O=gpurun_out/gaps; mkdir -p $O; export TMPDIR=/tmp; R=$PWD
 timeout 300 python bench.py --no-cpu-baseline --config4 0 > $O/b1.json 2> $O/b1.err
 timeout 300 python bench.py --no-cpu-baseline --config4 0 --batch 16 --steps 100 > $O/b16.json 2>> $O/b1.err
