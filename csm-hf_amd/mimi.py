@@ -298,7 +298,8 @@ class MimiDecoder:
     the reference's `audio_tokenizer.decode` (README.md:114-118: `audio_tokenizer.decode(gen_frames.permute(0, 2, 1))`).
     `state_dict`: the decode-path tensors in the `kyutai/mimi` key layout (see mimi_state_dict_spec)."""
 
-    def __init__(self, cfg: MimiDecodeConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", max_frames: int = 512):
+    def __init__(self, cfg: MimiDecodeConfig, state_dict: Optional[Dict[str, torch.Tensor]], device="cuda:0", max_frames: int = 512,
+                 _packed: Optional[Dict[str, object]] = None):
         from .engine import load_library, ABI_VERSION, _ck
         self.cfg, self.device = cfg, torch.device(device)
         if self.device.type != "cuda":
@@ -328,7 +329,8 @@ class MimiDecoder:
             h = C.c_void_p()
             _ck(self.lib, self.lib.csm_mimi_create(C.byref(c), C.byref(h)))
             self._h = h
-            self.packed = pack_mimi_weights(cfg, state_dict, self.device)          # keeps the tensors alive
+            # the packed tensors stay alive with the object; `new_stream()` hands the SAME tensors to another handle
+            self.packed = _packed if _packed is not None else pack_mimi_weights(cfg, state_dict, self.device)
             w = _MimiWeights()
             for name, _ in _MimiWeights._fields_:
                 v = self.packed[name]
@@ -366,6 +368,12 @@ class MimiDecoder:
         return out
 
     # ---- streaming: one sequence, a few frames per call (e.g. every frame `generate_frame` returns) -----------------
+    def new_stream(self, max_frames: Optional[int] = None) -> "MimiDecoder":
+        """Another decoder on the SAME device weights (no second copy of the 79 M parameters): its own handle, scratch and
+        stream state, so the rows of a generated batch can be streamed side by side -- one `stream_decode` per row and frame
+        (0.8 ms each at the kyutai shape); the handles do not share anything mutable."""
+        return MimiDecoder(self.cfg, None, self.device, self.max_frames if max_frames is None else max_frames, _packed=self.packed)
+
     def stream_reset(self):
         self._ck(self.lib, self.lib.csm_mimi_stream_reset(self._h))
 

@@ -237,3 +237,47 @@ def test_stream_decode_small_calls_on_the_skinny_gemm(name):
     assert differs                                        # the switch selects a different kernel: the two paths are not one
     fast.close()
     plain.close()
+
+
+@pytest.mark.gpu
+def test_streams_side_by_side_on_one_weight_set():
+    """`MimiDecoder.new_stream()`: further decoders on the SAME device weights (no second copy), each with its own stream state.
+    Three rows of a batch streamed frame by frame in interleaved order: every stream equals ITS one-shot decode bitwise on the
+    plain tile, i.e. the handles share nothing mutable; closing the parent first keeps the children's weights alive."""
+    from csm_hf_amd import MimiDecoder
+    cfg = CASES["tiny"]
+    sd = synth_mimi_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(5)
+    T = 24
+    codes = torch.randint(0, cfg.codebook_size, (3, cfg.num_quantizers, T), generator=gen).to("cuda:0")
+    first = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
+    decs = [first, first.new_stream(), first.new_stream()]
+    assert all(d.packed is first.packed for d in decs)
+    for d in decs:
+        d.set_option("skinny_rows", 0)
+        d.set_option("splitk", 0)
+        d.stream_reset()
+    whole = first.decode(codes)                            # [3, 1, T * spf], rows decoded one after the other
+    parts = [[] for _ in decs]
+    t = [0, 0, 0]
+    order = [0, 1, 2, 2, 1, 0, 1, 1, 2, 0, 0, 2] * 8       # interleaved, unequal progress
+    for b in order:
+        if t[b] >= T:
+            continue
+        n = 1 + (t[b] + b) % 3
+        n = min(n, T - t[b])
+        parts[b].append(decs[b].stream_decode(codes[b, :, t[b]:t[b] + n]).clone())
+        t[b] += n
+    for b in range(3):
+        while t[b] < T:
+            parts[b].append(decs[b].stream_decode(codes[b, :, t[b]:t[b] + 1]).clone())
+            t[b] += 1
+        assert torch.equal(torch.cat(parts[b], dim=-1)[0], whole[b]), b
+    want = MO.decode(sd, cfg, codes.cpu())
+    assert rel_max(whole.cpu(), want) < 1e-4
+    first.close()                                          # the children hold the packed tensors
+    decs[1].stream_reset()
+    again = decs[1].stream_decode(codes[1])
+    assert torch.equal(again[0], whole[1])
+    decs[1].close()
+    decs[2].close()
