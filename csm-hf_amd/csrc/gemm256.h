@@ -130,7 +130,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
   mx_v8i af[2][2];       // [register set][tile of the pair]
   int sw[4], sa[2][2];
   auto ld_frag = [&](const uint8_t* p) {
+    if constexpr (VAR == 4) return mx_v8i{0, 0, 0, 0, 0, 0, 0, 0};
     const u32x4 lo = *reinterpret_cast<const u32x4*>(p + c0), hi = *reinterpret_cast<const u32x4*>(p + c1);
+    if constexpr (VAR == 3) { asm volatile("" ::"v"(lo), "v"(hi)); }
     return mx_v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
   };
   auto read_w = [&](const uint8_t* sb) {
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
   };
   // activation tiles 2 pair, 2 pair + 1 (register set `set`) x weight tiles n0 .. n1 - 1
   auto mma = [&](int pair, int set, int n0 = 0, int n1 = 4) {
+    if constexpr (VAR == 3) return;
     __builtin_amdgcn_s_setprio(1);
     if constexpr (MX) {
 #pragma unroll
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last DMA must not outlive the workgroup's LDS allocation
   }
 
-  } else if constexpr (VAR == 1) {
+  } else if constexpr (VAR == 1 || VAR >= 3) {
+    // VAR 3 / 4 / 5 (tools/bench_gemm_mx.py only: WRONG results): VAR 1 without its MFMAs / without its fragment reads /
+    // without the DMA inside the loop -- which of the three streams bounds a k-step
     // VAR 1: the weight fragments live in two halves (tiles 0-1 | 2-3) and every phase multiplies by one half at a time, so
     // that the NEXT step's halves can be fetched as soon as the last phase has issued its MFMAs on the old ones: no fragment
     // read is waited for with an empty matrix pipe at the top of a step.
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
       mma(2, 0, 2, 4); SB;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                      // stage st^1 visible to every wave, stage st free
-      issue(min(ks + 2, nk - 1), ks & 1);
+      if constexpr (VAR != 5) issue(min(ks + 2, nk - 1), ks & 1);
       read_a(sn, 0, 0); SB;
       mma(3, 1, 0, 2); SB;
       read_wh(sn, 0); SB;

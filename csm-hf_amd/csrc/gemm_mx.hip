@@ -105,11 +105,16 @@ template <int EPI, bool MX, typename ARGS>
 static int launch_256_epi(hipStream_t st, const dim3& grid, const ARGS& a) {
   if (g256_var == 0) return launch_256_var<EPI, MX, 0, ARGS>(st, grid, a);
   if (g256_var == 1) return launch_256_var<EPI, MX, 1, ARGS>(st, grid, a);
+  if constexpr (EPI == GEPI_STORE && MX) {   // knock-out variants of the microbenchmark (wrong results by construction)
+    if (g256_var == 3) return launch_256_var<EPI, MX, 3, ARGS>(st, grid, a);
+    if (g256_var == 4) return launch_256_var<EPI, MX, 4, ARGS>(st, grid, a);
+    if (g256_var == 5) return launch_256_var<EPI, MX, 5, ARGS>(st, grid, a);
+  }
   return launch_256_var<EPI, MX, 2, ARGS>(st, grid, a);
 }
 
 int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs) {
-  { const int sel = (min_wgs >> 24) & 3; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : 2); }   // bits 24-25: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2 (A/B)
+  { const int sel = (min_wgs >> 24) & 7; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : sel); }   // bits 24-26: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2, 3-5 = knock-outs (A/B)
   min_wgs &= 0xffffff;
   if (!a.Aplanes || a.a_plane_stride != 0 || !a.W || a.wscale || a.R < 256 || a.R % 256 || a.N % 256 || a.K % 64 || a.ldc % 4) return -2;
   if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return -2;
@@ -128,7 +133,7 @@ int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs)
 }
 
 int launch_gemm256_mx(hipStream_t st, int epi, const GemmMxArgs& a, int min_wgs) {
-  { const int sel = (min_wgs >> 24) & 3; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : 2); }   // bits 24-25: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2 (A/B)
+  { const int sel = (min_wgs >> 24) & 7; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : sel); }   // bits 24-26: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2, 3-5 = knock-outs (A/B)
   min_wgs &= 0xffffff;
   if (a.R < 256 || a.R % 256 || a.N % 256 || a.K % 128 || !a.Aq || !a.As || !a.Wq || !a.Ws) return -2;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
