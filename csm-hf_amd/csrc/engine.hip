@@ -158,6 +158,8 @@ struct csm_engine {
   int gemm_256 = 256;   // gemm256_kernel (256 x 256 tile): minimum workgroup count (tiles x K splits) of a launch it takes (one per CU); 0 = off;
                         // bits 24-25 select a schedule variant (A/B).  csm-1b prefill, bf16 / mxfp8: 2048 frames 6.50 / 5.07 -> 5.86 / 4.71 ms,
                         // 16 x 512 frames 19.7 / 16.0 -> 18.8 / 13.6 ms (profiles/r03_gemm256.txt)
+  int gemm_dma_min_wgs = 200;   // exact (three-plane) LDS-DMA GEMM only for launches of at least this many 128 x 128 workgroups: below, the 64 x 64
+                                // square tile fills the chip better (256-frame exact prefill 3.26 -> 2.92 ms; 512 / 1024 frames unchanged: profiles/r03_prefill.txt)
   int gemm_dma = 5, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): bit 0 one plane, bit 2 three planes (exact), launches of up to 4096 rows
   // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
   // the quantised-activation scratch [max_prefill_rows][widest K] + scales
@@ -559,6 +561,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
   else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "gemm_dma")) e->gemm_dma = value;
+  else if (!strcmp(name, "gemm_dma_min_wgs")) e->gemm_dma_min_wgs = value;
   else if (!strcmp(name, "gemm_256")) e->gemm_256 = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_max_rows")) e->gemm_dma_max_rows = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
@@ -1249,7 +1252,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256;
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs;
     RopeArgs ra{};
     if (ks_q > 1) {
       g.ksplit = ks_q; g.Cpart = e->p_part; g.part_stride = R * (size_t)s.nqkv();
@@ -1277,7 +1280,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256;
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
     if (att_pl && ks_o > 1) {
       o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
@@ -1291,12 +1294,12 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256;
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs;
     gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
     LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256;
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
     if (pl && ks_d > 1) {
       d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;

@@ -48,6 +48,7 @@ struct GemmArgs {
   // profiles/r03_prefill.txt): one plane 64 / 512 / 2048 rows 1.68 / 2.78 / 6.80 -> 1.53 / 2.29 / 6.31 ms, 8192 rows 19.6 ->
   // 22.3 ms (gemm_wide_kernel's 128 x 256 tile wins there); three planes 512 / 2048 rows 5.03 / 17.2 -> 4.52 / 16.1 ms
   int dma, dma_max_rows;
+  int dma_min_wgs;   // three-plane launches with fewer 128 x 128 tiles x K splits than this stay on the 64 x 64 square tile (A/B; 0 = no limit)
   // gemm256_kernel (gemm256.h: the same staging, 256 x 256 tile, 8 waves): one-plane bf16 launches whose 256 x 256 tiles (x K
   // splits) number at least big256 (0 = never)
   int big256;
