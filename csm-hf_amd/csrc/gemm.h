@@ -44,7 +44,8 @@ struct GemmArgs {
   int wide, wide_depth, wide_exact, krot;
   // gemm_dma_bf16_kernel (gemm_mx.h: both operands staged by LDS-DMA from row-major memory, 128 x 128 x 64 tile) for one-plane
   // bf16 launches.  Bits: 1 = one-plane launches of at most dma_max_rows rows, 2 = one-plane always (A/B), 4 = three-plane
-  // (exact) launches of 256 ... dma_max_rows rows, 8 = three-plane always (A/B).  Measured (csm-1b, whole prefill,
+  // (exact) launches of 256 ... dma_max_rows rows, 8 = three-plane always (A/B), 32 = three-plane launches on 32-wide k-steps
+  // (gemm_dma3_k32_kernel: two workgroups per CU).  Measured (csm-1b, whole prefill,
   // profiles/r03_prefill.txt): one plane 64 / 512 / 2048 rows 1.68 / 2.78 / 6.80 -> 1.53 / 2.29 / 6.31 ms, 8192 rows 19.6 ->
   // 22.3 ms (gemm_wide_kernel's 128 x 256 tile wins there); three planes 512 / 2048 rows 5.03 / 17.2 -> 4.52 / 16.1 ms
   int dma, dma_max_rows;
