@@ -235,6 +235,8 @@ struct csm_engine {
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
   int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
   int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
+  int gemv_norm_ks = 1;   // B = 1, K = 2048 normed launches on the register GEMV with two waves per task: bit 0 the backbone QKV (3.134 -> 3.103 ms
+                          // per step, tokens unchanged), bit 1 gate/up (measured slower: off); profiles/r03_b1_ab.txt
   int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
@@ -578,6 +580,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
   else if (!strcmp(name, "rows64")) e->rows64 = value ? 1 : 0;
   else if (!strcmp(name, "attn_key_groups")) e->attn_key_groups = value;
+  else if (!strcmp(name, "gemv_norm_ks")) e->gemv_norm_ks = value;
   else if (!strcmp(name, "attn_prefetch")) e->attn_prefetch = value;
   else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
@@ -716,6 +719,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   a.n_q = nq; a.n_kv = nkv; a.hd = hd; a.qscale = 1.0f / sqrtf((float)hd);
   a.cos_tab = s.cos; a.sin_tab = s.sin; a.pos_ptr = pos_ptr; a.pos_const = pos_const;
   a.qbuf = qb; a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.lmax = s.lmax;
+  a.norm_ks = e->gemv_norm_ks & 1 ? 2 : 0;
   if (planes && in_planes) { a.xplanes = e->pl_h; a.xss = e->pl_ss; a.xss_n = H / 16; a.xss_ld = PL_SS_LD; }
   if (tok) {  // the row comes from (partials -> token -> projected-embedding table); h is written by workgroup 0
     a.am_in = tok->am_in; a.am_n = tok->am_n; a.tok_table = tok->tok_table; a.tok_row_base = tok->tok_row_base;
@@ -775,6 +779,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   GemvArgs g{};
   g.nt = nt_big;
   g.W = w.wgu; g.wscale = w.sgu; g.N = 2 * F; g.K = H; g.x = h; g.ldx = ldh; g.ln = w.ln2; g.eps = s.c.rms_eps; g.out = act; g.ldo = F;
+  g.norm_ks = e->gemv_norm_ks & 2 ? 2 : 0;
   {  // panel tiles of the gate/up launch: low byte decoder, next byte backbone (0 = auto)
     const int pt = (&s == &e->bb) ? (e->g16_gu >> 8) & 0xff : e->g16_gu & 0xff;
     if (pt) g.g16_pt = pt;

@@ -84,6 +84,7 @@ struct GemvArgs {
   int no_mfma;         // host-side: rows >= 2 stay on the fp32-FMA kernel (two-token decoder pass: a row's arithmetic is then
                        // bitwise that of the single-row kernel)
   int v2_tasks;        // host-side: 1 = force one task per wave in the fast path (A/B measurements)
+  int norm_ks;         // host-side: 2 = single-row normed launches with K = 2048 take the register path with two waves per task (K split in the workgroup)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
   int g16_slab;  // split-K slab exchange of the MFMA kernel: 0 = write-through (sc1) stores + sc1 loads, 1 = plain stores + sc1 loads, 2 = plain both (A/B)
@@ -381,7 +382,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       xp[m][u][2] = f32x2{xb[m][u][0], xb[m][u][1]};
       xp[m][u][3] = f32x2{xb[m][u][2], xb[m][u][3]};
     }
-  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {  // KS == 1 here: the wave holds the whole row
+  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
+    // KS == 1: the wave holds the whole row.  KS > 1 (round 3: the backbone's K = 2048 normed launches on this register path
+    // with two waves per task): every wave sums its K slice and the KS waves of a task meet through LDS (LDS-only barrier:
+    // the weight loads stay in flight) -- a fixed order, so the statistic is the same in every wave of the task.
+    __shared__ float ssx[4][M];
+    float ssw[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       f32x2 ss2 = f32x2{0.f, 0.f};
@@ -389,9 +395,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss2 = PKFMA(xp[m][u][i], xp[m][u][i], ss2);
+      ssw[m] = wave_sum(ss2[0] + ss2[1]);
+      if (KS > 1 && lane == 0) ssx[wave][m] = ssw[m];
+    }
+    if (KS > 1) {
+      lds_barrier();
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) t += ssx[tw * KS + s][m];
+        ssw[m] = t;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       // mean = sum * rcp(K): identical to sum / K for the power-of-two widths of this model family; raw v_rsq_f32
       // (the argument is >= eps, far from the denormal range the library wrapper rescales for)
-      const float sc = __builtin_amdgcn_rsqf(wave_sum(ss2[0] + ss2[1]) * __builtin_amdgcn_rcpf((float)K) + a.eps);
+      const float sc = __builtin_amdgcn_rsqf(ssw[m] * __builtin_amdgcn_rcpf((float)K) + a.eps);
       const f32x2 sc2 = f32x2{sc, sc};
 #pragma unroll
       for (int u = 0; u < U; ++u) {

@@ -36,7 +36,10 @@ static int launch_dispatch(hipStream_t st, int wdtype, int kvdtype, int M, int p
 int launch_gemv(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a) {
   if (a.K % 8 != 0 || a.K < 8) return -1;
   const int ntask = (epi == EPI_QKV) ? (a.N >> 1) : ((a.N + 1) >> 1);
-  return launch_dispatch(st, wdtype, kvdtype, M, pro, epi, pick_ks(ntask, a.K), a);
+  int ks = pick_ks(ntask, a.K);
+  // single-row normed launches with K = 2048 (the backbone's QKV / gate-up): the register path with two waves per task
+  if (a.norm_ks == 2 && M == 1 && pro == PRO_NORM && ks == 1 && a.K == 2048 && !a.force_generic) ks = 2;
+  return launch_dispatch(st, wdtype, kvdtype, M, pro, epi, ks, a);
 }
 
 // set the dynamic-LDS limit on every instantiation (call once per process before any capture)
