@@ -239,7 +239,7 @@ struct csm_engine {
                           // per step, tokens unchanged), bit 1 gate/up (measured slower: off); profiles/r03_b1_ab.txt
   int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
-  int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bits 8-12 the same for the backbone
+  int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bit 5 the fused B = 1 attention + o_proj launch, bit 6 the B = 1 fused-argmax heads, bits 8-12 the same five for the backbone
   int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
   int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
@@ -735,7 +735,9 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   o.nt = nt_small;
   o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
   int ao = -2;
-  if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
+  if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn && (sk & 32)) {
+    ao = 0;   // dbg_skip bit 5: the fused attention + o_proj launch knocked out (timing only)
+  } else if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
     // single sequence, short cache: one launch for SDPA + o_proj (heads in parallel on the waves of each o_proj workgroup)
     AttnOprojArgs f{};
     f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
@@ -979,7 +981,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(p - 1) * V : nullptr;
       a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
       a.out = e->logits_dec; a.ldo = (V + 3) & ~3; a.am_out = e->am_part; a.am_from = 0;
-      LCK(gemv_rows(e, B, PRO_NORM, EPI_ARGMAX, a));
+      if (!(e->dbg_skip & 64)) LCK(gemv_rows(e, B, PRO_NORM, EPI_ARGMAX, a));   // dbg_skip bit 6: the fused-argmax head launches (timing only)
     } else if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame
