@@ -115,24 +115,27 @@ static int launch_256_var(hipStream_t st, const dim3& grid, const ARGS& a) {
   return (int)hipGetLastError();
 }
 
-// min_wgs: low 24 bits = workgroups (tiles x K splits) a launch must have, bits 24-25 = schedule variant (gemm256.h VAR, A/B).
+// min_wgs: low 24 bits = workgroups (tiles x K splits) a launch must have, bits 24-26 = schedule variant (gemm256.h VAR, A/B).
 // Measured (profiles/r03_gemm256.txt): VAR 1 (weight fragments in halves) is 1-3 % ahead of VAR 0; VAR 2 (DMA pieces spread over
 // the phases, buffer form) wins 5-10 % on single 2048-row GEMMs and LOSES 3-6 % on whole prefills and at 8192 rows.
-static int g256_var = 0;
+static inline int g256_variant(int min_wgs) {   // 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2, 3-5 = knock-outs
+  const int sel = (min_wgs >> 24) & 7;
+  return sel == 0 ? 1 : (sel == 1 ? 0 : sel);
+}
 template <int EPI, bool MX, typename ARGS>
-static int launch_256_epi(hipStream_t st, const dim3& grid, const ARGS& a) {
-  if (g256_var == 0) return launch_256_var<EPI, MX, 0, ARGS>(st, grid, a);
-  if (g256_var == 1) return launch_256_var<EPI, MX, 1, ARGS>(st, grid, a);
+static int launch_256_epi(hipStream_t st, const dim3& grid, const ARGS& a, int var) {
+  if (var == 0) return launch_256_var<EPI, MX, 0, ARGS>(st, grid, a);
+  if (var == 1) return launch_256_var<EPI, MX, 1, ARGS>(st, grid, a);
   if constexpr (EPI == GEPI_STORE && MX) {   // knock-out variants of the microbenchmark (wrong results by construction)
-    if (g256_var == 3) return launch_256_var<EPI, MX, 3, ARGS>(st, grid, a);
-    if (g256_var == 4) return launch_256_var<EPI, MX, 4, ARGS>(st, grid, a);
-    if (g256_var == 5) return launch_256_var<EPI, MX, 5, ARGS>(st, grid, a);
+    if (var == 3) return launch_256_var<EPI, MX, 3, ARGS>(st, grid, a);
+    if (var == 4) return launch_256_var<EPI, MX, 4, ARGS>(st, grid, a);
+    if (var == 5) return launch_256_var<EPI, MX, 5, ARGS>(st, grid, a);
   }
   return launch_256_var<EPI, MX, 2, ARGS>(st, grid, a);
 }
 
 int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs) {
-  { const int sel = (min_wgs >> 24) & 7; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : sel); }   // bits 24-26: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2, 3-5 = knock-outs (A/B)
+  const int var = g256_variant(min_wgs);
   min_wgs &= 0xffffff;
   if (!a.Aplanes || a.a_plane_stride != 0 || !a.W || a.wscale || a.R < 256 || a.R % 256 || a.N % 256 || a.K % 64 || a.ldc % 4) return -2;
   if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride != 0) return -2;
@@ -142,16 +145,16 @@ int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs)
   if (tiles * ks < min_wgs) return -2;
   const dim3 grid((unsigned)tiles, ks);
   switch (epi) {
-    case GEPI_STORE: return launch_256_epi<GEPI_STORE, false, GemmArgs>(st, grid, a);
-    case GEPI_RESID: return launch_256_epi<GEPI_RESID, false, GemmArgs>(st, grid, a);
-    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, false, GemmArgs>(st, grid, a);
-    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, false, GemmArgs>(st, grid, a);
+    case GEPI_STORE: return launch_256_epi<GEPI_STORE, false, GemmArgs>(st, grid, a, var);
+    case GEPI_RESID: return launch_256_epi<GEPI_RESID, false, GemmArgs>(st, grid, a, var);
+    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, false, GemmArgs>(st, grid, a, var);
+    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, false, GemmArgs>(st, grid, a, var);
     default: return -1;
   }
 }
 
 int launch_gemm256_mx(hipStream_t st, int epi, const GemmMxArgs& a, int min_wgs) {
-  { const int sel = (min_wgs >> 24) & 7; g256_var = sel == 0 ? 1 : (sel == 1 ? 0 : sel); }   // bits 24-26: 0 = the default schedule (VAR 1), 1 = VAR 0, 2 = VAR 2, 3-5 = knock-outs (A/B)
+  const int var = g256_variant(min_wgs);
   min_wgs &= 0xffffff;
   if (a.R < 256 || a.R % 256 || a.N % 256 || a.K % 128 || !a.Aq || !a.As || !a.Wq || !a.Ws) return -2;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
@@ -160,10 +163,10 @@ int launch_gemm256_mx(hipStream_t st, int epi, const GemmMxArgs& a, int min_wgs)
   if (tiles * ks < min_wgs) return -2;
   const dim3 grid((unsigned)tiles, ks);
   switch (epi) {
-    case GEPI_STORE: return launch_256_epi<GEPI_STORE, true, GemmMxArgs>(st, grid, a);
-    case GEPI_RESID: return launch_256_epi<GEPI_RESID, true, GemmMxArgs>(st, grid, a);
-    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, true, GemmMxArgs>(st, grid, a);
-    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, true, GemmMxArgs>(st, grid, a);
+    case GEPI_STORE: return launch_256_epi<GEPI_STORE, true, GemmMxArgs>(st, grid, a, var);
+    case GEPI_RESID: return launch_256_epi<GEPI_RESID, true, GemmMxArgs>(st, grid, a, var);
+    case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, true, GemmMxArgs>(st, grid, a, var);
+    case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, true, GemmMxArgs>(st, grid, a, var);
     default: return -1;
   }
 }
