@@ -29,6 +29,7 @@ struct AttnOprojArgs {
   int N;
   float* out;            // residual stream [N], updated in place (batched form: [rows][ldo])
   int beside_streamer;   // host-side: refuse (-2) when a workgroup of this launch does not fit beside a resident streamer wave
+  int dbg_onekey;        // TIMING ONLY (wrong results): every lane loads key 0 -- the launch without its K/V traffic
   // batched form (attn_oproj_rows_kernel, 2 <= rows <= 64): sequence = row; the updated residual row also leaves as
   // MFMA B-operand planes for the gate/up launch (x * oln in fragment order, 16 rows per group) + per-16-column sums of x^2
   int ldo;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
     const KT* kc = reinterpret_cast<const KT*>(a.kcache) + (size_t)j * (size_t)(HD / 4) * a.lmax * 4;
     const KT* vc = reinterpret_cast<const KT*>(a.vcache) + (size_t)j * (size_t)a.lmax * HD;
     Tile tile;
-    tile.load(kc, vc, a.lmax, 0, cnt, lane);
+    tile.load(kc, vc, a.lmax, 0, a.dbg_onekey ? 1 : cnt, lane);
     const float* qsrc = a.q + (size_t)h * HD;
 #pragma unroll
     for (int i = 0; i < HD / 64; ++i) qs[lane + 64 * i] = qsrc[lane + 64 * i];

@@ -743,6 +743,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
     f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h;
     f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
+    f.dbg_onekey = (e->dbg_skip >> 7) & 1;
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
   }

@@ -210,4 +210,181 @@ __global__ __launch_bounds__(256) void mimi_last_conv_kernel(const float* xa, co
     if (lane == 0) audio[l] = s + bias;
   }
 }
+// ---- stream GROUPS (round 3: csm_mimi_streams_*): S streams advance in lockstep, T frames each per call, every launch
+// covers all of them -- the one-frame streaming call is launch-bound (~120 launches of a few rows each), so S streams in the
+// same launches cost little more than one.  Compact activations are [S * L][C] (row = s * L + l); a convolution's input is
+// [S][PADR + L][C] (every stream's own left context in front of its rows); per-stream state (rotary position, history rows,
+// "has a previous frame", history rows to keep) comes from small device arrays, so streams restarted at different times
+// (continuous batching) share a call.
+__global__ __launch_bounds__(256) void mimi_rvq_gather_g_kernel(const int64_t* codes, const float* embed, int n_q, int n_sem, int csize,
+                                                                int D, int T, float* out) {
+  const int t = blockIdx.x, s = blockIdx.y;
+  const int64_t* cb = codes + (size_t)s * n_q * T;
+  for (int d = threadIdx.x; d < 2 * D; d += 256) {
+    const int acoustic = d >= D, dd = acoustic ? d - D : d;
+    float v = 0.f;
+    for (int k = acoustic ? n_sem : 0; k < (acoustic ? n_q : n_sem); ++k) {
+      const int64_t c = cb[(size_t)k * T + t];
+      v += embed[((size_t)k * csize + c) * D + dd];
+    }
+    out[((size_t)s * T + t) * 2 * D + d] = v;
+  }
+}
+__global__ __launch_bounds__(256) void mimi_upsample_g_kernel(const float* x, const float* w, int T, int C, int st, const float* prev,
+                                                              const int* hasprev, int S, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per = (size_t)T * st * C;
+  if (i >= per * S) return;
+  const int s = (int)(i / per);
+  const size_t j = i - (size_t)s * per;
+  const int c = (int)(j % C);
+  const size_t lo = j / C;
+  const int q = (int)(lo / st), p = (int)(lo % st);
+  const float* xs = x + (size_t)s * T * C;
+  float v = xs[(size_t)q * C + c] * w[(size_t)c * 2 * st + p];
+  if (q > 0) v += xs[(size_t)(q - 1) * C + c] * w[(size_t)c * 2 * st + p + st];
+  else if (hasprev[s]) v += prev[(size_t)s * C + c] * w[(size_t)c * 2 * st + p + st];
+  out[i] = v;
+}
+__global__ __launch_bounds__(256) void mimi_rope_g_kernel(float* qkv, int L, int heads, int hd, float theta, const int* pos0, int S) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int half = hd / 2, A = heads * hd;
+  const size_t per = (size_t)L * 2 * heads * half;
+  if (i >= per * S) return;
+  const int s = (int)(i / per);
+  const size_t j = i - (size_t)s * per;
+  const int f = (int)(j % half);
+  const size_t r = j / half;
+  const int h = (int)(r % (2 * heads));
+  const int pos = (int)(r / (2 * heads));
+  float* p = qkv + ((size_t)s * L + pos) * 3 * A + (size_t)h * hd;
+  const float ang = (float)(pos0[s] + pos) * powf(theta, -2.f * (float)f / (float)hd);
+  const float c = cosf(ang), sn = sinf(ang);
+  const float a = p[f], b = p[f + half];
+  p[f] = a * c - b * sn;
+  p[f + half] = b * c + a * sn;
+}
+__global__ __launch_bounds__(256) void mimi_kv_append_g_kernel(const float* qkv, float* hist, size_t hstride, const int* nh, size_t L, int A, int S) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per = L * 2 * A;
+  if (i >= per * S) return;
+  const int s = (int)(i / per);
+  const size_t j = i - (size_t)s * per;
+  const size_t r = j / (2 * A);
+  const int c = (int)(j % (2 * A));
+  hist[(size_t)s * hstride + ((size_t)nh[s] + r) * 2 * A + c] = qkv[((size_t)s * L + r) * 3 * A + A + c];
+}
+// per stream: rows [nh + L - keep, nh + L) of src to the front of dst
+__global__ __launch_bounds__(256) void mimi_rows_copy_g_kernel(const float* src, float* dst, size_t hstride, const int* nh, const int* keep, int L,
+                                                               int A2) {
+  const int s = blockIdx.y;
+  const size_t n = (size_t)keep[s] * A2;
+  const size_t from = (size_t)(nh[s] + L - keep[s]) * A2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[(size_t)s * hstride + i] = src[(size_t)s * hstride + from + i];
+}
+// mimi_attn_kernel with the stream taken from the row: grid = (S * L, heads)
+__global__ __launch_bounds__(64) void mimi_attn_g_kernel(const float* qkv, const float* hist_all, size_t hstride, const int* nhs, int L, int heads, int hd,
+                                                         int window, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // q[hd] | scores[window]
+  float* qs = sm;
+  float* sc = sm + hd;
+  const int row = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int s = row / L, i = row - s * L;
+  const float* hist = hist_all + (size_t)s * hstride;
+  const int A = heads * hd;
+  const int hi = nhs[s] + i;
+  const int j0 = max(0, hi - window + 1), n = hi - j0 + 1;
+  const float* q = qkv + (size_t)row * 3 * A + (size_t)h * hd;
+  const float scale = rsqrtf((float)hd);
+  for (int d = tid; d < hd; d += 64) qs[d] = q[d] * scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < n; j += 64) {
+    const float* k = hist + (size_t)(j0 + j) * 2 * A + (size_t)h * hd;
+    float s0 = 0.f, s1 = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(k + d), k1 = *reinterpret_cast<const f32x4*>(k + d + 4);
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + d), q1 = *reinterpret_cast<const f32x4*>(qs + d + 4);
+      s0 += (k0[0] * q0[0] + k0[1] * q0[1]) + (k0[2] * q0[2] + k0[3] * q0[3]);
+      s1 += (k1[0] * q1[0] + k1[1] * q1[1]) + (k1[2] * q1[2] + k1[3] * q1[3]);
+    }
+    const float sv = s0 + s1;
+    sc[j] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = tid; j < n; j += 64) { const float p = expf(sc[j] - mx); sc[j] = p; se += p; }
+  se = wave_sum(se);
+  __syncthreads();
+  const float inv = 1.f / se;
+  for (int d = tid; d < hd; d += 64) {
+    float o0 = 0.f, o1 = 0.f;
+    const float* v = hist + (size_t)j0 * 2 * A + A + (size_t)h * hd + d;
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+      o0 = fmaf(sc[j], v[(size_t)j * 2 * A], o0);
+      o1 = fmaf(sc[j + 1], v[(size_t)(j + 1) * 2 * A], o1);
+    }
+    if (j < n) o0 = fmaf(sc[j], v[(size_t)j * 2 * A], o0);
+    out[(size_t)row * A + (size_t)h * hd + d] = (o0 + o1) * inv;
+  }
+}
+// convolution input of a group, [S][PR + L][C]: mode 0: the PR cached rows of every stream to the front of its segment;
+// mode 1: (ELU of) the compact rows [S * L][C] behind them; mode 2: the last PR rows of every segment back to the cache
+__global__ __launch_bounds__(256) void mimi_pad_g_kernel(float* pad, float* cache, const float* src, int S, int PR, size_t L, int C, int mode, int elu) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t seg = ((size_t)PR + L) * C;
+  if (mode == 1) {
+    const size_t per = L * C;
+    if (i >= per * S) return;
+    const size_t s = i / per, j = i - s * per;
+    const float v = src[i];
+    pad[s * seg + (size_t)PR * C + j] = (elu && v <= 0.f) ? expm1f(v) : v;
+  } else {
+    const size_t per = (size_t)PR * C;
+    if (i >= per * S) return;
+    const size_t s = i / per, j = i - s * per;
+    if (mode == 0) pad[s * seg + j] = cache[i];
+    else cache[i] = pad[s * seg + L * C + j];
+  }
+}
+// mimi_bias_act_kernel for a GEMM over a group's padded input: the result row of (stream s, row l) is s * (PR + L) + l
+__global__ __launch_bounds__(256) void mimi_bias_act_g_kernel(const float* src, int lds, const float* bias, int nb, int C, int S, int PR, size_t L,
+                                                              int act, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)S * L * C) return;
+  const size_t r = i / C;
+  const int c = (int)(i % C);
+  const size_t s = r / L, l = r - s * L;
+  float v = src[(s * ((size_t)PR + L) + l) * lds + c] + (bias ? bias[c % nb] : 0.f);
+  if (act == 1) v = v > 0.f ? v : expm1f(v);
+  out[i] = v;
+}
+// mimi_last_conv_kernel over a group's padded input [S][PR + L][C]; audio [S][L]
+__global__ __launch_bounds__(256) void mimi_last_conv_g_kernel(const float* pad, const float* w, const float* b, int C, int k, int PR, size_t L, float* audio) {
+  const int lane = threadIdx.x & 63, s = blockIdx.y;
+  const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int K = k * C;
+  const float* xa = pad + ((size_t)s * ((size_t)PR + L) + (size_t)(PR - (k - 1))) * C;
+  float wr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) wr[u] = lane + 64 * u < K ? w[lane + 64 * u] : 0.f;
+  const float bias = b[0];
+  for (int o = 0; o < 16; ++o) {
+    const size_t l = wv * 16 + o;
+    if (l >= L) return;
+    const float* p = xa + l * C;
+    float v = 0.f;
+    if (K <= 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lane + 64 * u < K) v = fmaf(wr[u], p[lane + 64 * u], v);
+    } else {
+      for (int i = lane; i < K; i += 64) v = fmaf(w[i], p[i], v);
+    }
+    v = wave_sum(v);
+    if (lane == 0) audio[(size_t)s * L + l] = v + bias;
+  }
+}
 #endif  // CSM_MIMI_KERNELS

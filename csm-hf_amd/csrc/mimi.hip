@@ -43,6 +43,16 @@ struct csm_mimi {
   int s_frames = 0, s_nh = 0, s_cur = 0;
   float* s_up_prev = nullptr;
   std::vector<float*> s_conv;
+  // stream GROUP (csm_mimi_streams_*): S streams in lockstep, every launch covers all of them (mimi.h: *_g kernels)
+  int g_S = 0, g_T = 0, g_cur = 0;     // streams, most frames per call (max_frames / S), ping-pong index of the histories
+  std::vector<int> g_frames, g_nh, g_host;   // per stream: frames decoded, history rows kept; staging of the device arrays
+  std::vector<float*> g_hist[2];       // per layer: [S][g_hrows][2 A]
+  size_t g_hrows = 0;
+  float* g_up_prev = nullptr;          // [S][hidden]
+  std::vector<float*> g_conv;          // per convolution: [S][PADR][C_in]
+  float *g_pad = nullptr, *g_scr = nullptr;
+  int* g_meta = nullptr;               // device [4][S]: rotary position | history rows | has a previous frame | rows to keep
+  std::vector<void*> g_allocs;
   float* part = nullptr;               // split-K partial products of a GEMM with too few tiles (gemm())
   size_t part_floats = (size_t)8 << 20;
   bool splitk = true;                  // csm_mimi_set_option("splitk", 0): no K split (A/B; with "skinny_rows" 0: one kernel, one order)
@@ -142,6 +152,7 @@ extern "C" int csm_mimi_destroy(csm_mimi_t* m) {
   if (!m) return 0;
   hipStreamSynchronize(m->stream);
   for (void* p : m->allocs) hipFree(p);
+  for (void* p : m->g_allocs) hipFree(p);
   hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -349,5 +360,189 @@ extern "C" int csm_mimi_stream_decode(csm_mimi_t* m, const int64_t* codes, int T
   if (T < 1 || T > m->c.max_frames) return mfail(CSM_ERR_CAPACITY, "T = %d outside 1..max_frames %d", T, m->c.max_frames);
   if (int r = decode_one(m, codes, T, audio, true)) return r;
   MHIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+
+// ---- stream groups: S streams decoded in lockstep, T frames each per call, every launch covering all of them -------------
+// (one-frame streaming calls are launch-bound: S streams through csm_mimi_stream_decode cost S x 0.8 ms, through a group
+// about one call).  Streams may be restarted one by one (csm_mimi_streams_reset(m, s)): rotary position, history length and
+// left contexts are per stream.  Same arithmetic as decode_one; GEMMs see S times the rows, so they may take another of the
+// three GEMM paths (fp32 summation order: ~1e-6 of the peak against the single-stream result).
+template <typename T>
+static int malloc_g(csm_mimi* m, T** p, size_t n) {
+  void* q = nullptr;
+  if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) return mfail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) failed", n * sizeof(T));
+  m->g_allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+static std::vector<int> conv_cins(const csm_mimi_config_t& c) {
+  int chs = c.num_filters << c.n_ratios;
+  std::vector<int> cins{c.hidden};
+  for (int i = 0; i < c.n_ratios; ++i) { cins.push_back(chs); cins.push_back(chs / 2); chs /= 2; }
+  cins.push_back(chs);
+  return cins;
+}
+
+extern "C" int csm_mimi_streams_reset(csm_mimi_t* m, int stream) {
+  if (!m || m->g_S < 1) return mfail(CSM_ERR_STATE, "no stream group (csm_mimi_streams_open first)");
+  if (stream < -1 || stream >= m->g_S) return mfail(CSM_ERR_ARG, "stream %d outside the group of %d", stream, m->g_S);
+  const std::vector<int> cins = conv_cins(m->c);
+  const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? m->g_S : stream + 1;
+  for (int s = s0; s < s1; ++s) { m->g_frames[s] = 0; m->g_nh[s] = 0; }
+  MHIP(hipMemsetAsync(m->g_up_prev + (size_t)s0 * m->c.hidden, 0, (size_t)(s1 - s0) * m->c.hidden * sizeof(float), m->stream));
+  for (size_t i = 0; i < cins.size(); ++i)
+    MHIP(hipMemsetAsync(m->g_conv[i] + (size_t)s0 * PADR * cins[i], 0, (size_t)(s1 - s0) * PADR * cins[i] * sizeof(float), m->stream));
+  MHIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+extern "C" int csm_mimi_streams_open(csm_mimi_t* m, int S) {
+  if (!m) return mfail(CSM_ERR_ARG, "null argument");
+  const csm_mimi_config_t& c = m->c;
+  if (S < 1 || S > c.max_frames) return mfail(CSM_ERR_CAPACITY, "a group of %d streams needs max_frames >= %d (one frame per stream and call)", S, S);
+  MHIP(hipStreamSynchronize(m->stream));
+  for (void* p : m->g_allocs) hipFree(p);
+  m->g_allocs.clear();
+  m->g_hist[0].clear(); m->g_hist[1].clear(); m->g_conv.clear();
+  m->g_S = 0;
+  const int A = c.heads * c.head_dim, Tg = c.max_frames / S;
+  const size_t L1 = (size_t)Tg * c.up_stride;
+  m->g_hrows = (size_t)(c.window - 1) + L1;
+  // padded convolution inputs [S][PADR + L][C] and the GEMM results over them, stage by stage
+  size_t Lf = L1, padf = (size_t)S * (PADR + L1) * c.hidden;
+  int ch = c.num_filters << c.n_ratios;
+  size_t scrf = (size_t)S * (PADR + L1) * pad128(ch);
+  for (int i = 0; i < c.n_ratios; ++i) {
+    const int co = ch / 2, hid = co / c.compress;
+    padf = std::max(padf, (size_t)S * (PADR + Lf) * ch);
+    scrf = std::max(scrf, (size_t)S * (PADR + Lf) * (size_t)(c.ratios[i] * co));
+    Lf *= c.ratios[i];
+    padf = std::max(padf, (size_t)S * (PADR + Lf) * co);
+    scrf = std::max(scrf, (size_t)S * (PADR + Lf) * (size_t)std::max(pad128(hid), pad128(co)));
+    ch = co;
+  }
+  padf = std::max(padf, (size_t)S * (PADR + Lf) * ch);
+  int r = 0;
+  for (int l = 0; l < c.layers && !r; ++l)
+    for (int pp = 0; pp < 2 && !r; ++pp) {
+      float* h = nullptr;
+      r = malloc_g(m, &h, (size_t)S * m->g_hrows * 2 * A);
+      m->g_hist[pp].push_back(h);
+    }
+  if (!r) r = malloc_g(m, &m->g_up_prev, (size_t)S * c.hidden);
+  const std::vector<int> cins = conv_cins(c);
+  for (size_t i = 0; i < cins.size() && !r; ++i) {
+    float* q = nullptr;
+    r = malloc_g(m, &q, (size_t)S * PADR * cins[i]);
+    m->g_conv.push_back(q);
+  }
+  if (!r) r = malloc_g(m, &m->g_pad, padf);
+  if (!r) r = malloc_g(m, &m->g_scr, scrf);
+  if (!r) r = malloc_g(m, &m->g_meta, (size_t)4 * S);
+  if (r) {
+    for (void* p : m->g_allocs) hipFree(p);
+    m->g_allocs.clear();
+    return r;
+  }
+  m->g_S = S; m->g_T = Tg; m->g_cur = 0;
+  m->g_frames.assign(S, 0); m->g_nh.assign(S, 0); m->g_host.assign((size_t)4 * S, 0);
+  return csm_mimi_streams_reset(m, -1);
+}
+
+// group form of conv1d(): xin / out compact [S * L][C]; cache [S][PADR][Cin]
+static int conv1d_g(csm_mimi* m, const float* xin, size_t L, int Cin, int k, int elu, const float* Wp, int Cout, const float* bias,
+                    int act, float* out, float* cache) {
+  hipStream_t st = m->stream;
+  const int S = m->g_S;
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * Cin)), dim3(256), 0, st, m->g_pad, cache, (const float*)nullptr, S, PADR, L, Cin, 0, 0);
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * L * Cin)), dim3(256), 0, st, m->g_pad, (float*)nullptr, xin, S, PADR, L, Cin, 1, elu);
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * Cin)), dim3(256), 0, st, m->g_pad, cache, (const float*)nullptr, S, PADR, L, Cin, 2, 0);
+  const int Np = pad128(Cout);
+  MLCK(gemm(m, m->g_pad + (size_t)(PADR - (k - 1)) * Cin, Cin, Wp, Np, k * Cin, (size_t)S * (PADR + L) - PADR, m->g_scr, Np));
+  hipLaunchKernelGGL(mimi_bias_act_g_kernel, dim3(nblk((size_t)S * L * Cout)), dim3(256), 0, st, m->g_scr, Np, bias, Cout, Cout, S, PADR, L, act, out);
+  const hipError_t le = hipGetLastError();
+  return le != hipSuccess ? mfail((int)le, "conv1d_g launch failed: %s", hipGetErrorString(le)) : 0;
+}
+
+extern "C" int csm_mimi_streams_decode(csm_mimi_t* m, const int64_t* codes, int T, float* audio) {
+  if (!m || !m->bound || !codes || !audio) return mfail(CSM_ERR_ARG, "null argument / weights not bound");
+  if (m->g_S < 1) return mfail(CSM_ERR_STATE, "no stream group (csm_mimi_streams_open first)");
+  if (T < 1 || T > m->g_T) return mfail(CSM_ERR_CAPACITY, "T = %d outside 1..%d (max_frames / streams)", T, m->g_T);
+  const csm_mimi_config_t& c = m->c;
+  hipStream_t st = m->stream;
+  const int S = m->g_S, H = c.hidden, D = c.codebook_dim, A = c.heads * c.head_dim, F = c.ffn;
+  const size_t L1 = (size_t)T * c.up_stride, R1 = (size_t)S * L1;
+  int* hm = m->g_host.data();
+  for (int s = 0; s < S; ++s) {
+    hm[s] = m->g_frames[s] * c.up_stride;
+    hm[S + s] = m->g_nh[s];
+    hm[2 * S + s] = m->g_frames[s] > 0;
+    hm[3 * S + s] = std::min<int>(c.window - 1, m->g_nh[s] + (int)L1);
+  }
+  MHIP(hipMemcpyAsync(m->g_meta, hm, (size_t)4 * S * sizeof(int), hipMemcpyHostToDevice, st));
+  const int *d_pos0 = m->g_meta, *d_nh = m->g_meta + S, *d_prev = m->g_meta + 2 * S, *d_keep = m->g_meta + 3 * S;
+  int ci = 0;
+  auto cache = [&]() -> float* { return m->g_conv[ci++]; };
+  hipLaunchKernelGGL(mimi_rvq_gather_g_kernel, dim3(T, S), dim3(256), 0, st, codes, m->w.embed, c.n_q, c.n_sem, c.codebook_size, D, T, m->q2);
+  MLCK(gemm(m, m->q2, 2 * D, m->w.out_proj, H, 2 * D, (size_t)S * T, m->e0, H));
+  hipLaunchKernelGGL(mimi_upsample_g_kernel, dim3(nblk(R1 * H)), dim3(256), 0, st, m->e0, m->w.upsample, T, H, c.up_stride, m->g_up_prev, d_prev, S, m->x);
+  MHIP(hipMemcpy2DAsync(m->g_up_prev, (size_t)H * sizeof(float), m->e0 + (size_t)(T - 1) * H, (size_t)T * H * sizeof(float), (size_t)H * sizeof(float), S,
+                        hipMemcpyDeviceToDevice, st));
+  const size_t hstride = m->g_hrows * 2 * A;
+  for (int l = 0; l < c.layers; ++l) {
+    float* hist = m->g_hist[m->g_cur][l];
+    hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)R1), dim3(256), 0, st, m->x, m->w.ln1_w[l], m->w.ln1_b[l], H, c.norm_eps, m->hn);
+    MLCK(gemm(m, m->hn, H, m->w.wqkv[l], 3 * A, H, R1, m->qkv, 3 * A));
+    hipLaunchKernelGGL(mimi_rope_g_kernel, dim3(nblk(R1 * 2 * c.heads * (c.head_dim / 2))), dim3(256), 0, st, m->qkv, (int)L1, c.heads, c.head_dim, c.rope_theta, d_pos0, S);
+    hipLaunchKernelGGL(mimi_kv_append_g_kernel, dim3(nblk(R1 * 2 * A)), dim3(256), 0, st, m->qkv, hist, hstride, d_nh, L1, A, S);
+    hipLaunchKernelGGL(mimi_attn_g_kernel, dim3((unsigned)R1, c.heads), dim3(64), (size_t)(c.head_dim + c.window) * sizeof(float), st, m->qkv, hist, hstride,
+                       d_nh, (int)L1, c.heads, c.head_dim, c.window, m->ao);
+    hipLaunchKernelGGL(mimi_rows_copy_g_kernel, dim3(64, S), dim3(256), 0, st, hist, m->g_hist[m->g_cur ^ 1][l], hstride, d_nh, d_keep, (int)L1, 2 * A);
+    MLCK(gemm(m, m->ao, A, m->w.wo[l], H, A, R1, m->tmp, H));
+    hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(R1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls1[l], R1 * H, H);
+    hipLaunchKernelGGL(mimi_layernorm_kernel, dim3((unsigned)R1), dim3(256), 0, st, m->x, m->w.ln2_w[l], m->w.ln2_b[l], H, c.norm_eps, m->hn);
+    MLCK(gemm(m, m->hn, H, m->w.w1[l], F, H, R1, m->ff, F));
+    hipLaunchKernelGGL(mimi_gelu_kernel, dim3(nblk(R1 * F)), dim3(256), 0, st, m->ff, R1 * F);
+    MLCK(gemm(m, m->ff, F, m->w.w2[l], H, F, R1, m->tmp, H));
+    hipLaunchKernelGGL(mimi_scale_add_kernel, dim3(nblk(R1 * H)), dim3(256), 0, st, m->x, m->tmp, m->w.ls2[l], R1 * H, H);
+  }
+  // ---- SEANet decoder ----
+  int ch = c.num_filters << c.n_ratios;
+  size_t L = L1;
+  float *cbuf = m->bufa, *nxt = m->bufb;
+  if (int r = conv1d_g(m, m->x, L, H, c.kernel_size, 0, m->w.conv0_w, ch, m->w.conv0_b, 0, cbuf, cache())) return r;
+  for (int i = 0; i < c.n_ratios; ++i) {
+    const int rr = c.ratios[i], co = ch / 2, hid = co / c.compress;
+    float* cc = cache();
+    hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * ch)), dim3(256), 0, st, m->g_pad, cc, (const float*)nullptr, S, PADR, L, ch, 0, 0);
+    hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * L * ch)), dim3(256), 0, st, m->g_pad, (float*)nullptr, (const float*)cbuf, S, PADR, L, ch, 1, 1);
+    hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * ch)), dim3(256), 0, st, m->g_pad, cc, (const float*)nullptr, S, PADR, L, ch, 2, 0);
+    MLCK(gemm(m, m->g_pad + (size_t)(PADR - 1) * ch, ch, m->w.up_w[i], rr * co, 2 * ch, (size_t)S * (PADR + L) - PADR, m->g_scr, rr * co));
+    hipLaunchKernelGGL(mimi_bias_act_g_kernel, dim3(nblk((size_t)S * L * rr * co)), dim3(256), 0, st, m->g_scr, rr * co, m->w.up_b[i], co, rr * co, S, PADR, L, 0, nxt);
+    L *= rr;
+    std::swap(cbuf, nxt);   // cbuf = [S * L][co]
+    float* hb = nxt;        // [S * L][hid]
+    if (int r = conv1d_g(m, cbuf, L, co, c.res_kernel_size, 1, m->w.res1_w[i], hid, m->w.res1_b[i], 1, hb, cache())) return r;
+    {
+      const int Np = pad128(co);
+      MLCK(gemm(m, hb, hid, m->w.res2_w[i], Np, hid, (size_t)S * L, m->g_scr, Np));
+      hipLaunchKernelGGL(mimi_bias_act_kernel, dim3(nblk((size_t)S * L * co)), dim3(256), 0, st, m->g_scr, Np, m->w.res2_b[i], co, cbuf, co, (size_t)S * L, 0, cbuf, co);
+    }
+    ch = co;
+  }
+  float* cc = cache();
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * ch)), dim3(256), 0, st, m->g_pad, cc, (const float*)nullptr, S, PADR, L, ch, 0, 0);
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * L * ch)), dim3(256), 0, st, m->g_pad, (float*)nullptr, (const float*)cbuf, S, PADR, L, ch, 1, 1);
+  hipLaunchKernelGGL(mimi_pad_g_kernel, dim3(nblk((size_t)S * PADR * ch)), dim3(256), 0, st, m->g_pad, cc, (const float*)nullptr, S, PADR, L, ch, 2, 0);
+  hipLaunchKernelGGL(mimi_last_conv_g_kernel, dim3((unsigned)((L + 63) / 64), S), dim3(256), 0, st, m->g_pad, m->w.last_w, m->w.last_b, ch, c.last_kernel_size, PADR, L, audio);
+  MHIP(hipGetLastError());
+  MHIP(hipStreamSynchronize(st));
+  for (int s = 0; s < S; ++s) {
+    m->g_frames[s] += T;
+    m->g_nh[s] = hm[3 * S + s];
+  }
+  m->g_cur ^= 1;
   return 0;
 }

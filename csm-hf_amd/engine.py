@@ -31,6 +31,7 @@ EXPORTS = [
     "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
     "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
+    "csm_mimi_streams_open", "csm_mimi_streams_reset", "csm_mimi_streams_decode",
     "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx", "csm_forward_backward",
 ]
 

@@ -313,6 +313,10 @@ class MimiDecoder:
         self.lib.csm_mimi_stream_reset.argtypes = [C.c_void_p]
         self.lib.csm_mimi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         self.lib.csm_mimi_stream_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.csm_mimi_streams_open.argtypes = [C.c_void_p, C.c_int]
+        self.lib.csm_mimi_streams_reset.argtypes = [C.c_void_p, C.c_int]
+        self.lib.csm_mimi_streams_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self.n_streams = 0
         if cfg.num_hidden_layers > _MAX_LAYERS or len(cfg.upsampling_ratios) > _MAX_RATIOS:
             raise ValueError("too many transformer layers / upsampling ratios for csm_mimi_config_t")
         c = _MimiCfg(abi_version=ABI_VERSION, n_q=cfg.num_quantizers, n_sem=cfg.num_semantic_quantizers,
@@ -395,6 +399,38 @@ class MimiDecoder:
         torch.cuda.synchronize(self.device)
         with torch.cuda.device(self.device):
             self._ck(self.lib, self.lib.csm_mimi_stream_decode(self._h, codes.data_ptr(), T, out.data_ptr()))
+        return out
+
+    # ---- stream groups: the rows of a generated batch streamed together, every launch covering all of them --------------
+    def streams_open(self, n_streams: int):
+        """Allocate the state of `n_streams` lockstep streams (replaces an earlier group); a call then takes up to
+        `max_frames // n_streams` frames per stream."""
+        with torch.cuda.device(self.device):
+            self._ck(self.lib, self.lib.csm_mimi_streams_open(self._h, int(n_streams)))
+        self.n_streams = int(n_streams)
+
+    def streams_reset(self, stream: Optional[int] = None):
+        """Restart one stream of the group (a batch row taken over by a new utterance), or all of them (`None`)."""
+        self._ck(self.lib, self.lib.csm_mimi_streams_reset(self._h, -1 if stream is None else int(stream)))
+
+    def streams_decode(self, audio_codes: torch.Tensor) -> torch.Tensor:
+        """`audio_codes` [S, n_q, T]: the NEW frames of every stream of the group (e.g. `frames.permute(0, 2, 1)` of the frames one
+        `generate_frame` / one chunk of `generate` produced for the batch); returns `[S, 1, T * samples_per_frame]`.  One pass over
+        the codec for all S streams: a one-frame call for 16 / 64 streams costs about what one stream costs alone."""
+        if self.n_streams < 1:
+            raise RuntimeError("no stream group: call streams_open(n_streams) first")
+        if audio_codes.dim() != 3 or audio_codes.shape[0] != self.n_streams or audio_codes.shape[1] != self.cfg.num_quantizers:
+            raise ValueError(f"audio_codes must be [{self.n_streams}, {self.cfg.num_quantizers}, T], got {tuple(audio_codes.shape)}")
+        S, _, T = audio_codes.shape
+        if T < 1 or S * T > self.max_frames:
+            raise ValueError(f"T = {T} outside 1..{self.max_frames // S} (max_frames // n_streams)")
+        if int(audio_codes.min()) < 0 or int(audio_codes.max()) >= self.cfg.codebook_size:
+            raise ValueError("audio codes outside the codebook")
+        codes = audio_codes.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(S, 1, T * self.cfg.samples_per_frame, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib, self.lib.csm_mimi_streams_decode(self._h, codes.data_ptr(), T, out.data_ptr()))
         return out
 
     def close(self):

@@ -204,6 +204,15 @@ int csm_mimi_decode(csm_mimi_t* m, const int64_t* codes, int B, int T, float* au
  * modeling_mimi.py:73-166, 1388-1406), so the concatenated chunks equal one csm_mimi_decode of the whole sequence */
 int csm_mimi_stream_reset(csm_mimi_t* m);
 int csm_mimi_stream_decode(csm_mimi_t* m, const int64_t* codes, int T, float* audio);
+/* stream GROUPS (round 3): S streams -- the rows of a generated batch (reference call site README.md:114-118, applied frame by
+ * frame to every row of `generate`'s output) -- advance in lockstep, T <= max_frames / S frames each per call, and every launch
+ * covers all of them: codes [S][n_q][T] -> audio [S][T * samples_per_frame].  csm_mimi_streams_open allocates the group's state
+ * (and replaces an earlier group); csm_mimi_streams_reset(m, s) restarts stream s alone (s = -1: all), so a batch row taken
+ * over by a new utterance (continuous batching) starts from silence while the others continue.  Each stream's chunks
+ * concatenate to csm_mimi_decode of its whole sequence (fp32 summation order of the GEMM paths aside). */
+int csm_mimi_streams_open(csm_mimi_t* m, int S);
+int csm_mimi_streams_reset(csm_mimi_t* m, int stream);
+int csm_mimi_streams_decode(csm_mimi_t* m, const int64_t* codes, int T, float* audio);
 
 /* ---- continuous batching (no reference counterpart): a new utterance takes over batch row
  * `row` of the running batch between two frame-steps.  ids [S][C+1] / mask [S][C+1] on the device; S <= the batch's

@@ -281,3 +281,58 @@ def test_streams_side_by_side_on_one_weight_set():
     assert torch.equal(again[0], whole[1])
     decs[1].close()
     decs[2].close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_stream_group_equals_each_streams_one_shot_decode(name):
+    """csm_mimi_streams_* (round 3): S streams advance in lockstep and every launch covers all of them.  Each stream's chunks
+    must concatenate to the ONE-SHOT decode of its own sequence: against the oracle at the codec's 1e-4 of the peak and
+    against the single-stream HIP decode at 1e-5 (the GEMMs see S times the rows and may take another of the three GEMM
+    paths: fp32 summation order).  Ragged chunk sizes, the attention window wrapping (tiny: window 6), and one stream
+    RESTARTED in the middle (a batch row taken over by a new utterance) while the others continue."""
+    from csm_hf_amd import MimiDecoder
+    cfg = CASES[name]
+    sd = synth_mimi_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(17)
+    S, T = (5, 36) if name == "tiny" else (4, 14)
+    codes = torch.randint(0, cfg.codebook_size, (S, cfg.num_quantizers, T), generator=gen)
+    new_row = torch.randint(0, cfg.codebook_size, (cfg.num_quantizers, T), generator=gen)   # the utterance that takes over stream 2
+    dec = MimiDecoder(cfg, sd, "cuda:0", max_frames=64)
+    cd = codes.to("cuda:0")
+    whole = dec.decode(cd)                                                   # [S, 1, T * spf], single-stream passes
+    want = MO.decode(sd, cfg, codes)
+    assert rel_max(whole.cpu(), want) < 1e-4
+    spf = cfg.samples_per_frame
+    dec.streams_open(S)
+    with pytest.raises(ValueError):
+        dec.streams_decode(cd[:, :, :1].repeat(1, 1, 64 // S + 1))           # more frames per call than max_frames // S
+    restart_at = T // 2
+    parts, t, chunks = [], 0, (1, 3, 2, 1, 4)
+    cur = cd.clone()
+    i = 0
+    restarted = False
+    while t < T:
+        n = min(chunks[i % len(chunks)], T - t, 64 // S)
+        if not restarted and t >= restart_at:
+            dec.streams_reset(2)                                             # stream 2 starts a new utterance at frame t
+            cur[2, :, t:] = new_row[:, :T - t].to("cuda:0")
+            restarted, t_restart = True, t
+        parts.append(dec.streams_decode(cur[:, :, t:t + n]).clone())
+        t += n
+        i += 1
+    got = torch.cat(parts, dim=-1)
+    for s in range(S):
+        if s == 2:
+            continue
+        assert rel_max(got[s].cpu(), want[s]) < 1e-4, s
+        assert rel_max(got[s].cpu(), whole[s].cpu()) < 1e-5, s
+    # stream 2: the old utterance up to the restart, then the new one from silence
+    assert rel_max(got[2, :, :t_restart * spf].cpu(), want[2, :, :t_restart * spf]) < 1e-4
+    fresh = MO.decode(sd, cfg, new_row[None, :, :T - t_restart])
+    assert rel_max(got[2, :, t_restart * spf:].cpu(), fresh[0]) < 1e-4
+    # a new group replaces the old one; all streams from silence again
+    dec.streams_open(2)
+    two = torch.cat([dec.streams_decode(cd[:2, :, a:a + 2]) for a in range(0, T - T % 2, 2)], dim=-1)
+    assert rel_max(two.cpu(), want[:2, :, :two.shape[-1]]) < 1e-4
+    dec.close()

@@ -8,8 +8,12 @@ for l in sys.stdin:
 " "$@"; }
 {
 run --steps 200
-for k in 32 64 96 1 127 8063; do run --steps 200 --opt dbg_skip=$k; done
+run --steps 200 --opt dbg_skip=128
+run --steps 200
+run --steps 200 --opt dbg_skip=128
+run --steps 200 --kv-dtype bf16
+run --steps 200 --kv-dtype bf16 --opt dbg_skip=128
 run --steps 200 --opt weight_prefetch=0
-for k in 32 64 1 127; do run --steps 200 --opt weight_prefetch=0 --opt dbg_skip=$k; done
-} > $O/ablate4.txt 2>&1
-cat $O/ablate4.txt
+run --steps 200 --opt weight_prefetch=0 --opt dbg_skip=128
+} > $O/ablate5.txt 2>&1
+cat $O/ablate5.txt
