@@ -59,6 +59,23 @@ print(f"streaming, 1 frame (80 ms of audio) per call: median {med * 1e3:.2f} ms 
 print(json.dumps({"workload": "mimi stream_decode, kyutai/mimi shape, 1 frame per call", "ms": round(med * 1e3, 3),
                   "roofline": {"bound": "hbm", "achieved": round(wb1 / med / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(wb1 / med / 1e9 / HBM_PEAK_GBS, 4), "weight_bytes": wb1}}), flush=True)
+# stream groups (csm_mimi_streams_*): S streams, one frame each per call, every launch covering all of them
+for S in (1, 4, 16, 64):
+    if S > dec.max_frames:
+        break
+    gc = torch.randint(0, cfg.codebook_size, (S, cfg.num_quantizers, 40), generator=g).to("cuda:0")
+    dec.streams_open(S)
+    ts = []
+    for t in range(40):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.streams_decode(gc[:, :, t:t + 1])
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[8:])
+    mg = ts[len(ts) // 2]
+    print(f"stream group, {S:3d} streams x 1 frame per call: median {mg * 1e3:.2f} ms per call = {mg * 1e3 / S:.3f} ms per stream "
+          f"({S * med / mg:.1f} x the throughput of {S} single-stream calls); {0.08 / mg * S:.0f} stream-seconds per second", flush=True)
 try:
     from transformers import MimiConfig, MimiModel
     m = MimiModel(MimiConfig()).eval()
