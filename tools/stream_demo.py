@@ -51,3 +51,35 @@ steady_g, steady_w = t_gen[5:], t_wav[5:]
 print(f"{n} frames after a {ctx}-frame context: first step (prefill + frame + waveform) {(t_gen[0] + t_wav[0]) * 1e3:.1f} ms; then per 80 ms frame: "
       f"generate_frame median {med(steady_g):.2f} ms + waveform {med(steady_w):.2f} ms = {med(steady_g) + med(steady_w):.2f} ms "
       f"(max {max(a + b for a, b in zip(steady_g, steady_w)) * 1e3:.2f} ms) = {80.0 / (med(steady_g) + med(steady_w)):.1f} x real time; {samples} samples")
+
+# ---- a BATCH streamed to audio frame by frame: B rows through the same generate_frame loop, every frame of every row decoded
+# by ONE stream-group call (csm_mimi_streams_*: all B streams in every launch) ----
+for B in (16, 64):
+    gdec = MimiDecoder(mc, None, dev, max_frames=max(8, B), _packed=dec.packed)      # the same device weights
+    gdec.streams_open(B)
+    ids, mask = synth_context(cfg, B, ctx // 4, ctx - ctx // 4, seed=3)
+    cur, cm, pkv = ids.to(dev), mask.to(dev), None
+    m.setup_caches(B)
+    t_gen, t_wav = [], []
+    nb = min(n, 40)
+    for i in range(nb):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = m.generate_frame(cur, cm, temperature=0.9, topk=50, past_key_values=pkv, return_dict=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        codes = out.samples.clamp(max=mc.codebook_size - 1).unsqueeze(-1).contiguous()       # [B, 32, 1]
+        wav = gdec.streams_decode(codes)                                                     # [B, 1, 1920]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        t_gen.append(t1 - t0)
+        t_wav.append(t2 - t1)
+        pkv = out.past_key_values
+        cur = torch.cat([out.samples, torch.zeros(B, 1, dtype=torch.long, device=dev)], 1).unsqueeze(1)
+        cm = torch.zeros(B, 1, 33, dtype=mask.dtype, device=dev)
+        cm[:, :, :32] = 1
+    g, w = med(t_gen[5:]), med(t_wav[5:])
+    print(f"batch of {B} rows, {nb} frames each: generate_frame median {g:.2f} ms + stream-group waveform {w:.2f} ms = {g + w:.2f} ms per "
+          f"80 ms frame-step = {80.0 / (g + w):.1f} x real time for every one of the {B} streams ({B * 1e3 / (g + w):.0f} frames/s with audio; "
+          f"{B} single-stream codec calls would add {B * med(steady_w):.1f} ms)")
+    gdec.close()
