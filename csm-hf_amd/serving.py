@@ -23,7 +23,7 @@ import torch
 
 class ContinuousBatcher:
     def __init__(self, model, batch_size: int, temperature: float = 1.0, topk: int = 50, max_new_frames: int = 100,
-                 check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None):
+                 check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None, audio_decoder=None):
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
         self.model = model
@@ -35,6 +35,11 @@ class ContinuousBatcher:
         self.initial_frames = initial_frames   # frames of cache room reserved up front (default: every queued budget, <= 4096)
         self._queue = deque()
         self._next_id = 0
+        # optional `MimiDecoder`: every chunk of frames is decoded to audio by ONE stream-group call for the whole batch
+        # (csm_mimi_streams_*), a row's stream is restarted when a new utterance takes the row over; `self.audio` then holds
+        # {request id: waveform [n * samples_per_frame]} (CPU) next to the frames `run()` returns
+        self.audio_decoder = audio_decoder
+        self.audio: Dict[int, torch.Tensor] = {}
         self.joined_mid_batch = 0      # utterances that took over a row of a running batch (statistics)
         self.shifted_for_long_context = 0   # joins whose context was longer than the running batch (resident rows moved up)
 
@@ -84,6 +89,13 @@ class ContinuousBatcher:
         eng.prefill(ids, mask, want_outputs=False)
         s = eng.sampling(temperature=self.temperature, topk=self.topk, seed=m._next_seed() if self.seed is None else int(self.seed),
                          row_offset=m.row_offset, per_row_stop=True)
+        dec = self.audio_decoder
+        if dec is not None:
+            if dec.max_frames < B:
+                raise ValueError(f"audio_decoder.max_frames ({dec.max_frames}) must be at least the batch size ({B})")
+            dec.streams_open(B)
+            spf = dec.cfg.samples_per_frame
+            waves = [[] for _ in range(B)]
         while any(r is not None for r in rows):
             if eng.frames + k > eng.max_frames:
                 eng.rewind_frames()                 # every frame so far has been read out
@@ -91,23 +103,40 @@ class ContinuousBatcher:
                 eng = m._ensure_engine(B, eng.length + k + 1, max(4 * k, 32), 1, cont=True)   # re-homed, never restarted
             f0 = eng.frames
             eng.generate(s, k, m.use_graph)
-            toks = eng.read_frames(f0, k).cpu()
+            toks_dev = eng.read_frames(f0, k)
+            toks = toks_dev.cpu()
+            wav = None
+            if dec is not None:
+                # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of
+                # idle / finished rows are decoded too and dropped; ids beyond the codec's codebook cannot come from a real model)
+                codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k]
+                step = max(1, dec.max_frames // B)
+                wav = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1).cpu()   # [B, 1, k * spf]
             for b, r in enumerate(rows):
                 if r is None:
                     continue
                 done = False
+                took = 0
                 for i in range(k):
                     if bool((toks[b, i] == 0).all()) or len(r[2]) >= r[1]:
                         done = True
                         break
                     r[2].append(toks[b, i])
+                    took += 1
+                if wav is not None and took:
+                    waves[b].append(wav[b, 0, :took * spf])
                 if done or len(r[2]) >= r[1]:
                     results[r[0]] = torch.stack(r[2]) if r[2] else torch.zeros(0, C, dtype=torch.long)
+                    if dec is not None:
+                        self.audio[r[0]] = torch.cat(waves[b]) if waves[b] else torch.zeros(0)
+                        waves[b] = []
                     rows[b] = None
             # every idle row (just finished, or idle since an earlier chunk) is offered the queue
             for b in range(B):
                 if rows[b] is None and self._queue:
                     rows[b], eng = self._join(eng, b, k)
+                    if dec is not None:
+                        dec.streams_reset(b)        # the row's audio stream starts from silence with the new utterance
         m._epoch += 1
 
     def _join(self, eng, row, k):

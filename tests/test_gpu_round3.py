@@ -624,3 +624,38 @@ def test_sampling_from_torchs_global_generator_csm1b(gold):
     first = int(diff[0]) if diff.numel() else got.numel()
     assert first >= 32, f"first differing draw at {first}"
     assert first == got.numel(), f"draw {first} differs (a race closer than the fp32 noise?)"
+
+
+def test_continuous_batcher_streams_every_utterance_to_audio():
+    """f-4 + f-2 together (round 3): `ContinuousBatcher(audio_decoder=MimiDecoder)` decodes every chunk of frames of the WHOLE batch
+    with one stream-group call (csm_mimi_streams_*) and restarts a row's audio stream when a new utterance takes the row over.
+    Every utterance's waveform must be the ONE-SHOT codec decode of exactly its own frames (1e-5 of the peak: GEMM path /
+    summation order), whatever happened in its row before (another utterance's frames, frames past a budget) and while
+    other rows joined."""
+    from csm_hf_amd import ContinuousBatcher, MimiDecoder, MimiDecodeConfig
+    from csm_hf_amd.mimi import synth_mimi_state_dict
+    cfg, sd, m = tiny_model()
+    mc = MimiDecodeConfig.tiny()
+    msd = synth_mimi_state_dict(mc, seed=0)
+    dec = MimiDecoder(mc, msd, DEV, max_frames=16)
+    reqs = []
+    for i, (nt, na, budget) in enumerate([(3, 6, 5), (2, 4, 11), (2, 5, 4), (1, 4, 7), (3, 5, 6), (2, 9, 3), (2, 3, 9)]):
+        ids, mask = synth_context(cfg, 1, nt, na, seed=300 + i)
+        reqs.append((ids[0], mask[0], budget))
+    cb = ContinuousBatcher(m, batch_size=3, temperature=1.0, topk=1, check_every=3, audio_decoder=dec)
+    rid = [cb.submit(i, k, max_new_frames=b) for i, k, b in reqs]
+    out = cb.run()
+    assert sorted(out) == sorted(rid) == sorted(cb.audio) and cb.joined_mid_batch >= 3
+    ref = MimiDecoder(mc, msd, DEV, max_frames=16)
+    spf = mc.samples_per_frame
+    for r, (_, _, budget) in zip(rid, reqs):
+        frames = out[r]
+        assert frames.shape == (budget, 32)
+        codes = frames.clamp(max=mc.codebook_size - 1).t()[None].contiguous()           # [1, 32, n]
+        want = ref.decode(codes.to(DEV))[0, 0].cpu()
+        got = cb.audio[r]
+        assert got.shape == (budget * spf,), (r, got.shape)
+        assert float((got - want).abs().max() / want.abs().max().clamp_min(1e-20)) < 1e-5, r
+    dec.close()
+    ref.close()
+    m._drop_engine()
