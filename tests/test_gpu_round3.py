@@ -634,8 +634,9 @@ def test_continuous_batcher_streams_every_utterance_to_audio():
     other rows joined."""
     from csm_hf_amd import ContinuousBatcher, MimiDecoder, MimiDecodeConfig
     from csm_hf_amd.mimi import synth_mimi_state_dict
+    import dataclasses
     cfg, sd, m = tiny_model()
-    mc = MimiDecodeConfig.tiny()
+    mc = dataclasses.replace(MimiDecodeConfig.tiny(), num_quantizers=32)          # the tiny codec with CSM's 32 codebooks
     msd = synth_mimi_state_dict(mc, seed=0)
     dec = MimiDecoder(mc, msd, DEV, max_frames=16)
     reqs = []
