@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Continuous batching (csm_hf_amd.serving.ContinuousBatcher) against static batches on csm-1b: N utterances with
 512-frame contexts... kept short here: contexts of 64-128 frames, frame budgets 20-200, batch of 16 rows.
-usage: python tools/serve_bench.py [n_utterances] [batch]"""
+usage: python tools/serve_bench.py [n_utterances] [batch] [audio]"""
 import os
 import sys
 import time
@@ -29,8 +29,15 @@ for i in range(N):
     ids, mask = synth_context(cfg, 1, T // 4, T - T // 4, seed=500 + i)
     reqs.append((ids[0], mask[0], budget))
 total = sum(r[2] for r in reqs)
-for label in ("warm-up", "continuous"):
-    cb = ContinuousBatcher(m, batch_size=B, topk=1, check_every=8)
+AUDIO = len(sys.argv) > 3 and sys.argv[3] == "audio"      # third argument "audio": every utterance also leaves as a waveform
+dec = None
+if AUDIO:
+    from csm_hf_amd import MimiDecoder, MimiDecodeConfig
+    from csm_hf_amd.mimi import synth_mimi_state_dict
+    mc = MimiDecodeConfig()
+    dec = MimiDecoder(mc, synth_mimi_state_dict(mc, seed=0, device=dev), dev, max_frames=max(64, 8 * B))   # one group call per chunk of 8 frames
+for label in (("warm-up", "continuous", "continuous+audio") if AUDIO else ("warm-up", "continuous")):
+    cb = ContinuousBatcher(m, batch_size=B, topk=1, check_every=8, audio_decoder=dec if label == "continuous+audio" else None)
     for ids, mask, budget in (reqs[:B] if label == "warm-up" else reqs):
         cb.submit(ids, mask, max_new_frames=budget if label != "warm-up" else 16)
     torch.cuda.synchronize()
@@ -40,8 +47,12 @@ for label in ("warm-up", "continuous"):
     dt = time.perf_counter() - t0
     if label != "warm-up":
         assert sum(v.shape[0] for v in out.values()) == total
-        print(f"continuous batching : {N} utterances, {total} frames, batch {B}: {dt:.2f} s = {total / dt:.0f} useful frames/s "
-              f"({cb.joined_mid_batch} utterances joined a running batch)", flush=True)
+        extra = ""
+        if label == "continuous+audio":
+            secs = sum(v.numel() for v in cb.audio.values()) / 24000.0
+            extra = f"; {secs:.0f} s of 24 kHz audio decoded on the way = {secs / dt:.0f} x real time in total"
+        print(f"{label:20s}: {N} utterances, {total} frames, batch {B}: {dt:.2f} s = {total / dt:.0f} useful frames/s "
+              f"({cb.joined_mid_batch} utterances joined a running batch){extra}", flush=True)
 # static batches (the reference's rule: a batch runs until its longest row is done), same rows per batch, FIFO order
 torch.cuda.synchronize()
 t0 = time.perf_counter()
