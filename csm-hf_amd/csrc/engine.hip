@@ -45,6 +45,7 @@ int configure_sample();
 int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz);
 int launch_widen(hipStream_t st, int wdtype, const void* src, float* dst, size_t n);
 int gemv_configure_all();
+int gemm32_configure_all();
 int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math);
 int launch_ce_rows(hipStream_t st, const CeArgs& a);
 int launch_ce_reduce(hipStream_t st, const float* row_loss, const int* labels, int V, int rows, double* acc);
@@ -283,6 +284,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   if (cfg->n_codebooks < 2) return fail(CSM_ERR_ARG, "n_codebooks must be >= 2");
   HIPCK(hipSetDevice(device));
   LCK(gemv_configure_all());
+  LCK(gemm32_configure_all());
   LCK(configure_sample());
   csm_engine* e = new csm_engine();
   e->cfg = *cfg;

@@ -293,5 +293,6 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
 #endif  // CSM_ARGS_ONLY
 
 // 17..64 rows (two or four batch tiles per weight fragment); needs a.xplanes and a.Wt; returns -2 when the shape is not covered
+int gemm32_configure_all();   // dynamic-LDS attributes of the 64-row instantiations (call once per engine, outside capture)
 int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                   size_t slab_floats, int* tickets, int n_tickets);

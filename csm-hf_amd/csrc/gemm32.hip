@@ -12,6 +12,7 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 16 * MT) * sizeof(float);
   auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT, MT>;
   if (lds > 64 * 1024) {   // four batch tiles x two weight tiles: 72 KiB -- raise the dynamic-LDS limit once per DEVICE
+    // (gemm32_configure_all() does this at engine creation, outside any stream capture; this is the safety net)
     static unsigned long long configured = 0ull;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -21,6 +22,7 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
       configured |= bit;
     }
   }
+  if (a.configure_only) return 0;
   hipLaunchKernelGGL(fn, dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
@@ -67,7 +69,28 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
 
 int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                   size_t slab_floats, int* tickets, int n_tickets) {
-  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 64 || !a.xplanes || !a.Wt || a.configure_only) return -2;
+  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 64 || !a.xplanes || !a.Wt) return -2;
   if (wdtype == 2) return launch_gemm32_t<fp8_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
   return launch_gemm32_t<bf16_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
+}
+
+// the dynamic-LDS limit of every instantiation that needs more than 64 KiB (four batch tiles x two weight tiles), once per
+// engine = per device, outside any stream capture (the launches themselves run inside captured frame-steps)
+int gemm32_configure_all() {
+  static bf16_t dummy_planes[8];
+  GemvArgs a{};
+  a.configure_only = 1;
+  a.xplanes = dummy_planes; a.Wt = dummy_planes;
+  a.K = 1024; a.N = 2048; a.ldo = 2048; a.hd = 128; a.n_q = 8; a.n_kv = 2;
+  static const int combos[4][2] = {{PRO_NORM, EPI_QKV}, {PRO_NORM, EPI_SWIGLU}, {PRO_PLAIN, EPI_RESID}, {PRO_NORM, EPI_STORE}};
+  for (int wd = 1; wd <= 2; ++wd)
+    for (int kd = 0; kd < 2; ++kd)
+      for (auto& c : combos)
+        for (int K : {1024, 8192}) {   // KB == 1 and the K-split panel choice of the residual launches
+          if (K == 8192 && c[0] == PRO_NORM) continue;
+          a.K = K;
+          const int r = launch_gemm32(nullptr, wd, kd, 64, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
+          if (r != 0 && r != -2) return r;
+        }
+  return 0;
 }
