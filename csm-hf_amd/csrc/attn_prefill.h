@@ -19,6 +19,8 @@ struct PrefillAttnArgs {
   float* out;           // [B*S][n_q*64]
   bf16_t* oplanes;      // nullable: output as row-major planes [3][B*S][n_q*64] for the o_proj GEMM instead of `out`
   size_t plane_stride;
+  const int* seq_slot;  // nullable: sequence b of this launch lives in cache slot seq_slot[b] (continuous batching: several rows of a
+                        // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
   int ksplit_groups;    // host-side A/B: 2 = two key groups per workgroup from 256 visible positions on, 3 = the same at <= 128 VGPRs; else one
 };
 
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const bool head_live = wave < G;
   const int h = j * G + (head_live ? wave : 0);
-  const int kv_lo = a.kv_start ? a.kv_start[b] : 0;
+  const int bs = a.seq_slot ? a.seq_slot[b] : b;   // cache slot of this sequence
+  const int kv_lo = a.kv_start ? a.kv_start[bs] : 0;
   const int s_last = min(a.S - 1, s0 + 31);
   const int kmax = a.past + s_last;  // last key any row of this tile may see
   const int s = s0 + li;             // this lane's query row
@@ -55,8 +58,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillAttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 32; ++t) qreg[t] = row_live ? qrow[2 * t] : 0.f;
   }
-  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
-  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)bs * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)bs * a.n_kv + j) * (size_t)a.lmax * HD;
 
   f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);   // O^T tiles: d = (reg&3) + 8*(reg>>2) + 4*lh (+32), row = li
   float m_run = -INFINITY, l_run = 0.f;
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
   const int li = lane & 31, lh = lane >> 5;
   const bool head_live = wave < G;
   const int h = j * G + (head_live ? wave : 0);
-  const int kv_lo = a.kv_start ? a.kv_start[b] : 0;
+  const int bs = a.seq_slot ? a.seq_slot[b] : b;   // cache slot of this sequence
+  const int kv_lo = a.kv_start ? a.kv_start[bs] : 0;
   const int s_last = min(a.S - 1, s0 + 31);
   const int kmax = a.past + s_last;
   const int s = s0 + li;
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
       qf[t] = row_live ? ap_pack8(x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]) : (ap_bf16x8)(0);
     }
   }
-  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
-  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)bs * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)bs * a.n_kv + j) * (size_t)a.lmax * HD;
 
   f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);
   // running reference in log2 units.  It is NOT the running max: it only moves when a tile's max exceeds it by more than
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(256) void attn_prefill_x3_kernel(PrefillAttnArgs a)
   const int li = lane & 31, lh = lane >> 5;
   const bool head_live = wave < G;
   const int h = j * G + (head_live ? wave : 0);
-  const int kv_lo = a.kv_start ? a.kv_start[b] : 0;
+  const int bs = a.seq_slot ? a.seq_slot[b] : b;   // cache slot of this sequence
+  const int kv_lo = a.kv_start ? a.kv_start[bs] : 0;
   const int s_last = min(a.S - 1, s0 + 31);
   const int kmax = a.past + s_last;
   const int s = s0 + li;
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(256) void attn_prefill_x3_kernel(PrefillAttnArgs a)
       ap_split3(x, qf[0][t], qf[1][t], qf[2][t]);
     }
   }
-  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
-  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)bs * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)bs * a.n_kv + j) * (size_t)a.lmax * HD;
 
   f32x16 o0 = (f32x16)(0.f), o1 = (f32x16)(0.f);
   float m_run = -INFINITY, l_run = 0.f;

@@ -39,6 +39,7 @@ int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
+int launch_rows_slots(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past, const int* slots);
 int launch_set_int(hipStream_t st, int* p, int v);
 int launch_set_rng(hipStream_t st, uint64_t* p, uint64_t seed, uint64_t row_offset);
 int configure_sample();
@@ -238,6 +239,8 @@ struct csm_engine {
   int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
   int gemv_norm_ks = 1;   // B = 1, K = 2048 normed launches on the register GEMV with two waves per task: bit 0 the backbone QKV (3.134 -> 3.103 ms
                           // per step, tokens unchanged), bit 1 gate/up (measured slower: off); profiles/r03_b1_ab.txt
+  int* p_seq_slot = nullptr;   // set around stack_rows by csm_prefill_slots: sequence b of the prefill lives in cache slot p_seq_slot[b]
+  int* d_slots = nullptr;      // [max_batch] device copy of the slots of one csm_prefill_slots call
   int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bit 5 the fused B = 1 attention + o_proj launch, bit 6 the B = 1 fused-argmax heads, bits 8-12 the same five for the backbone
@@ -1165,7 +1168,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, e->prefill_bf16_attn ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     if (fr == -2) {
       AttnArgs t{};
@@ -1277,7 +1280,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, (one && e->prefill_bf16_attn) ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     bool att_pl = pl && fr != -2;
@@ -1423,6 +1426,55 @@ extern "C" int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, co
   a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;
   a.x = hl; a.ldx = Hb; a.ln = s.final_norm; a.eps = s.c.rms_eps; a.out = e->head_out + (size_t)row * e->ld_head; a.ldo = e->ld_head;
   return gemv_rows(e, 1, PRO_NORM, EPI_STORE, a);
+}
+
+// Several utterances take over several rows of the running batch in ONE prefill (round 3): contexts ids / mask [n][S][C+1],
+// left-padded by the caller to the common S (mask 0 on the pad frames), lens[i] = true frames of context i, rows[i] = its batch
+// row.  The same result as n csm_prefill_slot calls (a left-padded row equals its solo run: kv_start hides the pad positions)
+// at the cost of one short prefill instead of n -- a joining context of 64-128 frames costs ~2 ms whatever its length, and the
+// whole batch waits for it.  Needs n * S <= max_prefill_rows and S <= the batch's current length (else -2: one by one).
+extern "C" int csm_prefill_slots(csm_engine_t* e, const int32_t* rows, const int32_t* lens, int n, const int64_t* ids, const uint8_t* mask, int S) {
+  if (!e || !e->bound || !ids || !rows || !lens) return fail(CSM_ERR_ARG, "null argument");
+  if (!e->ready || e->B < 1) return fail(CSM_ERR_STATE, "no running batch (csm_prefill first)");
+  if (n < 1 || n > e->B) return fail(CSM_ERR_ARG, "%d joining rows for a batch of %d", n, e->B);
+  if (S < 1 || S > e->h_len || (size_t)n * S > (size_t)e->cfg.max_prefill_rows)
+    return fail(CSM_ERR_CAPACITY, "joint slot prefill of %d x %d frames does not fit (batch length %d, max_prefill_rows %d)", n, S, e->h_len, e->cfg.max_prefill_rows);
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] < 0 || rows[i] >= e->B || lens[i] < 1 || lens[i] > S) return fail(CSM_ERR_ARG, "bad row / length at %d", i);
+    for (int j = 0; j < i; ++j) if (rows[j] == rows[i]) return fail(CSM_ERR_ARG, "row %d listed twice", rows[i]);
+  }
+  Stack& s = e->bb;
+  const int Hb = s.c.hidden, past0 = e->h_len - S;
+  if (!e->d_slots) { int r; if ((r = dalloc(e, &e->d_slots, (size_t)e->cfg.max_batch))) return r; }
+  HIPCK(hipMemcpyAsync(e->d_slots, rows, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  for (int i = 0; i < n; ++i) {
+    LCK(launch_set_int(e->stream, e->d_kv_start + rows[i], e->h_len - lens[i]));
+    if (e->d_row_done) LCK(launch_set_int(e->stream, e->d_row_done + rows[i], 0));
+  }
+  const int R = n * S;
+  LCK(launch_rows_slots(e->stream, e->p_row_seq, e->p_row_pos, R, S, past0, e->d_slots));
+  EmbedArgs em{};
+  em.text_emb = e->w.text_emb; em.audio_emb = e->w.audio_emb; em.H = Hb; em.C = e->cfg.n_codebooks; em.V = e->cfg.audio_vocab;
+  em.ids = ids; em.mask = mask; em.out = e->p_h;
+  LCK(launch_embed(e->stream, emb_dtype(e), R, em));
+  int pending = 0;
+  size_t part_stride = 0;
+  e->p_seq_slot = e->d_slots;
+  const int sr = stack_rows(e, s, s.kc.data(), s.vc.data(), s.lmax, n, S, past0, e->d_kv_start, nullptr, true, &pending, &part_stride);
+  e->p_seq_slot = nullptr;
+  if (sr) return sr;
+  for (int i = 0; i < n; ++i) {
+    const size_t last = (size_t)i * S + (S - 1);
+    const float* hl = e->p_h + last * Hb;
+    LCK(launch_rmsnorm(e->stream, hl, Hb, s.final_norm, 1, Hb, s.c.rms_eps, e->last_h + (size_t)rows[i] * Hb, Hb, nullptr, 0, 0, nullptr, 0,
+                       pending > 1 ? e->p_part + last * Hb : nullptr, pending, part_stride, Hb));
+    GemvArgs a{};
+    a.nt = e->nt_backbone;
+    a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;
+    a.x = hl; a.ldx = Hb; a.ln = s.final_norm; a.eps = s.c.rms_eps; a.out = e->head_out + (size_t)rows[i] * e->ld_head; a.ldo = e->ld_head;
+    LCK(gemv_rows(e, 1, PRO_NORM, EPI_STORE, a));
+  }
+  return 0;
 }
 
 // Continuous batching, contexts longer than the running batch: every cached position of the resident batch moves `delta`

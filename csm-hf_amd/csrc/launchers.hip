@@ -334,6 +334,14 @@ __global__ void rows_iota_kernel(int* row_seq, int* row_pos, int R, int S, int p
   }
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+// rows of several sequences that live in arbitrary cache slots (csm_prefill_slots): row r belongs to sequence r / S = slot slots[r / S]
+__global__ void rows_slots_kernel(int* row_seq, int* row_pos, int R, int S, int past, const int* slots) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) {
+    row_seq[r] = slots[r / S];
+    row_pos[r] = past + r % S;
+  }
+}
 
 template <typename WT>
 __global__ void widen_rows_kernel(const WT* src, float* dst, size_t n) {
@@ -381,6 +389,10 @@ int launch_tile16(hipStream_t st, const void* W, void* Wt, int N, int K, int esz
 
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past) {
   hipLaunchKernelGGL(rows_iota_kernel, dim3((R + 255) / 256), dim3(256), 0, st, row_seq, row_pos, R, S, past);
+  return (int)hipGetLastError();
+}
+int launch_rows_slots(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past, const int* slots) {
+  hipLaunchKernelGGL(rows_slots_kernel, dim3((R + 255) / 256), dim3(256), 0, st, row_seq, row_pos, R, S, past, slots);
   return (int)hipGetLastError();
 }
 int launch_set_int(hipStream_t st, int* p, int v) {

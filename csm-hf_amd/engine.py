@@ -28,7 +28,7 @@ EXPORTS = [
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
     "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
-    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot",
+    "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot", "csm_prefill_slots",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
     "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
     "csm_mimi_streams_open", "csm_mimi_streams_reset", "csm_mimi_streams_decode",
@@ -145,6 +145,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_prefill_slot.argtypes = [vp, i32, vp, vp, i32]
+    lib.csm_prefill_slots.argtypes = [vp, vp, vp, i32, vp, vp, i32]
     lib.csm_shift_context.argtypes = [vp, i32]
     lib.csm_bind_mx_weights.argtypes = [vp, C.POINTER(MxLayer), i32]
     lib.csm_mx_quantize.argtypes = [vp, vp, i32, i32, vp, vp]
@@ -490,6 +491,32 @@ class Engine:
         torch.cuda.current_stream().synchronize()
         _ck(self.lib, self.lib.csm_prefill_slot(self._h, int(row), _ptr(ids), _ptr(m), S))
         self.sync()
+
+    def prefill_slots(self, rows, ids_list, mask_list) -> bool:
+        """Several new utterances take over several batch rows in ONE prefill (csm_prefill_slots): the contexts (each [S_i, C+1]) are
+        left-padded to the longest and prefilled together -- the running batch waits for one short prefill instead of len(rows).
+        Returns False (nothing done) when that does not fit: a context longer than the batch's current length, or more than
+        max_prefill_rows rows in total; the caller then joins them one by one (prefill_slot)."""
+        n = len(rows)
+        if n == 0:
+            return True
+        S = max(int(t.shape[0]) for t in ids_list)
+        if n < 2 or S > self.length or n * S > self.max_prefill_rows:
+            return False
+        C1 = ids_list[0].shape[-1]
+        ids = torch.zeros(n, S, C1, dtype=torch.long)
+        mask = torch.zeros(n, S, C1, dtype=torch.long)
+        for i, (ri, rm) in enumerate(zip(ids_list, mask_list)):
+            T = ri.shape[0]
+            ids[i, S - T:] = ri
+            mask[i, S - T:] = rm if rm is not None else 1
+        ids_d, m_d = self._prep_ids(ids, mask)
+        rows_a = (C.c_int32 * n)(*[int(r) for r in rows])
+        lens_a = (C.c_int32 * n)(*[int(t.shape[0]) for t in ids_list])
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_prefill_slots(self._h, rows_a, lens_a, n, _ptr(ids_d), _ptr(m_d), S))
+        self.sync()
+        return True
 
     def shift_context(self, delta: int):
         """Move every resident row `delta` cache slots up (csm_shift_context): makes room for a joining context longer than

@@ -40,6 +40,8 @@ class ContinuousBatcher:
         # {request id: waveform [n * samples_per_frame]} (CPU) next to the frames `run()` returns
         self.audio_decoder = audio_decoder
         self.audio: Dict[int, torch.Tensor] = {}
+        self.joint_joins = True        # several joins of one chunk through one slot prefill (csm_prefill_slots); False: one by one
+        self.joined_together = 0       # ... how many utterances joined that way (statistics)
         self.joined_mid_batch = 0      # utterances that took over a row of a running batch (statistics)
         self.shifted_for_long_context = 0   # joins whose context was longer than the running batch (resident rows moved up)
 
@@ -131,13 +133,49 @@ class ContinuousBatcher:
                         self.audio[r[0]] = torch.cat(waves[b]) if waves[b] else torch.zeros(0)
                         waves[b] = []
                     rows[b] = None
-            # every idle row (just finished, or idle since an earlier chunk) is offered the queue
-            for b in range(B):
-                if rows[b] is None and self._queue:
+            # every idle row (just finished, or idle since an earlier chunk) is offered the queue.  Several joins in one chunk
+            # go through ONE slot prefill where that fits (contexts no longer than the batch, max_prefill_rows in total): the
+            # running batch waits for one short prefill instead of one per join
+            idle = [b for b in range(B) if rows[b] is None]
+            if self.joint_joins and len(idle) >= 2 and len(self._queue) >= 2:
+                eng = self._join_many(eng, rows, idle, k, dec)
+                idle = [b for b in range(B) if rows[b] is None]
+            for b in idle:
+                if self._queue:
                     rows[b], eng = self._join(eng, b, k)
                     if dec is not None:
                         dec.streams_reset(b)        # the row's audio stream starts from silence with the new utterance
         m._epoch += 1
+
+    def _join_many(self, eng, rows, idle, k, dec):
+        """As many of the queue's first utterances as there are idle rows join through ONE slot prefill (Engine.prefill_slots),
+        FIFO order kept: the leading run of queued contexts that are no longer than the batch's current length and fit the
+        prefill scratch together.  Whatever is left (a longer context at the head of the queue, a single join) goes through
+        `_join`."""
+        m = self.model
+        if eng.length + k + 1 > eng.max_len:
+            eng = m._ensure_engine(self.B, eng.length + k + 1, max(4 * k, 32), 1, cont=True)
+        take = []
+        smax = 0
+        for item in list(self._queue)[:len(idle)]:
+            S = item[1].shape[0]
+            if S > eng.length or (len(take) + 1) * max(smax, S) > eng.max_prefill_rows:
+                break
+            take.append(item)
+            smax = max(smax, S)
+        if len(take) < 2:
+            return eng
+        use = idle[:len(take)]
+        if not eng.prefill_slots(use, [t[1] for t in take], [t[2] for t in take]):
+            return eng
+        for b, (rid, _, _, budget) in zip(use, take):
+            self._queue.popleft()
+            rows[b] = [rid, budget, []]
+            self.joined_mid_batch += 1
+            self.joined_together += 1
+            if dec is not None:
+                dec.streams_reset(b)
+        return eng
 
     def _join(self, eng, row, k):
         """The first queued utterance takes over `row`.  Its context is placed right-aligned against the batch's current

@@ -220,6 +220,10 @@ int csm_mimi_streams_decode(csm_mimi_t* m, const int64_t* codes, int T, float* a
  * csm_shift_context first; contexts longer than max_prefill_rows are prefilled in chunks).  The row's frames from
  * the current frame index on belong to the new utterance; other rows are untouched. */
 int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, const uint8_t* mask, int S);
+/* several utterances take over several rows in ONE prefill (round 3): ids / mask [n][S][C+1] left-padded by the caller to the
+ * common S (mask 0 on pad frames), lens[i] = true frames of context i, rows[i] = its batch row (host arrays).  Same result as n
+ * csm_prefill_slot calls; needs n * S <= max_prefill_rows and S <= the batch's current length (CSM_ERR_CAPACITY otherwise). */
+int csm_prefill_slots(csm_engine_t* e, const int32_t* rows, const int32_t* lens, int n, const int64_t* ids, const uint8_t* mask, int S);
 /* A context LONGER than the running batch's current length: first move every resident row `delta` cache slots up (keys
  * re-rotated by `delta`: RoPE is relative, the rows' results change by fp32 rounding only; kv_start of every row and the
  * shared length grow by delta; length + delta <= max_len), then csm_prefill_slot.  No reference counterpart. */

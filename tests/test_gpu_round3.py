@@ -660,3 +660,41 @@ def test_continuous_batcher_streams_every_utterance_to_audio():
     dec.close()
     ref.close()
     m._drop_engine()
+
+
+def test_joint_slot_prefill_of_several_joining_rows():
+    """csm_prefill_slots (round 3): the utterances that take over several rows of a running batch in the same chunk are
+    prefilled TOGETHER, left-padded to the longest (kv_start hides the pads, as in a left-padded batch prefill).  Every
+    utterance still equals its SOLO run through the oracle; the one-by-one path (`joint_joins = False`) gives the same frames."""
+    from csm_hf_amd import ContinuousBatcher
+    cfg, sd, m = tiny_model()
+    reqs = []
+    shapes = [(3, 6, 4), (2, 4, 4), (2, 5, 4), (1, 4, 4), (3, 5, 6), (2, 9, 3), (2, 3, 5), (1, 7, 6), (2, 2, 4), (3, 3, 5), (2, 6, 2), (1, 5, 3)]
+    for i, (nt, na, budget) in enumerate(shapes):
+        ids, mask = synth_context(cfg, 1, nt, na, seed=400 + i)
+        reqs.append((ids[0], mask[0], budget))
+    outs = []
+    for joint in (True, False):
+        cb = ContinuousBatcher(m, batch_size=4, temperature=1.0, topk=1, check_every=4)
+        cb.joint_joins = joint
+        rid = [cb.submit(i, k, max_new_frames=b) for i, k, b in reqs]
+        out = cb.run()
+        assert sorted(out) == sorted(rid)
+        if joint:
+            assert cb.joined_together >= 4, cb.joined_together            # the first four finish in the same chunk
+        else:
+            assert cb.joined_together == 0
+        outs.append([out[r] for r in rid])
+    for r, (ids, mask, budget) in enumerate(reqs):
+        want = O.generate(sd, cfg, ids[None], mask[None], max_new_frames=budget, topk=1, stop_on_all_zeros=False)[0]
+        assert torch.equal(outs[0][r], want), f"request {r} (joint joins)"
+        assert torch.equal(outs[1][r], want), f"request {r} (one by one)"
+    # the C entry point refuses what it cannot do
+    eng = m._engine
+    with pytest.raises((RuntimeError, ValueError)):
+        import ctypes as C
+        from csm_hf_amd.engine import _ck, _ptr
+        rows_a, lens_a = (C.c_int32 * 2)(0, 0), (C.c_int32 * 2)(2, 2)
+        ids_d = torch.zeros(2, 2, 33, dtype=torch.long, device=DEV)
+        _ck(eng.lib, eng.lib.csm_prefill_slots(eng._h, rows_a, lens_a, 2, _ptr(ids_d), None, 2))      # the same row twice
+    m._drop_engine()
