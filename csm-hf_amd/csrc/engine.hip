@@ -195,7 +195,9 @@ struct csm_engine {
   int nsplit_eff() const {
     if (nsplit_bb > 0) return nsplit_bb;
     int by_len = (h_len + 256 + 63) / 64;
-    if (B >= 8) by_len = (by_len + 1) / 2;  // enough rows to fill the chip: fewer, longer splits (less combine work)
+    if (B >= 32) by_len = (by_len + 7) / 8;      // 32-64 rows: 256-512 (row, kv-head) pairs already fill the chip -- 2 splits at a 512-frame
+                                                 // context: B = 64 frame-step 9.48 -> 9.25 ms (8 splits -> 2; profiles/r03_b64_rows64.txt)
+    else if (B >= 8) by_len = (by_len + 1) / 2;  // enough rows to fill the chip: fewer, longer splits (less combine work)
     const int by_fill = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
     const int ns = by_len > by_fill ? by_len : by_fill;
     int p = 1;
