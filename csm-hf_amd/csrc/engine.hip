@@ -197,7 +197,8 @@ struct csm_engine {
     int by_len = (h_len + 256 + 63) / 64;
     if (B >= 32) by_len = (by_len + 7) / 8;      // 32-64 rows: 256-512 (row, kv-head) pairs already fill the chip -- 2 splits at a 512-frame
                                                  // context: B = 64 frame-step 9.48 -> 9.25 ms (8 splits -> 2; profiles/r03_b64_rows64.txt)
-    else if (B >= 8) by_len = (by_len + 1) / 2;  // enough rows to fill the chip: fewer, longer splits (less combine work)
+    else if (B >= 8) by_len = std::min(4, (by_len + 3) / 4);  // enough rows to fill the chip: fewer, longer splits (less combine work); B = 16:
+                                                 // 4 splits 5.04 ms against 5.08 (8) / 5.09 (2) at 512 frames, 5.40 / 5.44 / 5.47 at 2048
     const int by_fill = 256 / ((B > 0 ? B : 1) * cfg.backbone.n_kv);
     const int ns = by_len > by_fill ? by_len : by_fill;
     int p = 1;

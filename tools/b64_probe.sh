@@ -6,13 +6,7 @@ for l in sys.stdin:
 " "$@"; }
 mkdir -p gpurun_out/b64
 {
-python -m pytest tests/test_gpu_generate.py -x -q -k "64_row or other_shapes" 2>&1 | tail -2
-run --batch 32 --steps 50
-run --batch 32 --steps 50 --opt nsplit_backbone=8
-run --batch 32 --steps 50 --opt nsplit_backbone=4
-run --batch 48 --steps 50
-run --batch 64 --steps 50
-run --batch 64 --steps 50 --ctx 2048
-run --batch 64 --steps 50 --ctx 2048 --opt nsplit_backbone=8
-} > gpurun_out/b64/b64d.txt 2>&1
-cat gpurun_out/b64/b64d.txt
+for n in 8 4 2 8 4 2; do run --batch 16 --steps 100 --opt nsplit_backbone=$n; done
+for n in 8 4 2; do run --batch 16 --steps 100 --ctx 2048 --opt nsplit_backbone=$n; done
+} > gpurun_out/b64/b16split.txt 2>&1
+cat gpurun_out/b64/b16split.txt
