@@ -14,6 +14,7 @@ class StubEngine:
 
     def __init__(self, B, max_len, max_frames):
         self.max_batch, self.max_len, self.max_frames = B, max_len, max_frames
+        self.max_prefill_rows = 64
         self.length = self.frames = 0
         self.log = []
 
@@ -59,6 +60,19 @@ class StubEngine:
         self.key[row] = int(ids[-1, 0])
         self.t[row] = 0
         self.log.append(("join", row, ids.shape[0], self.length))
+
+
+    def prefill_slots(self, rows, ids_list, mask_list):
+        # Engine.prefill_slots: several joins through one prefill; refuses (False) what does not fit
+        S = max(t.shape[0] for t in ids_list)
+        if len(rows) < 2 or S > self.length or len(rows) * S > self.max_prefill_rows:
+            return False
+        for row, ids in zip(rows, ids_list):
+            self.key[row] = int(ids[-1, 0])
+            self.t[row] = 0
+            self.log.append(("join", row, ids.shape[0], self.length))
+        self.log.append(("joint", tuple(rows)))
+        return True
 
 
 class StubModel:
@@ -170,3 +184,27 @@ def test_cache_growth_is_requested_as_a_continuation():
     r = cb.submit(*utterance(7, 5), max_new_frames=80)
     out = cb.run()
     assert out[r].shape[0] == 80 and any(x[0] == "grow" for x in m.engines[0].log)
+
+
+def test_joins_of_one_chunk_go_through_one_slot_prefill():
+    """several rows finishing in the same chunk: the queue's leading utterances join through ONE Engine.prefill_slots call (FIFO
+    kept); a context longer than the running batch at the head of the queue falls back to the one-by-one path; switched off
+    (`joint_joins = False`) nothing is joined together.  Results are per utterance either way."""
+    specs = [(1, 6, 3), (2, 6, 3), (3, 6, 3), (4, 5, 4), (6, 4, 4), (7, 6, 2), (8, 40, 3), (9, 3, 2)]
+    for joint in (True, False):
+        m = StubModel()
+        cb = ContinuousBatcher(m, batch_size=3, topk=1, check_every=4)
+        cb.joint_joins = joint
+        rid = [cb.submit(*utterance(k, T), max_new_frames=b) for k, T, b in specs]
+        out = cb.run()
+        assert sorted(out) == rid
+        for r, (k, T, b) in zip(rid, specs):
+            assert torch.equal(out[r][:, 0], torch.arange(b) + k * 100 + 1)
+        e = m.engines[0]
+        joint_calls = [x for x in e.log if x[0] == "joint"]
+        if joint:
+            assert joint_calls and joint_calls[0][1] == (0, 1, 2) and cb.joined_together >= 3      # keys 4, 6, 7 took rows 0-2 together
+            assert any(x[0] == "shift" for x in e.log)                                             # the 40-frame context joined alone
+        else:
+            assert not joint_calls and cb.joined_together == 0
+        assert cb.joined_mid_batch == 5
