@@ -21,6 +21,8 @@ struct PrefillAttnArgs {
   size_t plane_stride;
   const int* seq_slot;  // nullable: sequence b of this launch lives in cache slot seq_slot[b] (continuous batching: several rows of a
                         // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
+  uint8_t* oq;          // nullable (attn_prefill_bf16_kernel only): output as MX-fp8 rows [B*S][n_q*64] e4m3 + os [B*S][n_q*2] E8M0 scales
+  uint8_t* os;          // (the OCP recipe of mx_quant_rows_kernel, gemm_mx.h; a 32-block = half a head = the lane pair of a query row) instead of `out`
   int ksplit_groups;    // host-side A/B: 2 = two key groups per workgroup from 256 visible positions on, 3 = the same at <= 128 VGPRs; else one
 };
 
@@ -383,8 +385,45 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
       o1[r] = o1[r] * w0 + mine_x[(16 + r) * 64] * w1;
     }
   }
-  if (!row_live) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  if (a.oq) {   // MX-fp8 output for the o_proj GEMM: dims 0-31 / 32-63 of the head are one scale block each, held by this lane and lane ^ 32
+    float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= inv; o1[r] *= inv; m0 = fmaxf(m0, fabsf(o0[r])); m1 = fmaxf(m1, fabsf(o1[r])); }
+    m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+    m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+    if (!row_live) return;
+    int e0 = (int)((__float_as_uint(m0) >> 23) & 0xff) - 8, e1 = (int)((__float_as_uint(m1) >> 23) & 0xff) - 8;
+    e0 = e0 < 0 ? 0 : (e0 > 254 ? 254 : e0);
+    e1 = e1 < 0 ? 0 : (e1 > 254 ? 254 : e1);
+    const float i0 = __uint_as_float((uint32_t)(254 - e0) << 23), i1 = __uint_as_float((uint32_t)(254 - e1) << 23);
+    const size_t row = (size_t)b * a.S + s;
+    uint8_t* qd = a.oq + row * a.n_q * HD + (size_t)h * HD;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int d = 8 * r4 + 4 * lh;
+      float w0[4], w1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w0[i] = fminf(fmaxf(o0[4 * r4 + i] * i0, -448.f), 448.f);
+        w1[i] = fminf(fmaxf(o1[4 * r4 + i] * i1, -448.f), 448.f);
+      }
+      int p0 = 0, p1 = 0;
+      p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w0[0], w0[1], p0, false);
+      p0 = __builtin_amdgcn_cvt_pk_fp8_f32(w0[2], w0[3], p0, true);
+      p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w1[0], w1[1], p1, false);
+      p1 = __builtin_amdgcn_cvt_pk_fp8_f32(w1[2], w1[3], p1, true);
+      *reinterpret_cast<uint32_t*>(qd + d) = (uint32_t)p0;
+      *reinterpret_cast<uint32_t*>(qd + 32 + d) = (uint32_t)p1;
+    }
+    if (lh == 0) {
+      uint8_t* sd = a.os + row * (a.n_q * 2) + h * 2;
+      sd[0] = (uint8_t)e0;
+      sd[1] = (uint8_t)e1;
+    }
+    return;
+  }
+  if (!row_live) return;
   float* dst = a.out + ((size_t)b * a.S + s) * a.n_q * HD + (size_t)h * HD;
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {

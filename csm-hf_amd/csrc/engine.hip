@@ -152,6 +152,8 @@ struct csm_engine {
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
+  int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
+  int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
   size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
   int prefill_splitk_max = 8;   // most K splits of a residual prefill GEMM (the partials buffer holds 4 at max_prefill_rows: more only for fewer rows)
   int prefill_planes = 1;
@@ -582,6 +584,8 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   }
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
+  else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
+  else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
   else if (!strcmp(name, "g16_down")) e->g16_down = value;
   else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
@@ -1115,6 +1119,15 @@ static inline int mx_ksplit(int R, int N, int K, int cap) {
   return ks;
 }
 
+// GEPI_ROPE arguments of a QKV launch (gemm.h: RopeEpi) -- what launch_rope_scatter would be given
+static RopeEpi rope_epi_of(csm_engine* e, Stack& s, void* kc, void* vc, int lmax, const int32_t* rope_pos) {
+  RopeEpi r{};
+  r.cos_tab = s.cos; r.sin_tab = s.sin; r.row_seq = e->p_row_seq; r.row_pos = e->p_row_pos; r.rope_pos = rope_pos;
+  r.qbuf = e->p_q; r.kcache = kc; r.vcache = vc; r.n_q = s.c.n_q; r.n_kv = s.c.n_kv; r.lmax = lmax;
+  r.kv_bf16 = e->cfg.kv_dtype == 1 ? 1 : 0; r.qscale = 1.0f / sqrtf((float)s.c.head_dim);
+  return r;
+}
+
 // stack_rows with every linear on the block-scaled fp8 matrix instruction (gemm_mx.h; backbone only): the producers
 // (RMSNorm, attention, SwiGLU epilogue) leave fp32 rows, mx_quant_rows_kernel turns them into e4m3 + E8M0 scales, the GEMM
 // multiplies them with the MX copy of the weights.  Same residual / split-K / RoPE / attention launches as the other modes.
@@ -1159,28 +1172,41 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
                        pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));   // normed rows leave as MX-fp8
     pending = 0;
     RopeArgs ra{};
+    bool roped = false;
     if (ks_q > 1) {
       LCK(gemm(GEPI_PARTIAL, m.qkv, m.qkv_s, NQKV, H, nullptr, 0, ks_q, R * (size_t)NQKV));
       ra.part = e->p_part; ra.nsplit = ks_q; ra.part_stride = R * (size_t)NQKV;
+    } else if (e->prefill_fuse_rope && hd == 64) {   // RoPE, q scale and the cache append in the GEMM's epilogue
+      GemmMxArgs g{};
+      g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.qkv; g.Ws = m.qkv_s; g.R = (int)R; g.N = NQKV; g.K = H; g.big = e->gemm_256;
+      g.rope = rope_epi_of(e, s, kc[l], vc[l], lmax, rope_pos);
+      LCK(launch_gemm_mx(e->stream, GEPI_ROPE, g));
+      roped = true;
     } else {
       LCK(gemm(GEPI_STORE, m.qkv, m.qkv_s, NQKV, H, e->p_qkv, NQKV, 1, 0));
     }
-    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
-    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
-    ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
-    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    if (!roped) {
+      ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
+      ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
+      ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
+      LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    }
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
     fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
+    // the bf16 flash kernel leaves its output already MX-quantised (a 32-block is half a head: the lane pair of a query row)
+    bool att_q = e->flash_prefill && e->prefill_bf16_attn && e->prefill_fuse_quant && hd == 64;
+    if (att_q) { fa.oq = e->p_mx_q; fa.os = e->p_mx_s; }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, e->prefill_bf16_attn ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     if (fr == -2) {
+      att_q = false;
       AttnArgs t{};
       t.q = e->p_q; t.kcache = kc[l]; t.vcache = vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = lmax;
       t.row_seq = e->p_row_seq; t.row_pos = e->p_row_pos; t.kv_start = kv_start; t.nsplit = 1; t.out = e->p_att;
       fr = launch_attn(e->stream, e->cfg.kv_dtype, (int)R, t);
     }
     LCK(fr);
-    LCK(quant(e->p_att, A));
+    if (!att_q) LCK(quant(e->p_att, A));
     if (ks_o > 1) {
       LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
       pending = ks_o;
@@ -1270,17 +1296,26 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
     g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs;
     RopeArgs ra{};
+    bool roped = false;
     if (ks_q > 1) {
       g.ksplit = ks_q; g.Cpart = e->p_part; g.part_stride = R * (size_t)s.nqkv();
       LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, g));
       ra.part = e->p_part; ra.nsplit = ks_q; ra.part_stride = g.part_stride;
     } else {
-      LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
+      if (pl && e->prefill_fuse_rope && hd == 64) {   // RoPE, q scale and the cache append in the GEMM's epilogue (LDS-DMA tiles only: -2 otherwise)
+        GemmArgs gr = g;
+        gr.rope = rope_epi_of(e, s, kc[l], vc[l], lmax, rope_pos);
+        const int rr = launch_gemm(e->stream, wd, GEPI_ROPE, gr);
+        if (rr != -2) { LCK(rr); roped = true; }
+      }
+      if (!roped) LCK(launch_gemm(e->stream, wd, GEPI_STORE, g));
     }
-    ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
-    ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
-    ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
-    LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    if (!roped) {
+      ra.qkv = e->p_qkv; ra.n_q = nq; ra.n_kv = nkv; ra.hd = hd; ra.qscale = 1.0f / sqrtf((float)hd);
+      ra.cos_tab = s.cos; ra.sin_tab = s.sin; ra.row_seq = e->p_row_seq; ra.row_pos = e->p_row_pos;
+      ra.qbuf = e->p_q; ra.kcache = kc[l]; ra.vcache = vc[l]; ra.lmax = lmax; ra.rope_pos = rope_pos;
+      LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
+    }
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
     fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;

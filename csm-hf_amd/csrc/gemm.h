@@ -11,7 +11,28 @@
 #pragma once
 #include "common.h"
 
-enum { GEPI_STORE = 0, GEPI_RESID = 1, GEPI_SWIGLU = 2, GEPI_PARTIAL = 3 };
+enum { GEPI_STORE = 0, GEPI_RESID = 1, GEPI_SWIGLU = 2, GEPI_PARTIAL = 3, GEPI_ROPE = 4 };
+
+// GEPI_ROPE (the QKV GEMM of a prefill whose head_dim is 64, LDS-DMA tiles only): the epilogue of the GEMM is the whole of
+// rope_scatter_kernel (misc.h) -- rotate q / k by the row's position (HF rotate_half pairs d, d + 32), scale q by hd^-0.5 into
+// qbuf, append k / v to the caches in their engine layouts -- so the [R][n_q + 2 n_kv][64] fp32 QKV matrix never goes to memory
+// (written + re-read: 2 x 25 MB per layer at 2 048 rows) and one launch per layer disappears.  A wave tile of these kernels is
+// 64 weight rows = ONE head, and a lane holds columns 16 ni + 4 g .. + 3 for ni = 0..3: both halves of a rotation pair sit in
+// the same lane (ni and ni + 2).  Replaces transformers' apply_rotary_pos_emb + DynamicCache.update behind q_proj / k_proj /
+// v_proj at q_len > 1 (modeling_llama.py:130-176, 267-281; reference call site modeling_csm.py:345-354).
+struct RopeEpi {
+  const float* cos_tab;   // [pos][32]
+  const float* sin_tab;
+  const int* row_seq;     // [R] cache slot of the row's sequence
+  const int* row_pos;     // [R] cache position
+  const int* rope_pos;    // nullable: rotation position (position_ids) when it differs from the cache position
+  float* qbuf;            // [R][n_q * 64]
+  void* kcache;           // [B][n_kv][16][lmax][4]
+  void* vcache;           // [B][n_kv][lmax][64]
+  int n_q, n_kv, lmax;
+  int kv_bf16;            // cache element type: 0 fp32, 1 bf16
+  float qscale;
+};
 
 struct GemmArgs {
   const float* A;  // [R][lda]
@@ -53,7 +74,68 @@ struct GemmArgs {
   // gemm256_kernel (gemm256.h: the same staging, 256 x 256 tile, 8 waves): one-plane bf16 launches whose 256 x 256 tiles (x K
   // splits) number at least big256 (0 = never)
   int big256;
+  RopeEpi rope;   // GEPI_ROPE only
 };
+
+#ifndef CSM_ARGS_ONLY
+// One activation row of one head (wave tile): v[ni] = columns 16 ni + 4 g .. + 3 of the head.  Same arithmetic, in the same
+// order, as rope_scatter_kernel.
+__device__ __forceinline__ void rope_epilogue_row(const RopeEpi& p, int r, int head, int g, const f32x4 (&v)[4]) {
+  const int b = p.row_seq[r], pos = p.row_pos[r];
+  if (head >= p.n_q + p.n_kv) {   // v head: plain append
+    const int j = head - p.n_q - p.n_kv;
+    const size_t at = (((size_t)b * p.n_kv + j) * p.lmax + pos) * 64 + 4 * g;
+    if (p.kv_bf16) {
+      bf16_t* vr = reinterpret_cast<bf16_t*>(p.vcache) + at;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        *reinterpret_cast<uint2*>(vr + 16 * ni) = make_uint2((uint32_t)f32_to_bf16(v[ni][0]) | ((uint32_t)f32_to_bf16(v[ni][1]) << 16),
+                                                              (uint32_t)f32_to_bf16(v[ni][2]) | ((uint32_t)f32_to_bf16(v[ni][3]) << 16));
+    } else {
+      float* vr = reinterpret_cast<float*>(p.vcache) + at;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(vr + 16 * ni) = v[ni];
+    }
+    return;
+  }
+  const int rpos = p.rope_pos ? p.rope_pos[r] : pos;
+  f32x4 o[4];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {   // dims 16 h2 + 4 g .. + 3 (first half) pair with the same + 32
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos_tab + (size_t)rpos * 32 + 16 * h2 + 4 * g);
+    const f32x4 s = *reinterpret_cast<const f32x4*>(p.sin_tab + (size_t)rpos * 32 + 16 * h2 + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = v[h2][e], v1 = v[h2 + 2][e];
+      o[h2][e] = __fmaf_rn(v0, c[e], -__fmul_rn(v1, s[e]));       // the contraction rope_scatter_kernel is written in (misc.h)
+      o[h2 + 2][e] = __fmaf_rn(v1, c[e], __fmul_rn(v0, s[e]));
+    }
+  }
+  if (head < p.n_q) {
+    float* q = p.qbuf + (size_t)r * p.n_q * 64 + head * 64 + 4 * g;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = __fmul_rn(o[ni][e], p.qscale);
+      *reinterpret_cast<f32x4*>(q + 16 * ni) = t;
+    }
+  } else {   // k head: [hd/4 = 16][lmax][4], dims 16 ni + 4 g .. + 3 are group 4 ni + g
+    const int j = head - p.n_q;
+    const size_t base = (((size_t)b * p.n_kv + j) * 16) * p.lmax;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const size_t at = (base + (size_t)(4 * ni + g) * p.lmax + pos) * 4;
+      if (p.kv_bf16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.kcache) + at) =
+            make_uint2((uint32_t)f32_to_bf16(o[ni][0]) | ((uint32_t)f32_to_bf16(o[ni][1]) << 16),
+                       (uint32_t)f32_to_bf16(o[ni][2]) | ((uint32_t)f32_to_bf16(o[ni][3]) << 16));
+      else
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.kcache) + at) = o[ni];
+    }
+  }
+}
+#endif
 
 // K splits of a residual-epilogue prefill GEMM (o_proj, down_proj): enough workgroups for ~4 per CU, k-steps of 64
 static inline int prefill_ksplit(int R, int N, int K, int cap = 4) {

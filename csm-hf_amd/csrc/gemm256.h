@@ -377,6 +377,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
       return;
     }
   }
+  if (EPI == GEPI_ROPE) {   // this wave tile is one head of the QKV projection (gemm.h: RopeEpi)
+    const int head = (n0 + wc * 64) >> 6;
+#pragma unroll
+    for (int ri = 0; ri < 8; ++ri) {
+      const int r = r0 + wr * 128 + ri * 16 + j16;
+      if (r < a.R) rope_epilogue_row(a.rope, r, head, g, acc[ri]);
+    }
+    return;
+  }
 #pragma unroll
   for (int ri = 0; ri < 8; ++ri) {
     const int r = r0 + wr * 128 + ri * 16 + j16;

@@ -43,6 +43,7 @@ struct GemmMxArgs {
   uint8_t* Cq;
   uint8_t* Cs;
   int big;             // host-side: workgroup count from which the 256 x 256 tile (gemm256.h) takes the launch (0 = never)
+  RopeEpi rope;        // GEPI_ROPE only (gemm.h)
 };
 
 // fp32 rows -> MX-fp8: q [rows][K] e4m3 + s [rows][K/32] E8M0, the OCP MX recipe (shared scale 2^(floor(log2(amax)) - 8),
@@ -240,6 +241,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
     }
     return;
   }
+  if (EPI == GEPI_ROPE) {   // this wave tile is one head of the QKV projection (gemm.h: RopeEpi)
+    const int head = (n0 + wc * 64) >> 6;
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const int r = r0 + wr * 64 + ri * 16 + j16;
+      if (r < a.R) rope_epilogue_row(a.rope, r, head, kb, acc[ri]);
+    }
+    return;
+  }
 #pragma unroll
   for (int ri = 0; ri < 4; ++ri) {
     const int r = r0 + wr * 64 + ri * 16 + j16;
@@ -371,6 +381,15 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
+  if (EPI == GEPI_ROPE) {   // this wave tile is one head of the QKV projection (gemm.h: RopeEpi)
+    const int head = (n0 + wc * 64) >> 6;
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const int r = r0 + wr * 64 + ri * 16 + j16;
+      if (r < a.R) rope_epilogue_row(a.rope, r, head, g, acc[ri]);
+    }
+    return;
   }
 #pragma unroll
   for (int ri = 0; ri < 4; ++ri) {

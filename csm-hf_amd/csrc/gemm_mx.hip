@@ -34,6 +34,7 @@ int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a) {
     case GEPI_RESID: return launch_mx_epi<GEPI_RESID>(st, grid, a);
     case GEPI_SWIGLU: return launch_mx_epi<GEPI_SWIGLU>(st, grid, a);
     case GEPI_PARTIAL: return launch_mx_epi<GEPI_PARTIAL>(st, grid, a);
+    case GEPI_ROPE: return launch_mx_epi<GEPI_ROPE>(st, grid, a);
     default: return -1;
   }
 }
@@ -71,6 +72,7 @@ int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
   if (!a.Aplanes || !a.W || a.wscale || a.R < 1 || a.N % 128 || a.K % 64 || a.ldc % 4) return -2;
   const bool exact = a.a_plane_stride != 0;
   if (exact && (a.dma & 32)) {   // three planes on 32-wide k-steps: two workgroups per CU
+    if (epi == GEPI_ROPE) return -2;
     if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride == 0) return -2;
     const int ks3 = epi == GEPI_PARTIAL ? a.ksplit : 1;
     if (ks3 < 1 || a.K % (32 * ks3) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
@@ -93,6 +95,7 @@ int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
     case GEPI_RESID: DMA_EPI(GEPI_RESID);
     case GEPI_SWIGLU: DMA_EPI(GEPI_SWIGLU);
     case GEPI_PARTIAL: DMA_EPI(GEPI_PARTIAL);
+    case GEPI_ROPE: DMA_EPI(GEPI_ROPE);
     default: return -1;
   }
 #undef DMA_EPI
@@ -149,6 +152,7 @@ int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs)
     case GEPI_RESID: return launch_256_epi<GEPI_RESID, false, GemmArgs>(st, grid, a, var);
     case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, false, GemmArgs>(st, grid, a, var);
     case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, false, GemmArgs>(st, grid, a, var);
+    case GEPI_ROPE: return launch_256_var<GEPI_ROPE, false, 1, GemmArgs>(st, grid, a);   // default schedule only
     default: return -1;
   }
 }
@@ -167,6 +171,7 @@ int launch_gemm256_mx(hipStream_t st, int epi, const GemmMxArgs& a, int min_wgs)
     case GEPI_RESID: return launch_256_epi<GEPI_RESID, true, GemmMxArgs>(st, grid, a, var);
     case GEPI_SWIGLU: return launch_256_epi<GEPI_SWIGLU, true, GemmMxArgs>(st, grid, a, var);
     case GEPI_PARTIAL: return launch_256_epi<GEPI_PARTIAL, true, GemmMxArgs>(st, grid, a, var);
+    case GEPI_ROPE: return launch_256_var<GEPI_ROPE, true, 1, GemmMxArgs>(st, grid, a);   // default schedule only
     default: return -1;
   }
 }

@@ -155,6 +155,7 @@ static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
       if (r != -2) return r;
     }
   }
+  if (epi == GEPI_ROPE) return -2;   // only the LDS-DMA tiles carry the RoPE / cache-append epilogue: the caller runs STORE + rope_scatter
   if (gemm_wide_ok(epi, a)) return launch_gemm_wide<WT>(st, epi, a);
   // 128x128 tiles unless they would occupy fewer than 256 workgroups
   if (epi == GEPI_PARTIAL) return a.K % 64 ? -1 : launch_gemm_x3_bk<WT, 64, 64>(st, epi, a);
@@ -180,6 +181,7 @@ static int launch_gemm_t(hipStream_t st, int epi, const GemmArgs& a) {
 
 int launch_gemm(hipStream_t st, int wdtype, int epi, const GemmArgs& a) {
   if (a.N % 128 != 0 || a.K % 32 != 0 || a.R < 1) return -1;
+  if (epi == GEPI_ROPE && (wdtype != 1 || a.f32_mfma || !a.Aplanes || !a.rope.qbuf)) return -2;
   if (wdtype == 2) return a.f32_mfma ? launch_gemm_t<fp8_t>(st, epi, a) : launch_gemm_x3<fp8_t>(st, epi, a);
   if (wdtype == 1) return a.f32_mfma ? launch_gemm_t<bf16_t>(st, epi, a) : launch_gemm_x3<bf16_t>(st, epi, a);
   return launch_gemm_t<float>(st, epi, a);

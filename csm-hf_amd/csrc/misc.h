@@ -336,11 +336,13 @@ __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
     if (head < a.n_q + a.n_kv) {
       const float v0 = ld(head * a.hd + i), v1 = ld(head * a.hd + i + half);
       const float c = a.cos_tab[(size_t)rpos * half + i], s = a.sin_tab[(size_t)rpos * half + i];
-      const float o0 = v0 * c - v1 * s, o1 = v1 * c + v0 * s;
+      // explicit contraction (what the compiler chose before it was spelled out), shared with the GEMM's RoPE epilogue
+      // (gemm.h: rope_epilogue_row) so that the two are bitwise interchangeable
+      const float o0 = __fmaf_rn(v0, c, -__fmul_rn(v1, s)), o1 = __fmaf_rn(v1, c, __fmul_rn(v0, s));
       if (head < a.n_q) {
         float* q = a.qbuf + (size_t)row * a.n_q * a.hd + head * a.hd;
-        q[i] = o0 * a.qscale;
-        q[i + half] = o1 * a.qscale;
+        q[i] = __fmul_rn(o0, a.qscale);
+        q[i + half] = __fmul_rn(o1, a.qscale);
       } else {
         const int j = head - a.n_q;
         const size_t base = (((size_t)b * a.n_kv + j) * (a.hd >> 2)) * a.lmax;

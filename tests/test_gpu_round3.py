@@ -698,3 +698,55 @@ def test_joint_slot_prefill_of_several_joining_rows():
         ids_d = torch.zeros(2, 2, 33, dtype=torch.long, device=DEV)
         _ck(eng.lib, eng.lib.csm_prefill_slots(eng._h, rows_a, lens_a, 2, _ptr(ids_d), None, 2))      # the same row twice
     m._drop_engine()
+
+
+def test_rope_epilogue_of_the_qkv_gemm_and_mx_output_of_the_attention_are_bitwise_the_separate_launches():
+    """The prefill's QKV GEMM on an LDS-DMA tile applies RoPE, the q scale and the cache append in its epilogue (GEPI_ROPE,
+    csrc/gemm.h: a wave tile is one head, both halves of a rotation pair sit in one lane) instead of storing the QKV matrix for
+    rope_scatter_kernel, and in mxfp8 mode the flash attention writes its output already MX-quantised instead of through
+    mx_quant_rows_kernel.  Same arithmetic in the same order: last hidden state, logits AND the exported K/V caches are bitwise
+    those of the separate launches -- for the 128 x 128 and 256 x 256 tiles, bf16 / mxfp8 / exact (three-plane) operands, fp32 and
+    bf16 caches, and a left-padded batch (per-row cache slots and positions).
+    Reference: apply_rotary_pos_emb + DynamicCache.update behind q/k/v_proj (modeling_llama.py:130-176, 267-281)."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    ids1, mask1 = synth_context(cfg, 1, 64, 192, seed=2)                 # 256 rows: one 256-row tile block
+    ids2, mask2 = synth_context(cfg, 2, 64, 192, seed=3)
+    ids2, mask2 = ids2.clone(), mask2.clone()
+    ids2[1, :40], mask2[1, :40] = 0, 0                                     # row 1 left-padded by 40 frames
+
+    def run(m, ids, mask, starts, precision, opts):
+        m.prefill_precision = precision
+        eng = m._ensure_engine(2, 600, 4, 512)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.reset()
+        eng.set_kv_start(starts)
+        lh, lg = eng.prefill(ids, mask)
+        kv = [(k.cpu(), v.cpu()) for k, v in eng.export_kv()]
+        return lh.cpu(), lg.cpu(), kv
+
+    def same(a, b, what):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (what, float((a[0] - b[0]).abs().max()))
+        for l, ((ka, va), (kb, vb)) in enumerate(zip(a[2], b[2])):
+            assert torch.equal(ka, kb) and torch.equal(va, vb), (what, "cache of layer", l)
+
+    for kv_dtype in (torch.float32, torch.bfloat16):
+        m = CSMModel(cfg)
+        m.load_state_dict(sd)
+        m.kv_dtype = kv_dtype
+        cases = [("bf16", dict(gemm_256=0, gemm_dma=2)), ("bf16", dict(gemm_256=1, gemm_dma=2)),
+                 ("mxfp8", dict(gemm_256=0)), ("mxfp8", dict(gemm_256=1))]
+        if kv_dtype == torch.float32:
+            cases.append(("exact", dict(gemm_256=0, gemm_dma=8)))          # three-plane LDS-DMA tile forced
+        for precision, opts in cases:
+            common = dict(gemm_wide=0, prefill_splitk=0, **opts)
+            for ids, mask, starts in ((ids1, mask1, [0]), (ids2, mask2, [0, 40])):
+                base = run(m, ids, mask, starts, precision, dict(prefill_fuse_rope=0, prefill_fuse_quant=0, **common))
+                fused = run(m, ids, mask, starts, precision, dict(prefill_fuse_rope=1, prefill_fuse_quant=0, **common))
+                same(base, fused, (kv_dtype, precision, opts, "rope", len(starts)))
+                if precision == "mxfp8":
+                    both = run(m, ids, mask, starts, precision, dict(prefill_fuse_rope=1, prefill_fuse_quant=1, **common))
+                    same(base, both, (kv_dtype, precision, opts, "quant", len(starts)))
+        m._engine.set_option("gemm_256", 256)
+        m._drop_engine()
