@@ -137,7 +137,9 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  * "fuse_decoder_attention", "flash_prefill", "prefill_planes" (prefill activations handed to the GEMMs as bf16 planes),
  * "g16_gu" / "g16_down" (panel-shape overrides of the batched gate/up and down_proj launches), "weight_prefetch" (weight
  * streamer on/off), "prefetch_window_mb" (bytes it may run ahead of the consumers, default 24), "prefetch_sub_kb"
- * (pacing granularity), "prefetch_grid" (its workgroups, default 256) */
+ * (pacing granularity), "prefetch_grid" (its workgroups, default 256); "prefill_fuse_rope" (1: apply_rotary_pos_emb +
+ * DynamicCache.update, modeling_llama.py:130-176 / 267-281, run as the EPILOGUE of the prefill's QKV GEMM instead of a launch
+ * of their own) and "prefill_fuse_quant" (1: MX-fp8 prefill, the attention output leaves its kernel already quantised) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
