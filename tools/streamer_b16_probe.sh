@@ -9,8 +9,8 @@ for l in sys.stdin:
 " "$@"; }
 {
 run
-run --opt g16_k16=1
-B="--opt g16_k16=1 --opt prefetch_batched=1"
+run --opt g16_k16=520
+B="--opt g16_k16=520 --opt prefetch_batched=1"
 run $B
 for v in 0 64 256; do run $B --opt prefetch_seg_sleep=$v; done
 for v in 8 16; do run $B --opt prefetch_window_mb=$v; done
