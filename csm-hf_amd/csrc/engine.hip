@@ -36,6 +36,8 @@ int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int 
                    size_t plane_stride = 0, const float* part = nullptr, int nsplit = 0, size_t part_stride = 0, int ldp = 0,
                    uint8_t* mxq = nullptr, uint8_t* mxs = nullptr);
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a);
+int launch_swiglu_reduce(hipStream_t st, const float* part, int nsplit, size_t part_stride, int rows, int F, float* out, int ldo,
+                         bf16_t* planes, size_t plane_stride, uint8_t* mxq, uint8_t* mxs);
 int launch_sample(hipStream_t st, int rows, const SampleArgs& a);
 int launch_kv_convert(hipStream_t st, int kvdtype, const KvConvArgs& a);
 int launch_rows_iota(hipStream_t st, int* row_seq, int* row_pos, int R, int S, int past);
@@ -152,6 +154,8 @@ struct csm_engine {
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
+  float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
+  int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
   int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
   size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
@@ -584,6 +588,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   }
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
+  else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -1152,6 +1157,15 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     const size_t room = 4 * (size_t)e->cfg.max_prefill_rows * (size_t)e->p_part_h / (R * (size_t)NQKV);
     ks_q = mx_ksplit((int)R, NQKV, H, (int)std::min<size_t>(std::min<size_t>((size_t)e->prefill_splitk_max, (size_t)e->prefill_splitk_qkv), room));
   }
+  int ks_gu = 1;   // gate/up of a short prefill split over K (see stack_rows)
+  if (can_split && e->prefill_splitk_gu > 1 && R <= 64 && F % 32 == 0) {   // measured: 32 / 64 rows 1.16 / 1.21 -> 1.12 / 1.18 ms, nothing at 128
+    int k = std::min(e->prefill_splitk_gu, 4);
+    while (k > 1 && (H % (128 * k) || H / k < 512)) --k;
+    if (k > 1 && !e->p_part_gu) {
+      if (int r = dalloc(e, &e->p_part_gu, (size_t)4 * std::min<size_t>(128, (size_t)e->cfg.max_prefill_rows) * (size_t)(2 * F))) return r;
+    }
+    ks_gu = k < 1 ? 1 : k;
+  }
   const size_t part_stride = R * (size_t)H;
   auto quant = [&](const float* x, int K) {
     MxQuantArgs q{};
@@ -1217,7 +1231,13 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
                        pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));
     pending = 0;
     const bool fq = e->mx_fuse_swiglu != 0;
-    {
+    if (ks_gu > 1) {   // short prefill: gate/up split over K, partials summed + SwiGLU + MX quantiser in swiglu_reduce_kernel (misc.h)
+      GemmMxArgs g{};
+      g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H;
+      g.ksplit = ks_gu; g.Cpart = e->p_part_gu; g.part_stride = R * (size_t)(2 * F); g.big = e->gemm_256;
+      LCK(launch_gemm_mx(e->stream, GEPI_PARTIAL, g));
+      LCK(launch_swiglu_reduce(e->stream, e->p_part_gu, ks_gu, g.part_stride, (int)R, F, e->p_act, F, nullptr, 0, fq ? e->p_mx_q2 : nullptr, fq ? e->p_mx_s2 : nullptr));
+    } else {
       GemmMxArgs g{};
       g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H; g.C = e->p_act; g.ldc = F;
       if (fq) { g.Cq = e->p_mx_q2; g.Cs = e->p_mx_s2; }
@@ -1284,6 +1304,17 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     const size_t room = 4 * (size_t)e->cfg.max_prefill_rows * (size_t)e->p_part_h / (R * (size_t)s.nqkv());
     ks_q = prefill_ksplit((int)R, s.nqkv(), H, (int)std::min<size_t>(std::min<size_t>((size_t)e->prefill_splitk_max, (size_t)e->prefill_splitk_qkv), room));
   }
+  // gate/up of a short prefill (<= 128 rows: 128 tiles of 128 x 128, half the chip with one k-step in flight each): the same K split,
+  // as many ways as fill the chip twice and fit p_part (free between the RMSNorm that folded o_proj's partials and down_proj)
+  int ks_gu = 1;
+  if (can_split && e->prefill_splitk_gu > 1 && R <= (one ? 128u : 64u) && &s == &e->bb) {
+    int k = std::min(e->prefill_splitk_gu, 4);
+    while (k > 1 && (H % (64 * k) || H / k < 512)) --k;
+    if (k > 1 && !e->p_part_gu) {
+      if (int r = dalloc(e, &e->p_part_gu, (size_t)4 * std::min<size_t>(128, (size_t)e->cfg.max_prefill_rows) * (size_t)(2 * F))) return r;
+    }
+    ks_gu = k < 1 ? 1 : k;
+  }
   const size_t part_stride = R * (size_t)H;
   int pending = 0;   // splits waiting in p_part for the next RMSNorm
   for (int l = 0; l < s.c.layers; ++l) {
@@ -1347,7 +1378,13 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
     gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs;
     gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
-    LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
+    if (ks_gu > 1) {   // short prefill: split over K, partials summed + SwiGLU by swiglu_reduce_kernel (misc.h)
+      gu.ksplit = ks_gu; gu.Cpart = e->p_part_gu; gu.part_stride = R * (size_t)(2 * F);
+      LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, gu));
+      LCK(launch_swiglu_reduce(e->stream, e->p_part_gu, ks_gu, gu.part_stride, (int)R, F, e->p_act, F, pl ? e->p_pl_act : nullptr, ps_act, nullptr, nullptr));
+    } else {
+      LCK(launch_gemm(e->stream, wd, GEPI_SWIGLU, gu));
+    }
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
     d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs;

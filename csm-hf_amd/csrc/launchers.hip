@@ -280,6 +280,15 @@ int launch_rmsnorm(hipStream_t st, const float* x, int ldx, const float* w, int 
   return (int)hipGetLastError();
 }
 
+int launch_swiglu_reduce(hipStream_t st, const float* part, int nsplit, size_t part_stride, int rows, int F, float* out, int ldo,
+                         bf16_t* planes, size_t plane_stride, uint8_t* mxq, uint8_t* mxs) {
+  if (rows < 1 || F % 4 || nsplit < 1 || (!planes && !mxq && (!out || ldo % 4)) || (mxq && (F % 32 || !mxs))) return -1;
+  const size_t quads = (size_t)rows * (F / 4);
+  hipLaunchKernelGGL(swiglu_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, part, nsplit, part_stride, rows, F, out, ldo,
+                     planes, plane_stride, mxq, mxs);
+  return (int)hipGetLastError();
+}
+
 int launch_rope_scatter(hipStream_t st, int kvdtype, int rows, const RopeArgs& a) {
   const dim3 grid(rows, (a.nsplit > 1 && rows < 1024) ? 4 : 1);
   if (kvdtype == 1) hipLaunchKernelGGL((rope_scatter_kernel<bf16_t>), grid, dim3(256), 0, st, a);

@@ -313,6 +313,48 @@ __global__ __launch_bounds__(256) void kv_convert_kernel(KvConvArgs a) {
   }
 }
 
+// Split-K gate/up GEMM of a SHORT prefill (GEPI_PARTIAL, gemm.h): a context of <= 128 rows has only 128 output tiles of
+// 128 x 128 for the 16 384-wide gate/up projection -- half the chip, one k-step in flight per CU: 67 MB of weights at 2.4 TB/s.
+// Split 4 ways over K it fills the chip twice; this launch sums the partial products in fixed order and applies SwiGLU
+// (act_fn(gate) * up, modeling_llama.py:155-159; (gate, up) rows are interleaved in the packed matrix, so columns 2c, 2c + 1),
+// writing what the GEMM's SWIGLU epilogue would have written: fp32 rows, or bf16 planes (one or three) for the down_proj GEMM.
+// mxq != nullptr (F % 32 == 0; rows * F / 4 a multiple of 8: every 32-block is held by 8 whole lanes): MX-fp8 output, the recipe of rmsnorm_kernel.
+__global__ __launch_bounds__(256) void swiglu_reduce_kernel(const float* part, int nsplit, size_t part_stride, int rows, int F,
+                                                            float* out, int ldo, bf16_t* planes, size_t plane_stride, uint8_t* mxq, uint8_t* mxs) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;       // 4 output columns each
+  const int qpr = F >> 2;
+  if (q >= (size_t)rows * qpr) return;   // (whole groups of 8 lanes leave together)
+  const size_t row = q / qpr;
+  const int c = (int)(q - row * qpr) * 4;
+  const float* pr = part + row * (size_t)(2 * F) + 2 * c;
+  f32x4 a = *reinterpret_cast<const f32x4*>(pr), b = *reinterpret_cast<const f32x4*>(pr + 4);
+  for (int sp = 1; sp < nsplit; ++sp) {
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(pr + (size_t)sp * part_stride), b2 = *reinterpret_cast<const f32x4*>(pr + (size_t)sp * part_stride + 4);
+    a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
+    b[0] += b2[0]; b[1] += b2[1]; b[2] += b2[2]; b[3] += b2[3];
+  }
+  f32x4 h;
+  h[0] = (a[0] / (1.f + __expf(-a[0]))) * a[1];
+  h[1] = (a[2] / (1.f + __expf(-a[2]))) * a[3];
+  h[2] = (b[0] / (1.f + __expf(-b[0]))) * b[1];
+  h[3] = (b[2] / (1.f + __expf(-b[2]))) * b[3];
+  if (mxq) {
+    float m = fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3])));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    int eb = (int)((__float_as_uint(m) >> 23) & 0xff) - 8;
+    eb = eb < 0 ? 0 : (eb > 254 ? 254 : eb);
+    const float inv = __uint_as_float((uint32_t)(254 - eb) << 23);
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(h[0] * inv, -448.f), 448.f), fminf(fmaxf(h[1] * inv, -448.f), 448.f), pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(h[2] * inv, -448.f), 448.f), fminf(fmaxf(h[3] * inv, -448.f), 448.f), pk, true);
+    *reinterpret_cast<uint32_t*>(mxq + row * (size_t)F + c) = (uint32_t)pk;
+    if ((threadIdx.x & 7) == 0) mxs[row * (size_t)(F >> 5) + (c >> 5)] = (uint8_t)eb;
+  } else if (planes) store_rowplanes4(planes + row * (size_t)F + c, plane_stride, h);
+  else *reinterpret_cast<f32x4*>(out + row * (size_t)ldo + c) = h;
+}
+
 template <typename KT>
 __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
   const int row = blockIdx.x;

@@ -750,3 +750,38 @@ def test_rope_epilogue_of_the_qkv_gemm_and_mx_output_of_the_attention_are_bitwis
                     same(base, both, (kv_dtype, precision, opts, "quant", len(starts)))
         m._engine.set_option("gemm_256", 256)
         m._drop_engine()
+
+
+def test_split_k_gate_up_of_a_short_prefill():
+    """A context of <= 64 rows (<= 128 with one activation plane) has 128 output tiles for the 16 384-wide gate/up GEMM: half the
+    chip, one k-step in flight per CU.  `prefill_splitk_gu` splits that launch over K and swiglu_reduce_kernel (csrc/misc.h) sums the
+    partial products in fixed order, applies act_fn(gate) * up (modeling_llama.py:155-159) and writes what the GEMM's SwiGLU
+    epilogue writes (fp32 rows, one / three bf16 planes, or MX-fp8).  Only the fp32 summation order changes: exact mode within 1e-5
+    of the unsplit launch, bf16 / mxfp8 within their re-rounding distance; the reducer's MX output is BITWISE the separate quantiser."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    ids, mask = synth_context(cfg, 1, 16, 48, seed=2)               # 64 rows
+
+    def run(precision, opts):
+        m.prefill_precision = precision
+        eng = m._ensure_engine(1, 200, 4, 128)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.reset()
+        eng.set_kv_start([0])
+        lh, lg = eng.prefill(ids, mask)
+        return lh.cpu(), lg.cpu()
+    for precision, tol in (("exact", 1e-5), ("bf16", 5e-2), ("mxfp8", 0.3)):
+        base = run(precision, dict(prefill_splitk_gu=0))
+        for ks in (2, 4):
+            split = run(precision, dict(prefill_splitk_gu=ks))
+            err = float((split[0] - base[0]).norm() / base[0].norm())
+            assert 0 < err < tol or (precision != "exact" and err == 0), (precision, ks, err)
+    a = run("mxfp8", dict(prefill_splitk_gu=2, mx_fuse_swiglu=1))
+    b = run("mxfp8", dict(prefill_splitk_gu=2, mx_fuse_swiglu=0))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    m._engine.set_option("prefill_splitk_gu", 2)
+    m._drop_engine()
