@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
   // the row stays in registers between the two passes (round 3: one read of x instead of two; rows wider than 8192 re-read)
   constexpr int KEEP = 8;
   f32x4 keep[KEEP];
+  // the partial products of a row piece are requested TOGETHER (eight at a time) and then added in split order: a short prefill's
+  // launch is one or two memory round trips long instead of one per split (64 rows x 8 splits: 8 -> 5 us per launch)
 #pragma unroll
   for (int it = 0; it < KEEP; ++it) {
     const int k = tid * 4 + it * 1024;
@@ -157,14 +159,25 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
       f32x4 v = *reinterpret_cast<const f32x4*>(xr + k);
       if (part) {
         const float* pr = part + (size_t)row * ldp + k;
-        for (int sp = 0; sp < nsplit; ++sp) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(pr + (size_t)sp * part_stride);
-          v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+          f32x4 q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (s0 + j < nsplit) q[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + (size_t)(s0 + j) * part_stride));
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (s0 + j < nsplit) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; v[3] += q[j][3]; }
         }
-        *reinterpret_cast<f32x4*>(const_cast<float*>(xr) + k) = v;
       }
       keep[it] = v;
       ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+  }
+  if (part) {   // the folded residual stream goes back in place (after every load of this thread: no store between the load batches)
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+      const int k = tid * 4 + it * 1024;
+      if (k < H) *reinterpret_cast<f32x4*>(const_cast<float*>(xr) + k) = keep[it];
     }
   }
   for (int k = tid * 4 + KEEP * 1024; k < H; k += 1024) {
@@ -364,10 +377,19 @@ __global__ __launch_bounds__(256) void rope_scatter_kernel(RopeArgs a) {
   const int nh = a.n_q + 2 * a.n_kv;
   const bool parts = a.nsplit > 1;
   const float* src = (parts ? a.part : a.qkv) + (size_t)row * nh * a.hd;
-  auto ld = [&](int col) {
+  auto ld = [&](int col) {   // the splits of an element are requested together, then added in split order
     float v = src[col];
-    if (parts)
-      for (int sp = 1; sp < a.nsplit; ++sp) v += src[(size_t)sp * a.part_stride + col];
+    if (parts) {
+      for (int s0 = 1; s0 < a.nsplit; s0 += 8) {
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < a.nsplit) q[j] = src[(size_t)(s0 + j) * a.part_stride + col];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < a.nsplit) v += q[j];
+      }
+    }
     return v;
   };
   KT* kc = reinterpret_cast<KT*>(a.kcache);
