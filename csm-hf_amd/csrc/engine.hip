@@ -156,6 +156,7 @@ struct csm_engine {
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
+  int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of <= 64 / 32 rows
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
   int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
   size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
@@ -589,6 +590,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
+  else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
@@ -1325,7 +1327,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs;
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs; g.dma_skinny = e->gemm_dma_skinny;
     RopeArgs ra{};
     bool roped = false;
     if (ks_q > 1) {
@@ -1362,7 +1364,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs;
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs; o.dma_skinny = e->gemm_dma_skinny;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
     if (att_pl && ks_o > 1) {
       o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
@@ -1376,7 +1378,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs;
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs; gu.dma_skinny = e->gemm_dma_skinny;
     gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
     if (ks_gu > 1) {   // short prefill: split over K, partials summed + SwiGLU by swiglu_reduce_kernel (misc.h)
       gu.ksplit = ks_gu; gu.Cpart = e->p_part_gu; gu.part_stride = R * (size_t)(2 * F);
@@ -1387,7 +1389,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     }
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs;
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs; d.dma_skinny = e->gemm_dma_skinny;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
     if (pl && ks_d > 1) {
       d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;

@@ -287,10 +287,15 @@ typedef __attribute__((ext_vector_type(8))) short dma_bf16x8;
 // weight fragment multiplied by lo, mid, hi in that order -- small terms first, like gemm_bf16x3_kernel).  With three planes a
 // stage is 64 KiB (one workgroup per CU), a k-step is 96 MFMAs per wave against 32 KB of operand reads: matrix-pipe bound,
 // where the one-plane form (32 MFMAs, 16 KB) sits at the LDS port's limit.
-template <int EPI, int NPL>
+// BM = activation rows per workgroup: 128, or 64 / 32 for SHORT prefills (R <= 64 / 32: the 128-row tile multiplies 64 / 96 dead rows --
+// 13.7 us of matrix work per workgroup on the gate/up projection whatever R is --; with BM rows the wave tile is BM/2 x 64, the
+// activation tile BM x 128 B and a stage 24 / 20 KiB, so two or three workgroups share a CU and the launch is bound by its weight DMA).
+template <int EPI, int NPL, int BM = 128>
 __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(GemmArgs a) {
-  constexpr int BM = 128, BN = 128, BKB = 128, BKE = 64;   // k-step: 128 bytes = 64 elements
-  constexpr int TILE = BM * BKB, STAGE = (NPL + 1) * TILE;
+  constexpr int BN = 128, BKB = 128, BKE = 64;   // k-step: 128 bytes = 64 elements
+  constexpr int RT = BM / 32;                    // 16-row MFMA tiles per wave along the activation rows
+  constexpr int AI = BM / 32;                    // LDS-DMA instructions per wave for one activation plane tile (8 rows each)
+  constexpr int ATILE = BM * BKB, WTILE = BN * BKB, STAGE = NPL * ATILE + WTILE;
   extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A planes | W tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -312,51 +317,62 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
   const uint8_t* Ab = reinterpret_cast<const uint8_t*>(a.Aplanes);
   const uint8_t* Wb = reinterpret_cast<const uint8_t*>(a.W);
   const size_t rowb = (size_t)a.K * 2, psb = a.a_plane_stride * 2;
-  const uint8_t* asrc[4];
+  const uint8_t* asrc[AI];
   const uint8_t* wsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
+    wsrc[i] = Wb + (size_t)(n0 + row) * rowb + (size_t)kbeg * 2 + c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = wave * (BM / 4) + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
     const int ra = min(r0 + row, a.R - 1);
     asrc[i] = Ab + (size_t)ra * rowb + (size_t)kbeg * 2 + c * 16;
-    wsrc[i] = Wb + (size_t)(n0 + row) * rowb + (size_t)kbeg * 2 + c * 16;
   }
   auto issue = [&](int ks, int st) {
     uint8_t* base = mx_lds + st * STAGE;
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AI; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + p * psb + (size_t)ks * BKB),
-                                         (__attribute__((address_space(3))) void*)(base + p * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(base + p * ATILE + (wave * AI + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BKB),
-                                       (__attribute__((address_space(3))) void*)(base + NPL * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + NPL * ATILE + (wave * 4 + i) * 1024), 16, 0, 0);
   };
-  f32x4 acc[4][4];
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
   const int fsw = (((j16 >> 1) & 1) << 1) | (((j16 >> 3) & 1) << 2);
   const int c0 = (g ^ fsw) * 16, c1 = ((g + 4) ^ fsw) * 16;
-  const int arow0 = (wr * 64 + j16) * BKB, wrow0 = (wc * 64 + j16) * BKB;
+  const int arow0 = (wr * (BM / 2) + j16) * BKB, wrow0 = (wc * 64 + j16) * BKB;
 
   issue(0, 0);
   for (int ks = 0; ks < nk; ++ks) {
     const int st = ks & 1;
     if (ks + 1 < nk) {
       issue(ks + 1, st ^ 1);
-      if (NPL == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // 4 (NPL + 1) DMA instructions per wave and stage stay in flight
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      // the NPL AI + 4 DMA instructions per wave of the next stage stay in flight
+      if (NPL * AI + 4 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NPL * AI + 4 == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (NPL * AI + 4 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (NPL * AI + 4 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (NPL * AI + 4 == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (NPL * AI + 4 == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     const uint8_t* At = mx_lds + st * STAGE;
-    const uint8_t* Wt = At + NPL * TILE;
+    const uint8_t* Wt = At + NPL * ATILE;
     dma_bf16x8 wf[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -364,12 +380,12 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
       *reinterpret_cast<u32x4*>(&wf[t][1]) = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BKB + c1);
     }
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
+    for (int ri = 0; ri < RT; ++ri) {
       dma_bf16x8 af[NPL][2];
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
-        *reinterpret_cast<u32x4*>(&af[p][0]) = *reinterpret_cast<const u32x4*>(At + p * TILE + arow0 + ri * 16 * BKB + c0);
-        *reinterpret_cast<u32x4*>(&af[p][1]) = *reinterpret_cast<const u32x4*>(At + p * TILE + arow0 + ri * 16 * BKB + c1);
+        *reinterpret_cast<u32x4*>(&af[p][0]) = *reinterpret_cast<const u32x4*>(At + p * ATILE + arow0 + ri * 16 * BKB + c0);
+        *reinterpret_cast<u32x4*>(&af[p][1]) = *reinterpret_cast<const u32x4*>(At + p * ATILE + arow0 + ri * 16 * BKB + c1);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -385,15 +401,15 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
   if (EPI == GEPI_ROPE) {   // this wave tile is one head of the QKV projection (gemm.h: RopeEpi)
     const int head = (n0 + wc * 64) >> 6;
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      const int r = r0 + wr * 64 + ri * 16 + j16;
+    for (int ri = 0; ri < RT; ++ri) {
+      const int r = r0 + wr * (BM / 2) + ri * 16 + j16;
       if (r < a.R) rope_epilogue_row(a.rope, r, head, g, acc[ri]);
     }
     return;
   }
 #pragma unroll
-  for (int ri = 0; ri < 4; ++ri) {
-    const int r = r0 + wr * 64 + ri * 16 + j16;
+  for (int ri = 0; ri < RT; ++ri) {
+    const int r = r0 + wr * (BM / 2) + ri * 16 + j16;
     if (r >= a.R) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {

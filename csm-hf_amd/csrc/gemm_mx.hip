@@ -46,10 +46,10 @@ int launch_mx_quant(hipStream_t st, const MxQuantArgs& a) {
   return (int)hipGetLastError();
 }
 
-template <int EPI, int NPL>
+template <int EPI, int NPL, int BM = 128>
 static int launch_dma_epi(hipStream_t st, const dim3& grid, const GemmArgs& a) {
-  constexpr size_t lds = 2 * ((NPL + 1) * 128 * 128);   // two stages of (A planes | W tile): 64 KiB (one plane) / 128 KiB (three)
-  auto fn = gemm_dma_bf16_kernel<EPI, NPL>;
+  constexpr size_t lds = 2 * (NPL * BM * 128 + 128 * 128);   // two stages of (A planes | W tile): 64 KiB (one plane) / 128 KiB (three) at BM = 128
+  auto fn = gemm_dma_bf16_kernel<EPI, NPL, BM>;
   if (lds > 64 * 1024) {   // raise the dynamic-LDS limit once per DEVICE
     static unsigned long long configured = 0ull;
     int dev = 0;
@@ -88,7 +88,16 @@ int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
   if (epi == GEPI_SWIGLU && a.Cplanes && (a.c_plane_stride != 0) != exact) return -2;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (ks < 1 || a.K % (64 * ks) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
-  const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
+  // short prefills (GemmArgs::dma_skinny): 64 / 32 activation rows per workgroup instead of 128 -- no matrix work on dead rows
+  const int bm = (a.dma_skinny && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU)) ? (a.R <= 32 ? 32 : (a.R <= 64 ? 64 : 128)) : 128;
+  const dim3 grid(((a.R + bm - 1) / bm) * (a.N / 128), ks);
+  if (bm != 128) {
+#define DMA_BM(E) return bm == 64 ? (exact ? launch_dma_epi<E, 3, 64>(st, grid, a) : launch_dma_epi<E, 1, 64>(st, grid, a)) \
+                                  : (exact ? launch_dma_epi<E, 3, 32>(st, grid, a) : launch_dma_epi<E, 1, 32>(st, grid, a))
+    if (epi == GEPI_PARTIAL) DMA_BM(GEPI_PARTIAL);
+    DMA_BM(GEPI_SWIGLU);
+#undef DMA_BM
+  }
 #define DMA_EPI(E) return exact ? launch_dma_epi<E, 3>(st, grid, a) : launch_dma_epi<E, 1>(st, grid, a)
   switch (epi) {
     case GEPI_STORE: DMA_EPI(GEPI_STORE);
