@@ -74,8 +74,8 @@ struct GemmArgs {
   // gemm256_kernel (gemm256.h: the same staging, 256 x 256 tile, 8 waves): one-plane bf16 launches whose 256 x 256 tiles (x K
   // splits) number at least big256 (0 = never)
   int big256;
-  int dma_skinny;   // 1: gemm_dma_bf16_kernel with 64 / 32 activation rows per workgroup for PARTIAL / SWIGLU launches of <= 64 / 32 rows (and
-                    // the three-plane form of that kernel for them too, instead of the 64 x 64 square tile)
+  int dma_skinny;   // 1: gemm_dma_bf16_kernel with 64 (32) activation rows per workgroup for the PARTIAL / SWIGLU launches of prefills of up to
+                    // 256 rows with one plane, 512 rows with three (there also instead of the 64 x 64 square tile); <= 32 rows: 32
   RopeEpi rope;   // GEPI_ROPE only
 };
 

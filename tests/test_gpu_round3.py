@@ -788,10 +788,11 @@ def test_split_k_gate_up_of_a_short_prefill():
 
 
 def test_skinny_tiles_of_the_lds_dma_gemm_for_short_prefills():
-    """gemm_dma_bf16_kernel<EPI, NPL, BM = 64 | 32> (csrc/gemm_mx.h): the split-K / SwiGLU launches of a prefill of <= 64 / 32 rows
-    run 64 / 32 activation rows per workgroup instead of 128 (no matrix work on dead rows; smaller stages, more workgroups per CU).
-    Every output element sees the same products in the same order as on the 128-row tile: BITWISE in bf16 mode; in exact mode the
-    three-plane LDS-DMA tile replaces the 64 x 64 square tile for these launches (fp32 summation order only)."""
+    """gemm_dma_bf16_kernel<EPI, NPL, BM = 64 | 32> (csrc/gemm_mx.h): the split-K / SwiGLU launches of a prefill of up to 256 rows
+    (bf16 mode; 512 in exact mode; <= 32 rows: BM = 32) run 64 activation rows per workgroup instead of 128 (no matrix work on dead
+    rows; smaller stages, twice the workgroups).  Every output element sees the same products in the same order as on the 128-row
+    tile: BITWISE in bf16 mode; in exact mode the three-plane LDS-DMA tile replaces the 64 x 64 square tile for these launches
+    (fp32 summation order only)."""
     cfg = CSMConfig()
     sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
     m = CSMModel(cfg)
@@ -801,14 +802,14 @@ def test_skinny_tiles_of_the_lds_dma_gemm_for_short_prefills():
     def run(precision, n_ctx, opts):
         ids, mask = synth_context(cfg, 1, n_ctx // 4, n_ctx - n_ctx // 4, seed=2)
         m.prefill_precision = precision
-        eng = m._ensure_engine(1, 200, 4, 128)
+        eng = m._ensure_engine(1, 400, 4, 256)
         for k, v in opts.items():
             eng.set_option(k, v)
         eng.reset()
         eng.set_kv_start([0])
         lh, lg = eng.prefill(ids, mask)
         return lh.cpu(), lg.cpu()
-    for n_ctx in (24, 32, 50, 64):           # 32-row and 64-row tiles, ragged and full
+    for n_ctx in (24, 32, 50, 64, 200):      # 32-row and 64-row tiles, ragged and full, several row blocks
         for gu in (0, 2):                    # SWIGLU epilogue / PARTIAL + reducer
             a = run("bf16", n_ctx, dict(gemm_dma_skinny=0, prefill_splitk_gu=gu))
             b = run("bf16", n_ctx, dict(gemm_dma_skinny=1, prefill_splitk_gu=gu))
