@@ -156,7 +156,7 @@ struct csm_engine {
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
-  int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 512 rows (exact mode)
+  int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 768 rows (exact mode)
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
   int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
   size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
@@ -590,7 +590,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
-  else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value ? 1 : 0;
+  else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value < 0 ? 0 : value;   // 2 = A/B: exact mode up to 4096 rows
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);

@@ -75,7 +75,7 @@ struct GemmArgs {
   // splits) number at least big256 (0 = never)
   int big256;
   int dma_skinny;   // 1: gemm_dma_bf16_kernel with 64 (32) activation rows per workgroup for the PARTIAL / SWIGLU launches of prefills of up to
-                    // 256 rows with one plane, 512 rows with three (there also instead of the 64 x 64 square tile); <= 32 rows: 32
+                    // 256 rows with one plane, 768 rows with three (there also instead of the 64 x 64 square tile); <= 32 rows: 32
   RopeEpi rope;   // GEPI_ROPE only
 };
 

@@ -789,7 +789,7 @@ def test_split_k_gate_up_of_a_short_prefill():
 
 def test_skinny_tiles_of_the_lds_dma_gemm_for_short_prefills():
     """gemm_dma_bf16_kernel<EPI, NPL, BM = 64 | 32> (csrc/gemm_mx.h): the split-K / SwiGLU launches of a prefill of up to 256 rows
-    (bf16 mode; 512 in exact mode; <= 32 rows: BM = 32) run 64 activation rows per workgroup instead of 128 (no matrix work on dead
+    (bf16 mode; 768 in exact mode; <= 32 rows: BM = 32) run 64 activation rows per workgroup instead of 128 (no matrix work on dead
     rows; smaller stages, twice the workgroups).  Every output element sees the same products in the same order as on the 128-row
     tile: BITWISE in bf16 mode; in exact mode the three-plane LDS-DMA tile replaces the 64 x 64 square tile for these launches
     (fp32 summation order only)."""
