@@ -156,6 +156,7 @@ struct csm_engine {
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
+  int gemm_mx_skinny = 256;     // GemmMxArgs::skinny: the same for the MX-fp8 GEMM, as a row bound (0 = off)
   int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 768 rows (exact mode)
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
   int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
@@ -590,6 +591,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
+  else if (!strcmp(name, "gemm_mx_skinny")) e->gemm_mx_skinny = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value < 0 ? 0 : value;   // 2 = A/B: exact mode up to 4096 rows
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
@@ -1177,7 +1179,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
   auto gemm = [&](int epi, const uint8_t* Wq, const uint8_t* Ws, int N, int K, float* C, int ldc, int ks, size_t pstride) {
     GemmMxArgs g{};
     g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = Wq; g.Ws = Ws; g.R = (int)R; g.N = N; g.K = K; g.C = C; g.ldc = ldc;
-    g.ksplit = ks; g.Cpart = e->p_part; g.part_stride = pstride; g.big = e->gemm_256;
+    g.ksplit = ks; g.Cpart = e->p_part; g.part_stride = pstride; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
     return launch_gemm_mx(e->stream, epi, g);
   };
   int pending = 0;
@@ -1236,21 +1238,21 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     if (ks_gu > 1) {   // short prefill: gate/up split over K, partials summed + SwiGLU + MX quantiser in swiglu_reduce_kernel (misc.h)
       GemmMxArgs g{};
       g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H;
-      g.ksplit = ks_gu; g.Cpart = e->p_part_gu; g.part_stride = R * (size_t)(2 * F); g.big = e->gemm_256;
+      g.ksplit = ks_gu; g.Cpart = e->p_part_gu; g.part_stride = R * (size_t)(2 * F); g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
       LCK(launch_gemm_mx(e->stream, GEPI_PARTIAL, g));
       LCK(launch_swiglu_reduce(e->stream, e->p_part_gu, ks_gu, g.part_stride, (int)R, F, e->p_act, F, nullptr, 0, fq ? e->p_mx_q2 : nullptr, fq ? e->p_mx_s2 : nullptr));
     } else {
       GemmMxArgs g{};
       g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.gu; g.Ws = m.gu_s; g.R = (int)R; g.N = 2 * F; g.K = H; g.C = e->p_act; g.ldc = F;
       if (fq) { g.Cq = e->p_mx_q2; g.Cs = e->p_mx_s2; }
-      g.big = e->gemm_256;
+      g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
       LCK(launch_gemm_mx(e->stream, GEPI_SWIGLU, g));
     }
     if (!fq) LCK(quant(e->p_act, F));
     {
       GemmMxArgs g{};
       g.Aq = fq ? e->p_mx_q2 : e->p_mx_q; g.As = fq ? e->p_mx_s2 : e->p_mx_s; g.Wq = m.d; g.Ws = m.d_s; g.R = (int)R; g.N = H; g.K = F;
-      g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride; g.big = e->gemm_256;
+      g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
       LCK(launch_gemm_mx(e->stream, ks_d > 1 ? GEPI_PARTIAL : GEPI_RESID, g));
       if (ks_d > 1) pending = ks_d;
     }

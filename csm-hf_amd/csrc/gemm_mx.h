@@ -43,6 +43,7 @@ struct GemmMxArgs {
   uint8_t* Cq;
   uint8_t* Cs;
   int big;             // host-side: workgroup count from which the 256 x 256 tile (gemm256.h) takes the launch (0 = never)
+  int skinny;          // host-side: > 0 = PARTIAL / SWIGLU launches of at most this many rows run 64 (<= 32 rows: 32) activation rows per workgroup
   RopeEpi rope;        // GEPI_ROPE only (gemm.h)
 };
 
@@ -97,11 +98,13 @@ __global__ __launch_bounds__(256) void mx_quant_rows_kernel(MxQuantArgs a) {
   }
 }
 
-template <int EPI>
+// BM = activation rows per workgroup (128; 64 / 32 for the split-K / SwiGLU launches of short prefills, as gemm_dma_bf16_kernel below)
+template <int EPI, int BM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
-  constexpr int BM = 128, BN = 128, BK = 128;          // activation rows, weight rows, k (= bytes) per step
-  constexpr int TILE = BM * BK;                        // 16 KiB per operand tile
-  constexpr int STAGE = 2 * TILE + 2 * BM * 4;         // + the two scale tiles [128 rows][4 k blocks]
+  constexpr int BN = 128, BK = 128;                    // weight rows, k (= bytes) per step
+  constexpr int RT = BM / 32, AI = BM / 32;            // 16-row MFMA tiles per wave along the activation rows; activation-tile DMA instructions per wave
+  constexpr int ATILE = BM * BK, TILE = BN * BK;       // activation tile; 16 KiB weight tile
+  constexpr int STAGE = ATILE + TILE + 2 * 128 * 4;    // + the two scale tiles [128 rows][4 k blocks] (the activation one is used up to row BM)
   extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];   // [2 stages][A tile | W tile | A scales | W scales]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -126,15 +129,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
 
   // ---- LDS-DMA sources of this lane.  Operand tiles: wave w, instruction i covers tile rows 32 w + 8 i .. + 8; lane l
   // lands at row + (l >> 3), chunk position l & 7, and must therefore FETCH chunk (l & 7) ^ f(row).
-  const uint8_t* asrc[4];
+  const uint8_t* asrc[AI];
   const uint8_t* wsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
+    wsrc[i] = a.Wq + (size_t)(n0 + row) * a.K + kbeg + c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = wave * (BM / 4) + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2));
     const int ra = min(r0 + row, a.R - 1);                        // rows past R: a valid address, the result is never stored
     asrc[i] = a.Aq + (size_t)ra * a.K + kbeg + c * 16;
-    wsrc[i] = a.Wq + (size_t)(n0 + row) * a.K + kbeg + c * 16;
   }
   // scale tiles: waves 0 / 1 fetch the activation rows 0-63 / 64-127, waves 2 / 3 the weight rows (4 bytes = 4 k blocks each)
   const uint8_t* ssrc;
@@ -145,20 +153,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
   auto issue = [&](int ks, int st) {
     uint8_t* base = mx_lds + st * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)ks * BK),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wave * AI + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BK),
-                                       (__attribute__((address_space(3))) void*)(base + TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + ATILE + (wave * 4 + i) * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)ks * 4),
-                                     (__attribute__((address_space(3))) void*)(base + 2 * TILE + wave * 256), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(base + ATILE + TILE + wave * 256), 4, 0, 0);
   };
 
-  f32x4 acc[4][4];   // [activation-row tile][weight-row tile]
+  f32x4 acc[RT][4];   // [activation-row tile][weight-row tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
 
@@ -168,38 +176,43 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
   // 16-byte chunks g and g + 4 (stored at g ^ f, (g + 4) ^ f; f depends on row & 15 = j16 only: tiles are 16 rows apart)
   const int fsw = (((j16 >> 1) & 1) << 1) | (((j16 >> 3) & 1) << 2);
   const int c0 = (kb ^ fsw) * 16, c1 = ((kb + 4) ^ fsw) * 16;
-  const int arow0 = (wr * 64 + j16) * BK, wrow0 = (wc * 64 + j16) * BK;
-  const int asc0 = (wr * 64 + j16) * 4 + kb, wsc0 = (wc * 64 + j16) * 4 + kb;
+  const int arow0 = (wr * (BM / 2) + j16) * BK, wrow0 = (wc * 64 + j16) * BK;
+  const int asc0 = (wr * (BM / 2) + j16) * 4 + kb, wsc0 = (wc * 64 + j16) * 4 + kb;
 
   issue(0, 0);
   for (int ks = 0; ks < nk; ++ks) {
     const int st = ks & 1;
     if (ks + 1 < nk) {
       issue(ks + 1, st ^ 1);
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // this wave's 9 DMA instructions of step ks have landed; step ks+1 stays in flight
+      // this wave's AI + 5 DMA instructions of step ks have landed; step ks+1 stays in flight
+      if (AI == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (AI == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                          // ... and so have every other wave's
     const uint8_t* At = mx_lds + st * STAGE;
-    const uint8_t* Wt = At + TILE;
-    const uint8_t* Asc = At + 2 * TILE;
-    const uint8_t* Wsc = Asc + BM * 4;
-    mx_v8i af[4], wf[4];
-    int sa[4], sw[4];
+    const uint8_t* Wt = At + ATILE;
+    const uint8_t* Asc = At + ATILE + TILE;
+    const uint8_t* Wsc = Asc + 128 * 4;
+    mx_v8i af[RT], wf[4];
+    int sa[RT], sw[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c0);
-      const u32x4 a1 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c1);
-      af[t] = mx_v8i{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+      if (t < RT) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c0);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(At + arow0 + t * 16 * BK + c1);
+        af[t < RT ? t : 0] = mx_v8i{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+        sa[t < RT ? t : 0] = (int)Asc[asc0 + t * 64];
+      }
       const u32x4 w0 = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BK + c0);
       const u32x4 w1 = *reinterpret_cast<const u32x4*>(Wt + wrow0 + t * 16 * BK + c1);
       wf[t] = mx_v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
-      sa[t] = (int)Asc[asc0 + t * 64];
       sw[t] = (int)Wsc[wsc0 + t * 64];
     }
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri)
+    for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[ri][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[ri], acc[ri][ni], 0, 0, 0, sw[ni], 0, sa[ri]);
@@ -212,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
     const int F2 = a.N >> 1;                       // SwiGLU output columns
     const int cb0 = (n0 + wc * 64) >> 1;           // first output column of this wave tile = one 32-column MX block
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      const int r = r0 + wr * 64 + ri * 16 + j16;
+    for (int ri = 0; ri < RT; ++ri) {
+      const int r = r0 + wr * (BM / 2) + ri * 16 + j16;
       float h[4][2];
       float m = 0.f;
 #pragma unroll
@@ -244,15 +257,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
   if (EPI == GEPI_ROPE) {   // this wave tile is one head of the QKV projection (gemm.h: RopeEpi)
     const int head = (n0 + wc * 64) >> 6;
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      const int r = r0 + wr * 64 + ri * 16 + j16;
+    for (int ri = 0; ri < RT; ++ri) {
+      const int r = r0 + wr * (BM / 2) + ri * 16 + j16;
       if (r < a.R) rope_epilogue_row(a.rope, r, head, kb, acc[ri]);
     }
     return;
   }
 #pragma unroll
-  for (int ri = 0; ri < 4; ++ri) {
-    const int r = r0 + wr * 64 + ri * 16 + j16;
+  for (int ri = 0; ri < RT; ++ri) {
+    const int r = r0 + wr * (BM / 2) + ri * 16 + j16;
     if (r >= a.R) continue;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {

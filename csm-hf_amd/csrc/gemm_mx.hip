@@ -3,10 +3,10 @@
 
 #include "gemm256.h"
 
-template <int EPI>
+template <int EPI, int BM = 128>
 static int launch_mx_epi(hipStream_t st, const dim3& grid, const GemmMxArgs& a) {
-  constexpr size_t lds = 2 * (2 * 128 * 128 + 2 * 128 * 4);   // two stages of (A tile | W tile | scales) = 66 KiB
-  auto fn = gemm_mx_kernel<EPI>;
+  constexpr size_t lds = 2 * (BM * 128 + 128 * 128 + 2 * 128 * 4);   // two stages of (A tile | W tile | scales) = 66 KiB at BM = 128
+  auto fn = gemm_mx_kernel<EPI, BM>;
   // more than 64 KiB of dynamic LDS: raise the limit once per DEVICE (the attribute is per device)
   static unsigned long long configured = 0ull;
   int dev = 0;
@@ -28,7 +28,11 @@ int launch_gemm_mx(hipStream_t st, int epi, const GemmMxArgs& a) {
   }
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (ks < 1 || a.K % (128 * ks)) return -2;
-  const dim3 grid(((a.R + 127) / 128) * (a.N / 128), ks);
+  // short prefills (GemmMxArgs::skinny = row bound): 64 / 32 activation rows per workgroup for the split-K / SwiGLU launches
+  const int bm = (a.skinny > 0 && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU)) ? (a.R <= 32 ? 32 : (a.R <= a.skinny ? 64 : 128)) : 128;
+  const dim3 grid(((a.R + bm - 1) / bm) * (a.N / 128), ks);
+  if (bm == 64) return epi == GEPI_PARTIAL ? launch_mx_epi<GEPI_PARTIAL, 64>(st, grid, a) : launch_mx_epi<GEPI_SWIGLU, 64>(st, grid, a);
+  if (bm == 32) return epi == GEPI_PARTIAL ? launch_mx_epi<GEPI_PARTIAL, 32>(st, grid, a) : launch_mx_epi<GEPI_SWIGLU, 32>(st, grid, a);
   switch (epi) {
     case GEPI_STORE: return launch_mx_epi<GEPI_STORE>(st, grid, a);
     case GEPI_RESID: return launch_mx_epi<GEPI_RESID>(st, grid, a);

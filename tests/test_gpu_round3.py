@@ -820,3 +820,32 @@ def test_skinny_tiles_of_the_lds_dma_gemm_for_short_prefills():
         assert err < 1e-5, (n_ctx, err)
     m._engine.set_option("gemm_dma_skinny", 1)
     m._drop_engine()
+
+
+def test_skinny_tiles_of_the_mx_gemm_are_bitwise():
+    """gemm_mx_kernel<EPI, BM = 64 | 32> (csrc/gemm_mx.h): the MX-fp8 form of the 64 / 32-row workgroups for the split-K / SwiGLU
+    launches of short prefills (engine option gemm_mx_skinny = row bound).  Same products in the same order per output element:
+    bitwise the 128-row tile (hidden state and logits of whole csm-1b prefills, SwiGLU with the fused quantiser and through the reducer)."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    m.prefill_precision = "mxfp8"
+
+    def run(n_ctx, opts):
+        ids, mask = synth_context(cfg, 1, n_ctx // 4, n_ctx - n_ctx // 4, seed=2)
+        eng = m._ensure_engine(1, 400, 4, 256)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.reset()
+        eng.set_kv_start([0])
+        lh, lg = eng.prefill(ids, mask)
+        return lh.cpu(), lg.cpu()
+    for n_ctx in (24, 64, 100, 200):
+        for gu in (0, 2):
+            a = run(n_ctx, dict(gemm_mx_skinny=0, prefill_splitk_gu=gu))
+            b = run(n_ctx, dict(gemm_mx_skinny=256, prefill_splitk_gu=gu))
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (n_ctx, gu, float((a[0] - b[0]).abs().max()))
+    m._engine.set_option("gemm_mx_skinny", 256)
+    m._drop_engine()
