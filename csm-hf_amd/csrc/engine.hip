@@ -156,6 +156,7 @@ struct csm_engine {
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
+  int prefill_part_resid = 0;   // A/B (GemmArgs::part_resid): split 0 of a split-K o_proj / down_proj adds straight into the residual stream, the next RMSNorm folds the other ksplit - 1.  Bitwise the all-partials form and MEASURED SLOWER (the split-0 workgroups' read-modify-write makes them the launch's tail: 512 / 2 048 frames bf16 2.34 / 5.79 -> 2.42 / 5.85 ms, mxfp8 1.93 / 4.50 -> 2.00 / 4.63): off
   int gemm_mx_skinny = 256;     // GemmMxArgs::skinny: the same for the MX-fp8 GEMM, as a row bound (0 = off)
   int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 768 rows (exact mode)
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
@@ -591,6 +592,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefill_part_resid")) e->prefill_part_resid = value ? 1 : 0;
   else if (!strcmp(name, "gemm_mx_skinny")) e->gemm_mx_skinny = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value < 0 ? 0 : value;   // 2 = A/B: exact mode up to 4096 rows
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
@@ -1187,7 +1189,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     const csm_layer_weights_t& w = s.layers[l];
     const csm_mx_layer_t& m = e->mx_layers[l];
     LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln1, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, nullptr, 0,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));   // normed rows leave as MX-fp8
+                       pending > 0 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));   // normed rows leave as MX-fp8
     pending = 0;
     RopeArgs ra{};
     bool roped = false;
@@ -1226,13 +1228,21 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     LCK(fr);
     if (!att_q) LCK(quant(e->p_att, A));
     if (ks_o > 1) {
-      LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
-      pending = ks_o;
+      if (e->prefill_part_resid) {
+        GemmMxArgs g{};
+        g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.o; g.Ws = m.o_s; g.R = (int)R; g.N = H; g.K = A; g.C = e->p_h; g.ldc = H;
+        g.ksplit = ks_o; g.Cpart = e->p_part; g.part_stride = part_stride; g.part_resid = 1; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
+        LCK(launch_gemm_mx(e->stream, GEPI_PARTIAL, g));
+        pending = ks_o - 1;
+      } else {
+        LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
+        pending = ks_o;
+      }
     } else {
       LCK(gemm(GEPI_RESID, m.o, m.o_s, H, A, e->p_h, H, 1, 0));
     }
     LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln2, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, nullptr, 0,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));
+                       pending > 0 ? e->p_part : nullptr, pending, part_stride, H, e->p_mx_q, e->p_mx_s));
     pending = 0;
     const bool fq = e->mx_fuse_swiglu != 0;
     if (ks_gu > 1) {   // short prefill: gate/up split over K, partials summed + SwiGLU + MX quantiser in swiglu_reduce_kernel (misc.h)
@@ -1253,8 +1263,9 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
       GemmMxArgs g{};
       g.Aq = fq ? e->p_mx_q2 : e->p_mx_q; g.As = fq ? e->p_mx_s2 : e->p_mx_s; g.Wq = m.d; g.Ws = m.d_s; g.R = (int)R; g.N = H; g.K = F;
       g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
+      g.part_resid = (ks_d > 1 && e->prefill_part_resid) ? 1 : 0;
       LCK(launch_gemm_mx(e->stream, ks_d > 1 ? GEPI_PARTIAL : GEPI_RESID, g));
-      if (ks_d > 1) pending = ks_d;
+      if (ks_d > 1) pending = ks_d - g.part_resid;
     }
   }
   *pending_out = pending;
@@ -1324,7 +1335,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
   for (int l = 0; l < s.c.layers; ++l) {
     const csm_layer_weights_t& w = s.layers[l];
     LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln1, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H));
+                       pending > 0 ? e->p_part : nullptr, pending, part_stride, H));
     pending = 0;
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
@@ -1369,14 +1380,14 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs; o.dma_skinny = e->gemm_dma_skinny;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
     if (att_pl && ks_o > 1) {
-      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
+      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride; o.part_resid = e->prefill_part_resid;
       LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, o));
-      pending = ks_o;
+      pending = ks_o - o.part_resid;
     } else {
       LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
     }
     LCK(launch_rmsnorm(e->stream, e->p_h, H, w.ln2, (int)R, H, s.c.rms_eps, e->p_xn, H, nullptr, 0, 0, pl ? e->p_pl_h : nullptr, ps_h,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, H));
+                       pending > 0 ? e->p_part : nullptr, pending, part_stride, H));
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
@@ -1394,9 +1405,9 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs; d.dma_skinny = e->gemm_dma_skinny;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
     if (pl && ks_d > 1) {
-      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
+      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride; d.part_resid = e->prefill_part_resid;
       LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, d));
-      pending = ks_d;
+      pending = ks_d - d.part_resid;
     } else {
       LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
     }
@@ -1428,7 +1439,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   if (int r = stack_rows(e, s, s.kc.data(), s.vc.data(), s.lmax, B, S, e->h_len, e->d_kv_start, rope_pos, true, &pending, &part_stride)) return r;
   if (all_h_out) {   // training forward: the final-normed hidden state of EVERY row (the last layer's partials fold in here)
     LCK(launch_rmsnorm(e->stream, e->p_h, Hb, s.final_norm, (int)R, Hb, s.c.rms_eps, all_h_out, Hb, nullptr, 0, 0, nullptr, 0,
-                       pending > 1 ? e->p_part : nullptr, pending, part_stride, Hb));
+                       pending > 0 ? e->p_part : nullptr, pending, part_stride, Hb));
     pending = 0;
   }
   // last position of every sequence: rows b*S + S-1
@@ -1436,7 +1447,7 @@ static int prefill_impl(csm_engine_t* e, const int64_t* ids, const uint8_t* mask
   const int ldl = S * Hb;
   // (the last layer's split-K partials are folded into the last rows here, in place, before the head reads them)
   LCK(launch_rmsnorm(e->stream, hl, ldl, s.final_norm, B, Hb, s.c.rms_eps, e->last_h, Hb, nullptr, 0, 0, nullptr, 0,
-                     pending > 1 ? e->p_part + (size_t)(S - 1) * Hb : nullptr, pending, part_stride, ldl));
+                     pending > 0 ? e->p_part + (size_t)(S - 1) * Hb : nullptr, pending, part_stride, ldl));
   LCK(launch_set_int(e->stream, e->d_len, e->h_len + S));
   LCK(backbone_head(e, hl, ldl, B, false, false));
   e->h_len += S;
@@ -1499,7 +1510,7 @@ extern "C" int csm_prefill_slot(csm_engine_t* e, int row, const int64_t* ids, co
   }
   const float* hl = e->p_h + (size_t)(n - 1) * Hb;
   LCK(launch_rmsnorm(e->stream, hl, Hb, s.final_norm, 1, Hb, s.c.rms_eps, e->last_h + (size_t)row * Hb, Hb, nullptr, 0, 0, nullptr, 0,
-                     pending > 1 ? e->p_part + (size_t)(n - 1) * Hb : nullptr, pending, part_stride, Hb));
+                     pending > 0 ? e->p_part + (size_t)(n - 1) * Hb : nullptr, pending, part_stride, Hb));
   GemvArgs a{};
   a.nt = e->nt_backbone;
   a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;
@@ -1546,7 +1557,7 @@ extern "C" int csm_prefill_slots(csm_engine_t* e, const int32_t* rows, const int
     const size_t last = (size_t)i * S + (S - 1);
     const float* hl = e->p_h + last * Hb;
     LCK(launch_rmsnorm(e->stream, hl, Hb, s.final_norm, 1, Hb, s.c.rms_eps, e->last_h + (size_t)rows[i] * Hb, Hb, nullptr, 0, 0, nullptr, 0,
-                       pending > 1 ? e->p_part + last * Hb : nullptr, pending, part_stride, Hb));
+                       pending > 0 ? e->p_part + last * Hb : nullptr, pending, part_stride, Hb));
     GemvArgs a{};
     a.nt = e->nt_backbone;
     a.W = e->w.proj_head0; a.wscale = e->w.s_proj_head0; a.N = e->cfg.decoder.hidden + e->cfg.audio_vocab; a.K = Hb;

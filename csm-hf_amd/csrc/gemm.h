@@ -57,6 +57,11 @@ struct GemmArgs {
   int ksplit;
   float* Cpart;
   size_t part_stride;
+  // part_resid = 1 (residual GEMMs: o_proj, down_proj): split 0 adds its partial product straight into the residual stream C (the
+  // RESID epilogue) and only splits 1.. go to Cpart (+ (s - 1) * part_stride): the consumer folds ksplit - 1 partials.  x + p0 is
+  // the first addition of the fold either way, so the result is bitwise the all-partials form at one partial array less written
+  // and re-read (16.8 MB each way per launch at 2 048 rows)
+  int part_resid;
   // fragment-order copy of W (launchers.hip tile16_kernel; nullable): enables gemm_wide_kernel for one-plane activations
   const void* Wt;
   // gemm_wide_kernel switches (per engine, csm_set_option): wide = 0 keeps the square tile; wide_depth = weight-fragment
@@ -226,7 +231,10 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
             else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
           }
         } else if (r < a.R) {
-          if (EPI == GEPI_PARTIAL) a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
+          if (EPI == GEPI_PARTIAL) {
+            if (a.part_resid && blockIdx.y == 0) a.C[(size_t)r * a.ldc + n] += v;
+            else a.Cpart[(size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n] = v;
+          }
           else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
         }
@@ -413,7 +421,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
             else a.C[(size_t)r * a.ldc + (n >> 1)] = hv;
           }
         } else if (r < a.R) {
-          if (EPI == GEPI_PARTIAL) a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
+          if (EPI == GEPI_PARTIAL) {
+            if (a.part_resid && blockIdx.y == 0) a.C[(size_t)r * a.ldc + n] += v;
+            else a.Cpart[(size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n] = v;
+          }
           else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
         }
@@ -595,7 +606,14 @@ __global__ __launch_bounds__(256, (DEPTH == 1 && NPL == 1) ? 2 : 1) void gemm_wi
           c[0] = h0; c[1] = h1;
         }
       } else if (EPI == GEPI_PARTIAL) {
-        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
+          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+          const f32x4 o = *c;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          *c = v;
+        } else {
+          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
+        }
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;

@@ -43,6 +43,7 @@ struct GemmMxArgs {
   uint8_t* Cq;
   uint8_t* Cs;
   int big;             // host-side: workgroup count from which the 256 x 256 tile (gemm256.h) takes the launch (0 = never)
+  int part_resid;      // GEPI_PARTIAL: split 0 adds into C (RESID), splits 1.. go to Cpart (GemmArgs::part_resid, gemm.h)
   int skinny;          // host-side: > 0 = PARTIAL / SWIGLU launches of at most this many rows run 64 (<= 32 rows: 32) activation rows per workgroup
   RopeEpi rope;        // GEPI_ROPE only (gemm.h)
 };
@@ -275,7 +276,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
         const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
         *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
       } else if (EPI == GEPI_PARTIAL) {
-        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
+          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+          const f32x4 o = *c;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          *c = v;
+        } else {
+          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
+        }
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;
@@ -439,7 +447,14 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
           *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
         }
       } else if (EPI == GEPI_PARTIAL) {
-        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
+          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+          const f32x4 o = *c;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          *c = v;
+        } else {
+          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
+        }
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;
@@ -566,7 +581,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma3_k32_kernel(GemmArgs a) {
           *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
         }
       } else if (EPI == GEPI_PARTIAL) {
-        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
+        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
+          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
+          const f32x4 o = *c;
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          *c = v;
+        } else {
+          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
+        }
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;
