@@ -156,6 +156,7 @@ struct csm_engine {
   int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
+  int prefill_plane_pad = 2176; // elements between the bf16 planes of an exact-mode operand beyond R K (multiple of 8, <= 8192).  Measured over 4 processes each at 2 048 rows: pad 0 16.1 / 18.2 / 16.1 / 18.3 ms (bimodal by process), 2176: 16.2 / 16.2 / 16.7 / 16.9; 1088: 17.5; 4224: 16.3 / 17.4; no effect at 512 / 1 024 / 16 x 512 rows
   int prefill_part_resid = 0;   // A/B (GemmArgs::part_resid): split 0 of a split-K o_proj / down_proj adds straight into the residual stream, the next RMSNorm folds the other ksplit - 1.  Bitwise the all-partials form and MEASURED SLOWER (the split-0 workgroups' read-modify-write makes them the launch's tail: 512 / 2 048 frames bf16 2.34 / 5.79 -> 2.42 / 5.85 ms, mxfp8 1.93 / 4.50 -> 2.00 / 4.63): off
   int gemm_mx_skinny = 256;     // GemmMxArgs::skinny: the same for the MX-fp8 GEMM, as a row bound (0 = off)
   int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 768 rows (exact mode)
@@ -378,7 +379,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     return r;
   if (cfg->weight_dtype != CSM_DTYPE_F32) {
     const size_t Km = std::max(Hm_, nqm);
-    if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km)) || (r = dalloc(e, &e->p_pl_act, 3 * R * ffm))) return r;
+    if ((r = dalloc(e, &e->p_pl_h, 3 * R * Km + 3 * 8192)) || (r = dalloc(e, &e->p_pl_act, 3 * R * ffm + 3 * 8192))) return r;   // + room for the plane pad (prefill_plane_pad <= 8192 elements)
     if (R <= 4096 && (r = dalloc(e, &e->p_part, 4 * R * Hm_))) return r;   // only small prefills are short of workgroups
     e->p_part_h = Hm_;
   }
@@ -592,6 +593,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
   else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefill_plane_pad")) e->prefill_plane_pad = value < 0 ? 0 : (value > 8192 ? 8192 : (value & ~7));
   else if (!strcmp(name, "prefill_part_resid")) e->prefill_part_resid = value ? 1 : 0;
   else if (!strcmp(name, "gemm_mx_skinny")) e->gemm_mx_skinny = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value < 0 ? 0 : value;   // 2 = A/B: exact mode up to 4096 rows
@@ -1292,7 +1294,10 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
   // prefill_precision = bf16: ONE plane (activations rounded to nearest bf16 by the producer), flagged by a plane
   // stride of 0; = exact: three planes, one stride apart
   const bool one = pl && e->prefill_bf16;
-  const size_t ps_h = one ? 0 : R * (size_t)H, ps_att = one ? 0 : R * (size_t)(nq * hd), ps_act = one ? 0 : R * (size_t)F;
+  // the three planes of an exact-mode operand sit a power-of-two distance apart when R K is one (2 048 x 2 048 x 2 B = 8 MiB): the three DMA
+  // requests of a tile then meet in the same memory channel.  A pad between the planes (prefill_plane_pad elements) moves them apart
+  const size_t ppad = (size_t)e->prefill_plane_pad;
+  const size_t ps_h = one ? 0 : R * (size_t)H + ppad, ps_att = one ? 0 : R * (size_t)(nq * hd) + ppad, ps_act = one ? 0 : R * (size_t)F + ppad;
   // split-K for the residual GEMMs (o_proj, down_proj) of a small prefill: partial products go to p_part and the NEXT
   // RMSNorm launch folds them into the residual stream (fixed order: deterministic)
   const bool can_split = allow_split && pl && e->prefill_splitk && e->p_part && R <= 4096;
