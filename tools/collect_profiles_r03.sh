@@ -80,3 +80,10 @@ python tools/pmc_summary.py $O/pmc_fetch_size/r03_results.db 6 $O/pmc_write_size
 rm -rf $O/pmc_fetch_size $O/pmc_write_size
 timeout 400 python tools/serve_bench.py 64 16 2>&1 | grep -v amdgpu > $O/serve_bench.txt
 ls -la $O | head -40; head -c 600 $O/bench.json
+# ---- second half of the round: prefill fusions and short-prefill tiles (each script writes gpurun_out/<name>.txt; copied to profiles/r03_*.txt)
+bash tools/fuse_probe.sh        > /dev/null 2>&1   # -> profiles/r03_prefill_fused_epilogues.txt   (GEPI_ROPE, MX output of the attention)
+bash tools/gu_split_probe.sh    > /dev/null 2>&1   # -> profiles/r03_prefill_gateup_splitk.txt     (split-K gate/up + swiglu_reduce_kernel)
+bash tools/skinny_probe.sh      > /dev/null 2>&1   # -> profiles/r03_prefill_skinny_tiles.txt      (64 / 32-row workgroups of the LDS-DMA GEMM)
+bash tools/streamer_b16_probe.sh > /dev/null 2>&1  # -> profiles/r03_streamer_b16.txt              (weight streamer beside the B = 16 chain)
+bash tools/prefill_profile.sh "2048 1" "2048 2" "512 1" "512 2" > /dev/null 2>&1   # -> profiles/r03_prefill{2048,512}_{bf16,mxfp8}_kernel_stats.md
+bash tools/final_check.sh       > /dev/null 2>&1   # -> profiles/r03_bench.json, r03_bench_config5.json, last sections of r03_prefill.txt / r03_serve_bench.txt
