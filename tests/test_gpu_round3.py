@@ -748,6 +748,22 @@ def test_rope_epilogue_of_the_qkv_gemm_and_mx_output_of_the_attention_are_bitwis
                 if precision == "mxfp8":
                     both = run(m, ids, mask, starts, precision, dict(prefill_fuse_rope=1, prefill_fuse_quant=1, **common))
                     same(base, both, (kv_dtype, precision, opts, "quant", len(starts)))
+        # caller-supplied rotation positions (position_ids != cache slot) and a second chunk on a partly filled cache (past > 0)
+        pos = (torch.arange(256)[None] * 3 + 5) % 1500
+        for fuse in (0, 1):
+            m.prefill_precision = "bf16"
+            eng = m._ensure_engine(2, 600, 4, 512)
+            for k, v in dict(gemm_wide=0, prefill_splitk=0, gemm_256=0, gemm_dma=2, prefill_fuse_rope=fuse).items():
+                eng.set_option(k, v)
+            eng.reset()
+            eng.set_kv_start([0])
+            eng.prefill(ids1[:, :128], mask1[:, :128], position_ids=pos[:, :128])
+            lh, lg = eng.prefill(ids1[:, 128:], mask1[:, 128:], position_ids=pos[:, 128:])
+            got = (lh.cpu(), lg.cpu(), [(k.cpu(), v.cpu()) for k, v in eng.export_kv()])
+            if fuse == 0:
+                want = got
+            else:
+                same(want, got, (kv_dtype, "position_ids + two chunks"))
         m._engine.set_option("gemm_256", 256)
         m._drop_engine()
 
