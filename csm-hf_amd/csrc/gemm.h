@@ -80,7 +80,8 @@ struct GemmArgs {
   // splits) number at least big256 (0 = never)
   int big256;
   int dma_skinny;   // 1: gemm_dma_bf16_kernel with 64 (32) activation rows per workgroup for the PARTIAL / SWIGLU launches of prefills of up to
-                    // 256 rows with one plane, 768 rows with three (there also instead of the 64 x 64 square tile); <= 32 rows: 32
+                    // 256 rows with one plane, 768 rows with three (there also instead of the 64 x 64 square tile); <= 32 rows: 32.  A/B bits: 2 = three planes up to 4096 rows
+                    // (2 048 rows: 16.2 -> 21.7 ms), 4 = keep 128 rows for launches of >= 512 workgroups (512 / 768 rows exact 4.38 / 6.59 -> 4.53 / 6.75 ms)
   RopeEpi rope;   // GEPI_ROPE only
 };
 

@@ -95,7 +95,9 @@ int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
   // short prefills (GemmArgs::dma_skinny): 64 / 32 activation rows per workgroup instead of 128 -- no matrix work on dead rows
   // Measured (whole csm-1b prefills, profiles/r03_prefill_skinny_tiles.txt): one plane: 64 rows per workgroup win up to 256 rows
   // (192 rows 1.86 -> 1.77 ms) and lose from 384 on (512 rows 2.34 -> 2.61); three planes: they win up to 768 rows (384 / 768 rows 4.36 / 7.33 -> 3.67 / 6.71), tie at 1024 and lose at 2048 (16.2 -> 21.7)
-  const int bm = (a.dma_skinny && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU)) ? (a.R <= 32 ? 32 : (a.R <= (exact ? (a.dma_skinny >= 2 ? 4096 : 768) : 256) ? 64 : 128)) : 128;
+  const long wgs128 = (long)((a.R + 127) / 128) * (a.N / 128) * ks;   // dma_skinny bit 2 (value 4, A/B): 64-row workgroups only for launches short of 512 workgroups
+  const int bm = (a.dma_skinny && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU) && !((a.dma_skinny & 4) && wgs128 >= 512 && a.R > 64))
+                     ? (a.R <= 32 ? 32 : (a.R <= (exact ? ((a.dma_skinny & 2) ? 4096 : 768) : 256) ? 64 : 128)) : 128;
   const dim3 grid(((a.R + bm - 1) / bm) * (a.N / 128), ks);
   if (bm != 128) {
 #define DMA_BM(E) return bm == 64 ? (exact ? launch_dma_epi<E, 3, 64>(st, grid, a) : launch_dma_epi<E, 1, 64>(st, grid, a)) \

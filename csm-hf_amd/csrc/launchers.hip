@@ -150,7 +150,7 @@ static int launch_gemm_x3(hipStream_t st, int epi, const GemmArgs& a) {
     // (three planes: one 4-wave workgroup per CU -- below ~256 rows the 64 x 64 square tile's many small workgroups win:
     //  64 rows 1.96 vs 2.32 ms per prefill; 512 / 2048 rows 5.03 / 17.2 -> 4.52 / 16.1 ms; 16 x 512 rows 56 vs 71 ms)
     const long dma_wgs = (long)((a.R + 127) / 128) * (a.N / 128) * (epi == GEPI_PARTIAL ? a.ksplit : 1);
-    const bool skinny3 = exact && (a.dma & 4) && a.dma_skinny && a.R <= (a.dma_skinny >= 2 ? 4096 : 768) && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU);   // prefills of up to 768 rows, three planes: the BM = 64 / 32 LDS-DMA tile instead of the 64 x 64 square tile
+    const bool skinny3 = exact && (a.dma & 4) && a.dma_skinny && a.R <= ((a.dma_skinny & 2) ? 4096 : 768) && (epi == GEPI_PARTIAL || epi == GEPI_SWIGLU);   // prefills of up to 768 rows, three planes: the BM = 64 / 32 LDS-DMA tile instead of the 64 x 64 square tile
     if (exact ? ((a.dma & 8) || skinny3 || ((a.dma & 4) && a.R >= 256 && a.R <= a.dma_max_rows && dma_wgs >= a.dma_min_wgs)) : ((a.dma & 2) || ((a.dma & 1) && a.R <= a.dma_max_rows))) {
       const int r = launch_gemm_dma_bf16(st, epi, a);
       if (r != -2) return r;
