@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
   float* o = out + (size_t)row * ldo;
   if (frame_ptr) o += (size_t)(*frame_ptr + frame_add) * frame_stride;
   float ss = 0.f;
+  const bool late_store = gridDim.x <= 512;
   // the row stays in registers between the two passes (round 3: one read of x instead of two; rows wider than 8192 re-read)
   constexpr int KEEP = 8;
   f32x4 keep[KEEP];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
           f32x4 q[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (s0 + j < nsplit) q[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr + (size_t)(s0 + j) * part_stride));
+            if (s0 + j < nsplit) q[j] = *reinterpret_cast<const f32x4*>(pr + (size_t)(s0 + j) * part_stride);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (s0 + j < nsplit) { v[0] += q[j][0]; v[1] += q[j][1]; v[2] += q[j][2]; v[3] += q[j][3]; }
@@ -171,9 +172,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
       }
       keep[it] = v;
       ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      // many rows (bandwidth-bound launch): the folded piece goes back at once, under the next piece's loads
+      if (part && !late_store) *reinterpret_cast<f32x4*>(const_cast<float*>(xr) + k) = v;
     }
   }
-  if (part) {   // the folded residual stream goes back in place (after every load of this thread: no store between the load batches)
+  if (part && late_store) {   // few rows (latency-bound launch): after every load of this thread, so that no store sits between the load batches
 #pragma unroll
     for (int it = 0; it < KEEP; ++it) {
       const int k = tid * 4 + it * 1024;
