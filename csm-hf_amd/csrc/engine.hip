@@ -691,6 +691,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       const bool rec = e->pf_rec && M <= 16 && e->pf_batched;
       if (!a.g16_nw && e->g16_k16 && a.K == 2048 && a.xplanes) { a.g16_nw = e->g16_k16 & 0xff; a.g16_kb = (e->g16_k16 >> 8) & 0xff; }
       if (rec) { a.prog = e->d_prog; a.geom_out = &geom; }
+      if (e->g16_slab >> 4) a.g16_slab = (a.g16_slab & 3) | (e->g16_slab & ~15);   // TIMING-ONLY in-kernel knock-outs (gemm16.h), every matrix-core launch
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       a.prog = nullptr; a.geom_out = nullptr;

@@ -178,11 +178,20 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   if (EPI == EPI_QKV) prefetch_epi();
   bf16x8 xh[4], xm[4], xl[4];
   f32x4 xa[4], xb[4], la[4], lb[4];
+  // TIMING-ONLY knock-outs inside the launch (g16_slab bits 4-7, wrong results by construction; tools/g16_inkernel_probe.sh):
+  // 16 = no activation-plane loads, 32 = no weight-fragment loads, 64 = no MFMAs, 128 = no plane stores in the epilogue
+#ifdef CSM_G16_KO   // variant build only (python -c "from csm_hf_amd import build; build.build_library(defines=('CSM_G16_KO',), out='csm-hf_amd/libcsm_hip_g16ko.so')";
+                    // CSM_HIP_LIB selects it): the runtime branches cost the default build 5 % of the B = 16 step
+  const int ko = a.g16_slab >> 4;
+#else
+  constexpr int ko = 0;
+#endif
   if (XP) {
     const bf16_t* pp = a.xplanes + ((size_t)chunk * 256 + lane) * 8;
     const size_t ps = (size_t)K * 16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (ko & 1) { xh[j] = xm[j] = xl[j] = (bf16x8)(short)(lane + j); continue; }
       xh[j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
       xm[j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
       xl[j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
@@ -210,7 +219,10 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       const size_t tile = (size_t)(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4);
       const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
+      for (int j = 0; j < 4; ++j) {
+        if (ko & 2) { wf[t][j].load(reinterpret_cast<const WT*>(a.Wt) + lane * 8, 0); continue; }   // one hot KiB instead of the stream
+        wf[t][j].load(wr + j * 512, a.nt);
+      }
     } else {
       int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
       n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const bf16x8 af = wf[t][j].get();
+      if (ko & 4) { acc[t][0] += (float)af[0] + (float)xl[j][0] + (float)xm[j][1] + (float)xh[j][2]; continue; }   // operands stay live, no matrix work
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[j], acc[t], 0, 0, 0);  // small terms first
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[j], acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[j], acc[t], 0, 0, 0);
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     for (int e = 0; e < NQ; ++e) {
       const int q = tid + e * 64 * NW;
       if (q < PT * 64) {
-        if (a.g16_slab) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, 0);
+        if (a.g16_slab & 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, /*sc1*/ 16);
       }
     }
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       f32x4 v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb)
-        v[kb] = kb < KB ? (a.g16_slab == 2 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, 0))
+        v[kb] = kb < KB ? ((a.g16_slab & 3) == 2 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, 0))
                                            : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, /*sc1*/ 16)))
                         : (f32x4)(0.f);
       f32x4 s = (f32x4)(0.f);
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         if (EPI == EPI_RESID) {
           const f32x4 xn = rq + pv;
           *reinterpret_cast<f32x4*>(a.out + (size_t)mm * a.ldo + n0) = xn;
-          if (a.oplanes) {
+          if (a.oplanes && !(ko & 8)) {
             f32x4 xt;
             xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
             store_planes4(a.oplanes, (size_t)a.N * 16, n0, mm, xt);
@@ -371,7 +384,8 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         } else {   // SwiGLU: (gate, up) pairs
           const float h0 = (pv[0] / (1.f + __expf(-pv[0]))) * pv[1];
           const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
-          if (a.oplanes) store_planes2(a.oplanes, (size_t)(a.N >> 1) * 16, n0 >> 1, mm, h0, h1);   // the consumer reads the planes only
+          if (a.oplanes && !(ko & 8)) store_planes2(a.oplanes, (size_t)(a.N >> 1) * 16, n0 >> 1, mm, h0, h1);   // the consumer reads the planes only
+          else if (a.oplanes) {}
           else *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
         }
       }
