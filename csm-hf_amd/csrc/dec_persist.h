@@ -26,13 +26,14 @@
 namespace dpk {
 constexpr int H = 1024, F = 8192, NQ = 8, NKV = 2, HD = 128, NQKV = (NQ + 2 * NKV) * HD;   // csm-1b decoder
 constexpr int NCU = 256, NCW = 4, NTHREADS = 64 * (NCW + 1);
-constexpr int RING = 30, SLOT = 4096, DEPTH = 8;   // ring slots, bytes per slot, slots in flight
+constexpr int RING = 34, SLOT = 4096, DEPTH = 8;   // ring slots, bytes per slot, slots in flight
 constexpr int S_QKV = 0, S_O = 3, S_GU = 5, S_DN = 37, SLOTS_LAYER = 53, SLOTS_HEAD = 5;
 // granule arrays (8 bytes each)
 constexpr int GX = 0, GQ = GX + H, GO = GQ + NQKV, GA = GO + H, GH = GA + F, GTOT = GH + 2 * NCU;
 // LDS map (bytes)
-constexpr int LDS_X = RING * SLOT, LDS_U = LDS_X + H * 4, LDS_BYTES = LDS_U + F * 4;   // + the static control block (Misc, 240 bytes)
-constexpr int U_Q = 0, U_ATT = NQKV * 4, U_P = U_ATT + H * 4;   // q|k|v, attention output, softmax strips: alias the SwiGLU vector
+// ring | per-consumer strip (q of two heads, new k, new v: 2 KiB each) | attention output | softmax strips; the 1024- and
+// 8192-vectors handed between CUs live in REGISTERS of the waves that multiply them (no LDS copy, no barrier)
+constexpr int LDS_SQW = RING * SLOT, LDS_ATT = LDS_SQW + NCW * 2048, LDS_P = LDS_ATT + H * 4, LDS_XA = LDS_P + NCW * 256, LDS_XB = LDS_XA + H * 4, LDS_BYTES = LDS_XB + H * 4;   // + the static control block
 constexpr unsigned ABORT = 0x40000000u;
 }  // namespace dpk
 
@@ -73,8 +74,8 @@ struct DecPersistArgs {
 namespace dpk {
 typedef unsigned long long u64;
 struct Misc {
-  unsigned landed, sync, pcnt, dead;
-  unsigned slot_gen[32];
+  unsigned landed, sync, pcnt, dead, gathering, pad_[3];
+  unsigned slot_gen[40];
   float part[4][4];
   float amv[4];
   int ami[4];
@@ -96,7 +97,7 @@ __device__ __forceinline__ void give_up(const DecPersistArgs& a, unsigned code, 
     *LW(dead) = 1u;
     *LW(landed) = ABORT; *LW(sync) = ABORT; *LW(pcnt) = ABORT;
 #pragma unroll 1
-    for (int i = 0; i < 32; ++i) LW(slot_gen)[i] = ABORT;
+    for (int i = 0; i < 40; ++i) LW(slot_gen)[i] = ABORT;
     if (atomicAdd(a.err, 1u) == 0u) a.err[1] = code;
   }
 }
@@ -108,6 +109,7 @@ __device__ __forceinline__ void lds_wait(const DecPersistArgs& a, const volatile
   const long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned spins = 0;
   while (__builtin_amdgcn_readfirstlane(lds_ld(p)) < target) {
+    __builtin_amdgcn_s_sleep(1);   // leave the LDS queue to the DMA and to the waves that compute
     if ((++spins & 1023u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > 10000000ll || lds_ld(LW(dead)))) { give_up(a, code, lane); break; }
   }
   asm volatile("" ::: "memory");
@@ -224,33 +226,86 @@ __device__ __forceinline__ void dot_pair(const char* slot, const f32x2 (&xp)[2][
   wave_sum2(s0, s1);
 }
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes from `src` (per lane) to 1 KiB of LDS at byte address `dst` (wave-uniform).
+// Inline asm on purpose: issued through the builtin, hipcc orders every later LDS access of the wave (the ring's control
+// words) behind the DMA with s_waitcnt vmcnt(0) -- ONE fill in flight, 0.66 us per 4 KiB, the whole engine starved (first
+// measurements of this file).  The asm is invisible to that pass; landing is counted by the loader's own vmcnt(32).
+template <bool NT>
+__device__ __forceinline__ void dma1k(const char* src, unsigned dst) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
 template <bool NT>
 __device__ __forceinline__ void loader(const DecPersistArgs& a, char* smem, int cu, int lane) {
   unsigned i = 0, pos = 0, gen = 0;
-  auto* lbase = (__attribute__((address_space(3))) char*)smem;
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const bool prof = a.dbg && cu == 0;
+  long long t_full = 0, t_vm = 0;
+  const long long t_begin = __builtin_amdgcn_s_memrealtime();
+  // snapshot of the release words: lane L holds slot_gen[L], lanes >= 40 hold `dead` -- ONE LDS read serves many fills (an LDS
+  // round trip per fill sat behind the consumers' read bursts and polls)
+  unsigned sg = 0;
+  bool alive = true;
+  auto snap = [&]() {
+    sg = lds_ld(lane < 40 ? LW(slot_gen) + lane : (lane == 62 ? LW(gathering) : LW(dead)));
+    alive = __builtin_amdgcn_readlane(sg, 63) == 0u;
+  };
   auto fill = [&](const char* s0, const char* s1, const char* s2, const char* s3) {
-    if (__builtin_amdgcn_readfirstlane(lds_ld(LW(slot_gen) + pos)) < gen) {   // ring full: publish what is in flight, then wait
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0 && lds_ld(LW(landed)) < ABORT) *LW(landed) = i;
-      const long long t0 = __builtin_amdgcn_s_memrealtime();
-      unsigned spins = 0;
-      while (__builtin_amdgcn_readfirstlane(lds_ld(LW(slot_gen) + pos)) < gen) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 255u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > 10000000ll || lds_ld(LW(dead)))) { give_up(a, 0x40u, lane); break; }
+    if (__builtin_amdgcn_readlane(sg, pos) < gen) {
+      snap();
+      if (__builtin_amdgcn_readlane(sg, pos) < gen) {   // ring full: publish what is in flight, then wait
+        const long long tf0 = prof ? __builtin_amdgcn_s_memrealtime() : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && alive) *LW(landed) = i;
+        const long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while (__builtin_amdgcn_readlane(sg, pos) < gen) {
+          __builtin_amdgcn_s_sleep(1);
+          snap();
+          if (!alive) break;
+          if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 10000000ll) {
+            // (no returning atomic on this path: hipcc would guard its result register with s_waitcnt vmcnt(0) in EVERY fill)
+            if (lane == 0) {
+              *LW(dead) = 1u;
+              *LW(landed) = ABORT; *LW(sync) = ABORT; *LW(pcnt) = ABORT;
+              __hip_atomic_store(a.err + 2, 0x40u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            alive = false;
+            break;
+          }
+        }
+        if (prof) t_full += __builtin_amdgcn_s_memrealtime() - tf0;
       }
     }
     if (!(a.flags & 2)) {
-      // (the builtin's immediate offset would move the GLOBAL address as well: four LDS bases instead)
-      auto* d = lbase + pos * SLOT;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + lane * 16), (__attribute__((address_space(3))) void*)d, 16, 0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + lane * 16), (__attribute__((address_space(3))) void*)(d + 1024), 16, 0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s2 + lane * 16), (__attribute__((address_space(3))) void*)(d + 2048), 16, 0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s3 + lane * 16), (__attribute__((address_space(3))) void*)(d + 3072), 16, 0, NT ? 2 : 0);
+      const unsigned d = lbase + pos * SLOT;
+      dma1k<NT>(s0 + lane * 16, d);
+      dma1k<NT>(s1 + lane * 16, d + 1024);
+      dma1k<NT>(s2 + lane * 16, d + 2048);
+      dma1k<NT>(s3 + lane * 16, d + 3072);
     }
     ++i;
     if (++pos == RING) { pos = 0; ++gen; }
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // 4 * DEPTH: every slot below i - DEPTH has landed
-    if (i > DEPTH && lane == 0 && lds_ld(LW(landed)) < ABORT) *LW(landed) = i - DEPTH;
+    const long long tv0 = prof ? __builtin_amdgcn_s_memrealtime() : 0;
+    // while consumers of this CU sweep granules the loader is THINNED to one fill in flight: their polls and publishes
+    // share the CU's memory queue with the DMA (MI355X guide, gather-pass row: 0.3-0.65 us per pass with the own DMA quiet,
+    // 1.0-1.7 behind an unthrottled refill burst).  The snapshot is refreshed by every fill; it is one fill old when used.
+    const bool thin = !(a.flags & 64) && __builtin_amdgcn_readlane(sg, 62) != 0u;
+    snap();
+    if (thin) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (lane == 0 && alive && i > 1u) *LW(landed) = i - 1u;
+    } else {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // 4 * DEPTH: every slot below i - DEPTH has landed
+      if (i > DEPTH && lane == 0 && alive) *LW(landed) = i - DEPTH;
+    }
+    if (prof) t_vm += __builtin_amdgcn_s_memrealtime() - tv0;
   };
   for (int p = 0; p < a.n_pass; ++p) {
     for (int l = 0; l < a.n_layers; ++l) {
@@ -285,7 +340,11 @@ __device__ __forceinline__ void loader(const DecPersistArgs& a, char* smem, int 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && lds_ld(LW(landed)) < ABORT) *LW(landed) = i;
+  if (lane == 0 && alive) *LW(landed) = i;
+  if (prof && lane == 0) {   // loader profile of CU 0 behind the stamps: ticks blocked on a full ring, in the in-flight limit, in total, fills
+    unsigned long long* d = a.dbg + (size_t)a.n_pass * (a.n_layers + 1) * 16;
+    d[0] = (unsigned long long)t_full; d[1] = (unsigned long long)t_vm; d[2] = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t_begin); d[3] = i;
+  }
 }
 
 __device__ __forceinline__ f32x4 ld_sc1(const float* base, unsigned off_floats) {
@@ -296,14 +355,191 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sweep NP granule PAIRS per lane (pair p = granules idx(p), idx(p) + 1, idx even: one 16-byte sc1 load, each 8-byte half
+// written by one store) until every tag equals `epoch`; out[2 p], out[2 p + 1] = the two values.  `mid` runs once, between
+// the issue of the first sweep and its check: loads issued there return under the wait for remote data (a first sweep
+// almost never finds everything).
+template <int NP, typename IdxF, typename MidF>
+__device__ __forceinline__ void gather_pairs(const DecPersistArgs& a, unsigned epoch, IdxF idx, MidF mid, float (&out)[2 * NP], int lane, unsigned code) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.gran, 0, 0x7ffffff0, 0x00020000);
+  u32x4 v[NP];
+  unsigned pending = (1u << NP) - 1u;
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned spins = 0;
+  if (lane == 0) __hip_atomic_fetch_add((lu32*)LW(gathering), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // thins the loader
+  // first sweep, `mid`, first check -- unconditionally, so that what `mid` defines is defined on every path
+#pragma unroll
+  for (int p = 0; p < NP; ++p) v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)idx(p) * 8u, 0, /*sc1*/ 16);
+  mid();
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const bool ok = v[p][1] == epoch && v[p][3] == epoch;
+    if (__all(ok) || (a.flags & 1)) pending &= ~(1u << p);
+  }
+  while (pending) {
+    for (int z = (a.flags >> 8) & 15; z > 0; --z) __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 63u) == 0u && (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ll || __builtin_amdgcn_readfirstlane(lds_ld(LW(dead))))) {   // 50 ms
+      give_up(a, code, lane);
+      break;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if ((pending >> p) & 1u) v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)idx(p) * 8u, 0, /*sc1*/ 16);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if ((pending >> p) & 1u) {
+        const bool ok = v[p][1] == epoch && v[p][3] == epoch;
+        if (__all(ok) || (a.flags & 1)) pending &= ~(1u << p);
+      }
+  }
+  if (lane == 0) __hip_atomic_fetch_add((lu32*)LW(gathering), 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { out[2 * p] = __uint_as_float(v[p][0]); out[2 * p + 1] = __uint_as_float(v[p][2]); }
+}
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+
+// A 1024-vector to every consumer in the layout gemv1_kernel<.., U = 2> holds it (x16[8 u + e] = x[8 lane + 512 u + e]):
+// each consumer sweeps ONE quarter of the granules (every wave sweeping all of them put four times the polling traffic
+// into the CU's memory pipe, next to the weight stream: 41 us per layer-pass instead of 23), the quarters meet in LDS.
+__device__ __forceinline__ void gather_x16(const DecPersistArgs& a, int g0, unsigned epoch, float* sx, unsigned& sync_t, int w, float (&x16)[16],
+                                           int lane, unsigned code) {
+  float q[4];
+  gather_pairs<2>(a, epoch, [&](int p) { return g0 + 256 * w + 128 * p + 2 * lane; }, NoMid(), q, lane, code);
+  *reinterpret_cast<f32x2*>(sx + 256 * w + 2 * lane) = f32x2{q[0], q[1]};
+  *reinterpret_cast<f32x2*>(sx + 256 * w + 128 + 2 * lane) = f32x2{q[2], q[3]};
+  csync(a, sync_t, lane);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(sx + lane * 8 + u * 512), xb = *reinterpret_cast<const f32x4*>(sx + lane * 8 + u * 512 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x16[8 * u + e] = xa[e]; x16[8 * u + 4 + e] = xb[e]; }
+  }
+}
+// the four values x[4 cu .. 4 cu + 3] out of that register layout, wave-uniform
+__device__ __forceinline__ void pick4(const float (&x16)[16], int cu, float (&r)[4]) {
+  const int i0 = 4 * cu, u = i0 >> 9, src = (i0 & 511) >> 3, e0 = i0 & 7;
+  // (lane reads first, then scalar selects: a select between register ELEMENTS became an indexed access through scratch)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x16[k]), src));
+    const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x16[4 + k]), src));
+    const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x16[8 + k]), src));
+    const float c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x16[12 + k]), src));
+    r[k] = u ? (e0 ? c3 : c2) : (e0 ? c1 : c0);
+  }
+}
+__device__ __forceinline__ void normed_x16(const float (&x16)[16], const f32x4 (&la)[2], const f32x4 (&lb)[2], float eps, f32x2 (&xp)[2][4]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xp[u][i] = f32x2{x16[8 * u + 2 * i], x16[8 * u + 2 * i + 1]};
+  f32x2 ss2 = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ss2 = PKFMA(xp[u][i], xp[u][i], ss2);
+  const float ssw = wave_sum(ss2[0] + ss2[1]);
+  const float sc = __builtin_amdgcn_rsqf(ssw * __builtin_amdgcn_rcpf((float)H) + eps);
+  const f32x2 sc2 = f32x2{sc, sc};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    xp[u][0] = (xp[u][0] * sc2) * f32x2{la[u][0], la[u][1]};
+    xp[u][1] = (xp[u][1] * sc2) * f32x2{la[u][2], la[u][3]};
+    xp[u][2] = (xp[u][2] * sc2) * f32x2{lb[u][0], lb[u][1]};
+    xp[u][3] = (xp[u][3] * sc2) * f32x2{lb[u][2], lb[u][3]};
+  }
+}
+// NT row pairs at K = 1024 from NT slots, interleaved (independent accumulator chains and reductions: one wave per SIMD
+// has nothing else to hide their latencies behind); per pair exactly dot_pair's arithmetic
+template <int NT_>
+__device__ __forceinline__ void dot_pairs(const char* const (&slot)[NT_], const f32x2 (&xp)[2][4], int lane, float (&s0)[NT_], float (&s1)[NT_]) {
+  f32x2 c0[NT_], c1[NT_];
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) { c0[t] = f32x2{0.f, 0.f}; c1[t] = f32x2{0.f, 0.f}; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    u32x4 w0[NT_], w1[NT_];
+#pragma unroll
+    for (int t = 0; t < NT_; ++t) {
+      w0[t] = *reinterpret_cast<const u32x4*>(slot[t] + u * 1024 + lane * 16);
+      w1[t] = *reinterpret_cast<const u32x4*>(slot[t] + 2048 + u * 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) {
+        c0[t] = PKFMA(wpair(w0[t], i), xp[u][i], c0[t]);
+        c1[t] = PKFMA(wpair(w1[t], i), xp[u][i], c1[t]);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) { s0[t] = c0[t][0] + c0[t][1]; s1[t] = c1[t][0] + c1[t][1]; }
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) wave_sum2(s0[t], s1[t]);
+}
+
+// two query heads against one 32-key register tile, interleaved; per head exactly AttnTile32::accumulate + reduce from
+// (m_run, l_run, acc) = (-inf, 0, 0), i.e. attn_oproj_kernel's arithmetic
+template <typename Tile>
+__device__ __forceinline__ void attn2(const Tile& tile, const float* qA, const float* qB, float* pA, float* pB, int cnt, int lane, float* oA, float* oB) {
+  const int t = lane & 31, half = lane >> 5;
+  f32x2 saA = f32x2{0.f, 0.f}, sbA = saA, saB = saA, sbB = saA;
+#pragma unroll
+  for (int i = 0; i < Tile::NK; ++i) {
+    const f32x4 qa = *reinterpret_cast<const f32x4*>(qA + (half * Tile::NK + i) * 4);
+    const f32x4 qb = *reinterpret_cast<const f32x4*>(qB + (half * Tile::NK + i) * 4);
+    const f32x2 k01 = f32x2{tile.k[i][0], tile.k[i][1]}, k23 = f32x2{tile.k[i][2], tile.k[i][3]};
+    if (i & 1) {
+      sbA = PKFMA((f32x2{qa[0], qa[1]}), k01, sbA); sbA = PKFMA((f32x2{qa[2], qa[3]}), k23, sbA);
+      sbB = PKFMA((f32x2{qb[0], qb[1]}), k01, sbB); sbB = PKFMA((f32x2{qb[2], qb[3]}), k23, sbB);
+    } else {
+      saA = PKFMA((f32x2{qa[0], qa[1]}), k01, saA); saA = PKFMA((f32x2{qa[2], qa[3]}), k23, saA);
+      saB = PKFMA((f32x2{qb[0], qb[1]}), k01, saB); saB = PKFMA((f32x2{qb[2], qb[3]}), k23, saB);
+    }
+  }
+  float sA = (saA[0] + saA[1]) + (sbA[0] + sbA[1]), sB = (saB[0] + saB[1]) + (sbB[0] + sbB[1]);
+  sA = xor32_sum(sA); sB = xor32_sum(sB);
+  const bool valid = t < cnt;
+  if (!valid) { sA = -INFINITY; sB = -INFINITY; }
+  float m_runA = -INFINITY, l_runA = 0.f, m_runB = -INFINITY, l_runB = 0.f;
+  const float m_newA = fmaxf(m_runA, wave_max(sA)), m_newB = fmaxf(m_runB, wave_max(sB));
+  const float pa = valid ? __expf(sA - m_newA) : 0.f, pb = valid ? __expf(sB - m_newB) : 0.f;
+  const float alphaA = __expf(m_runA - m_newA), alphaB = __expf(m_runB - m_newB);
+  l_runA = l_runA * alphaA + wave_sum(half == 0 ? pa : 0.f);
+  l_runB = l_runB * alphaB + wave_sum(half == 0 ? pb : 0.f);
+  __builtin_amdgcn_wave_barrier();
+  if (half == 0) { pA[t] = pa; pB[t] = pb; }
+  __builtin_amdgcn_wave_barrier();
+  const int tpar = lane / Tile::LPR;
+  f32x4 accA = (f32x4)(0.f), accB = (f32x4)(0.f);
+  accA *= alphaA; accB *= alphaB;
+  f32x2 a01 = f32x2{accA[0], accA[1]}, a23 = f32x2{accA[2], accA[3]}, b01 = f32x2{accB[0], accB[1]}, b23 = f32x2{accB[2], accB[3]};
+#pragma unroll
+  for (int i = 0; i < Tile::NK; ++i) {
+    const float va = pA[tpar + Tile::TP * i], vb = pB[tpar + Tile::TP * i];
+    const f32x2 v01 = f32x2{tile.v[i][0], tile.v[i][1]}, v23 = f32x2{tile.v[i][2], tile.v[i][3]};
+    a01 = PKFMA((f32x2{va, va}), v01, a01); a23 = PKFMA((f32x2{va, va}), v23, a23);
+    b01 = PKFMA((f32x2{vb, vb}), v01, b01); b23 = PKFMA((f32x2{vb, vb}), v23, b23);
+  }
+  accA[0] = a01[0]; accA[1] = a01[1]; accA[2] = a23[0]; accA[3] = a23[1];
+  accB[0] = b01[0]; accB[1] = b01[1]; accB[2] = b23[0]; accB[3] = b23[1];
+  __builtin_amdgcn_wave_barrier();
+  accA = Tile::reduce(accA);
+  accB = Tile::reduce(accB);
+  if (lane < Tile::LPR) {
+    *reinterpret_cast<f32x4*>(oA + 4 * lane) = accA * (1.f / l_runA);
+    *reinterpret_cast<f32x4*>(oB + 4 * lane) = accB * (1.f / l_runB);
+  }
+}
+
 __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, int cu, int w, int lane_in) {
-  int lane = lane_in;
   using Tile = AttnTile32<float, HD>;
-  float* sx = reinterpret_cast<float*>(smem + LDS_X);
-  float* sq = reinterpret_cast<float*>(smem + LDS_U + U_Q);
-  float* satt = reinterpret_cast<float*>(smem + LDS_U + U_ATT);
-  float* pbuf = reinterpret_cast<float*>(smem + LDS_U + U_P) + w * 32;
-  float* sact = reinterpret_cast<float*>(smem + LDS_U);
+  int lane = lane_in;
+  float* sqw = reinterpret_cast<float*>(smem + LDS_SQW) + w * 512;   // wave-private: q of heads 2 w, 2 w + 1 | k | v of the new position
+  float* satt = reinterpret_cast<float*>(smem + LDS_ATT);
+  float* pbuf = reinterpret_cast<float*>(smem + LDS_P) + w * 64;
+  float* sxa = reinterpret_cast<float*>(smem + LDS_XA);   // two landing buffers: a fast wave may already sweep the next vector
+  float* sxb = reinterpret_cast<float*>(smem + LDS_XB);   // while a slow one still reads the previous one
   u64* G = a.gran;
   unsigned sync_t = 0, pcnt_t = 0, ep = 0;
   unsigned base = 0;   // global slot index of the current layer's first slot
@@ -314,11 +550,16 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
     if (a.dbg && cu == 0 && w == 0 && lane == 0) a.dbg[((size_t)p * (a.n_layers + 1) + l) * 16 + e] = __builtin_amdgcn_s_memrealtime();
   };
   for (int p = 0; p < a.n_pass; ++p) {
-    // ---- the position's input row -------------------------------------------------------------------------------
+    // ---- the position's input row, straight into the register layout of the K = 1024 launches ---------------------
+    float x16[16];
     {
       const float* src = p == 0 ? a.x_pos0 : (p == 1 ? a.x_pos1 : a.tok_table + ((size_t)(p - 1) * a.V + token) * H);
-      *reinterpret_cast<f32x4*>(sx + w * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(src + w * 256 + lane * 4);
-      csync(a, sync_t, lane);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(src + lane * 8 + u * 512), xb = *reinterpret_cast<const f32x4*>(src + lane * 8 + u * 512 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x16[8 * u + e] = xa[e]; x16[8 * u + 4 + e] = xb[e]; }
+      }
     }
     const int pos = p, cnt = p + 1;
     for (int l = 0; l < a.n_layers; ++l) {
@@ -327,6 +568,8 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
       asm volatile("" : "+v"(lane));
       stamp(p, l, 0);
       const bool kv_only = a.kv_only_pass0 && p == 0 && l == a.n_layers - 1;
+      float res[4];
+      pick4(x16, cu, res);   // the residual values of this CU's o_proj rows
       // ---- QKV: tasks 3 cu + w on consumers 0-2 (RMSNorm prologue, RoPE + cache append epilogue) ------------------
       ++ep;
       if (w < 3) {
@@ -335,7 +578,7 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
         const int t = 3 * cu + w, head = t >> 6, hi = t & 63;
         const float cs = a.cos_tab[pos * 64 + hi], sn = a.sin_tab[pos * 64 + hi];
         f32x2 xp[2][4];
-        normed_x(sx, la, lb, a.eps, lane, xp);
+        normed_x16(x16, la, lb, a.eps, xp);
         const unsigned si = base + S_QKV + w;
         wait_landed(a, si, lane);
         float v0, v1;
@@ -370,50 +613,49 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
       }
       stamp(p, l, 1);
       if (kv_only) {   // nothing of this position is read again: the next position starts from its own input row
-        // K/V of this position reach later passes through the cache (sc1 stores above); make sure they left this wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its K / V reach later passes through the cache: they have left this wave
         base += 3;
         continue;
       }
-      // ---- earlier positions' K / V of this wave's kv-head: sc1 loads, in flight while the q / k / v granules arrive ----
+      // ---- this wave's q (two heads) + the new k / v of its kv-head, into its own LDS strip; the K / V of earlier positions
+      // (sc1 loads from the cache) are requested behind the first sweep and land while the granules are still on their way ----
       const int jkv = w >> 1;
       Tile tile;
       const int tk = lane & 31, half = lane >> 5, dg = lane & 31, tpar = lane >> 5;
-      if (pos > 0) {
-        const float* kc = a.kcache[l] + (size_t)jkv * (HD / 4) * a.lmax * 4;
-        const float* vc = a.vcache[l] + (size_t)jkv * a.lmax * HD;
-        const int tp = min(tk, pos - 1);
+      {
+        float qv[8];
+        gather_pairs<4>(a, ep,
+                        [&](int q) { return GQ + (q < 2 ? 256 * w + 128 * q : (q == 2 ? NQ * HD : (NQ + NKV) * HD) + HD * jkv) + 2 * lane; },
+                        [&]() {
+                          if (pos > 0) {
+                            const float* kc = a.kcache[l] + (size_t)jkv * (HD / 4) * a.lmax * 4;
+                            const float* vc = a.vcache[l] + (size_t)jkv * a.lmax * HD;
+                            const int tp = min(tk, pos - 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tile.k[i] = ld_sc1(kc, (unsigned)(((half * 16 + i) * a.lmax + tp) * 4));
+                            for (int i = 0; i < 16; ++i) tile.k[i] = ld_sc1(kc, (unsigned)(((half * 16 + i) * a.lmax + tp) * 4));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tile.v[i] = ld_sc1(vc, (unsigned)(min(tpar + 2 * i, pos - 1) * HD + 4 * dg));
-      } else {   // position 0: every lane takes the current key below; defined values keep the tile out of the loop-carried state
+                            for (int i = 0; i < 16; ++i) tile.v[i] = ld_sc1(vc, (unsigned)(min(tpar + 2 * i, pos - 1) * HD + 4 * dg));
+                          } else {   // position 0: every lane takes the current key below; defined values keep the tile out of the loop-carried state
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { tile.k[i] = (f32x4)(0.f); tile.v[i] = (f32x4)(0.f); }
+                            for (int i = 0; i < 16; ++i) { tile.k[i] = (f32x4)(0.f); tile.v[i] = (f32x4)(0.f); }
+                          }
+                        },
+                        qv, lane, 0x100u | (unsigned)(p << 16) | (unsigned)(l << 12));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x2*>(sqw + 128 * q + 2 * lane) = f32x2{qv[2 * q], qv[2 * q + 1]};
       }
-      gather<6>(a, G + GQ + w * 384, ep, sq + w * 384, lane, 0x100u | (unsigned)(p << 16) | (unsigned)(l << 12));
-      stamp(p, l, 10);
-      csync(a, sync_t, lane);
       stamp(p, l, 2);
       // ---- attention: heads 2 w, 2 w + 1 (attn_oproj_kernel's tile arithmetic) -----------------------------------
       {
-        const float* kn = sq + NQ * HD + jkv * HD;
-        const float* vn = sq + (NQ + NKV) * HD + jkv * HD;
+        const float* kn = sqw + 256;
+        const float* vn = sqw + 384;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (tk >= pos) tile.k[i] = *reinterpret_cast<const f32x4*>(kn + (half * 16 + i) * 4);
           if (tpar + 2 * i >= pos) tile.v[i] = *reinterpret_cast<const f32x4*>(vn + 4 * dg);
         }
         stamp(p, l, 11);
-#pragma unroll 1
-        for (int hh = 0; hh < ((a.flags & 16) ? 0 : 2); ++hh) {
-          const int h = 2 * w + hh;
-          float m_run = -INFINITY, l_run = 0.f;
-          f32x4 acc = (f32x4)(0.f);
-          tile.accumulate(sq + h * HD, pbuf, cnt, lane, m_run, l_run, acc);
-          acc = Tile::reduce(acc);
-          if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(satt + h * HD + 4 * lane) = acc * (1.f / l_run);
-        }
+        if (!(a.flags & 16)) attn2(tile, sqw, sqw + HD, pbuf, pbuf + 32, cnt, lane, satt + (2 * w) * HD, satt + (2 * w + 1) * HD);
       }
       stamp(p, l, 12);
       csync(a, sync_t, lane);
@@ -426,7 +668,7 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
         const char* slot = slot_ptr(smem, si);
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(satt + lane * 16), x1 = *reinterpret_cast<const f32x4*>(satt + lane * 16 + 4);
         const f32x4 x2 = *reinterpret_cast<const f32x4*>(satt + lane * 16 + 8), x3 = *reinterpret_cast<const f32x4*>(satt + lane * 16 + 12);
-        float res[2];
+        float o2[2];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const u32x4 w0 = *reinterpret_cast<const u32x4*>(slot + rr * 2048 + lane * 32);
@@ -449,31 +691,39 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
           s += dpp_all<0x140>(s);
           s = xor16_sum(s);
           s = xor32_sum(s);
-          res[rr] = sx[4 * cu + 2 * w + rr] + s * 1.f;
+          o2[rr] = (w ? res[2 + rr] : res[rr]) + s * 1.f;
         }
         release_slot(si, lane);
-        if (lane < 2) publish(G + GO + 4 * cu + 2 * w + lane, ep, lane ? res[1] : res[0]);
+        if (lane < 2) publish(G + GO + 4 * cu + 2 * w + lane, ep, lane ? o2[1] : o2[0]);
       }
       stamp(p, l, 4);
       f32x4 la[2], lb[2];
       load_ln(a.ln2[l], lane, la, lb);
-      gather<4>(a, G + GO + w * 256, ep, sx + w * 256, lane, 0x200u | (unsigned)(p << 16) | (unsigned)(l << 12));
-      csync(a, sync_t, lane);
+      gather_x16(a, GO, ep, sxa, sync_t, w, x16, lane, 0x200u | (unsigned)(p << 16) | (unsigned)(l << 12));
+      pick4(x16, cu, res);   // the residual values of this CU's down_proj rows
       stamp(p, l, 5);
-      // ---- gate / up + SwiGLU: tasks 32 cu + w + 4 i --------------------------------------------------------------
+      // ---- gate / up + SwiGLU: tasks 32 cu + w + 4 i, four at a time --------------------------------------------------
       ++ep;
       {
         f32x2 xp[2][4];
-        normed_x(sx, la, lb, a.eps, lane, xp);
+        normed_x16(x16, la, lb, a.eps, xp);
         float act[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const unsigned si = base + S_GU + w + 4 * i;
-          wait_landed(a, si, lane);
-          float v0, v1;
-          dot_pair(slot_ptr(smem, si), xp, lane, v0, v1);
-          release_slot(si, lane);
-          act[i] = (v0 / (1.f + __expf(-v0))) * v1;
+        for (int g = 0; g < 2; ++g) {
+          wait_landed(a, base + S_GU + w + 4 * (4 * g + 3), lane);   // slots land in order
+          stamp(p, l, 13 + g);
+          const char* sl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sl[i] = slot_ptr(smem, base + S_GU + w + 4 * (4 * g + i));
+          float v0[4], v1[4];
+          dot_pairs<4>(sl, xp, lane, v0, v1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane < 4) {
+            const unsigned si = base + S_GU + w + 4 * (4 * g + lane);
+            LW(slot_gen)[si % RING] = si / RING + 1u;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) act[4 * g + i] = (v0[i] / (1.f + __expf(-v0[i]))) * v1[i];
         }
         float mine = act[0];
 #pragma unroll
@@ -481,46 +731,42 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
         if (lane < 8) publish(G + GA + 32 * cu + w + 4 * lane, ep, mine);
       }
       stamp(p, l, 6);
-      if (!(a.flags & 8)) {
-        gather<16>(a, G + GA + w * 2048, ep, sact + w * 2048, lane, 0x300u | (unsigned)(p << 16) | (unsigned)(l << 12));
-        gather<16>(a, G + GA + w * 2048 + 1024, ep, sact + w * 2048 + 1024, lane, 0x380u | (unsigned)(p << 16) | (unsigned)(l << 12));
-      }
-      stamp(p, l, 13);
-      csync(a, sync_t, lane);
-      stamp(p, l, 7);
-      // ---- down_proj + residual: consumer kw multiplies quarter kw of rows 4 cu .. + 3 (gemv1_kernel<.., U = 4, KS = 4>) ----
-      ++ep;
+      // ---- down_proj + residual: consumer kw gathers ITS quarter of the SwiGLU vector into registers (no LDS, no barrier)
+      // and multiplies quarter kw of rows 4 cu .. + 3 (gemv1_kernel<.., U = 4, KS = 4>) ----------------------------------
       {
-        f32x2 xq[4][4];
+        float aq[32];
+        if (!(a.flags & 8))
+          gather_pairs<16>(a, ep, [&](int q) { return GA + w * 2048 + 512 * (q >> 2) + 8 * lane + 2 * (q & 3); }, NoMid(), aq, lane,
+                           0x300u | (unsigned)(p << 16) | (unsigned)(l << 12));
+        else
+#pragma unroll
+          for (int i = 0; i < 32; ++i) aq[i] = 0.f;
+        stamp(p, l, 7);
+        ++ep;
+        wait_landed(a, base + S_DN + 12 + w, lane);
+        f32x2 c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = f32x2{0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const f32x4 xa = *reinterpret_cast<const f32x4*>(sact + w * 2048 + u * 512 + lane * 8);
-          const f32x4 xb = *reinterpret_cast<const f32x4*>(sact + w * 2048 + u * 512 + lane * 8 + 4);
-          xq[u][0] = f32x2{xa[0], xa[1]}; xq[u][1] = f32x2{xa[2], xa[3]};
-          xq[u][2] = f32x2{xb[0], xb[1]}; xq[u][3] = f32x2{xb[2], xb[3]};
+          u32x4 wr[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wr[r] = *reinterpret_cast<const u32x4*>(slot_ptr(smem, base + S_DN + 4 * r + w) + u * 1024 + lane * 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = PKFMA(wpair(wr[r], i), (f32x2{aq[8 * u + 2 * i], aq[8 * u + 2 * i + 1]}), c[r]);
         }
+        float s[4];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const unsigned s0i = base + S_DN + (2 * tt) * 4 + w, s1i = base + S_DN + (2 * tt + 1) * 4 + w;
-          wait_landed(a, s1i, lane);
-          const char* q0 = slot_ptr(smem, s0i);
-          const char* q1 = slot_ptr(smem, s1i);
-          f32x2 c0 = f32x2{0.f, 0.f}, c1 = f32x2{0.f, 0.f};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const u32x4 w0 = *reinterpret_cast<const u32x4*>(q0 + u * 1024 + lane * 16);
-            const u32x4 w1 = *reinterpret_cast<const u32x4*>(q1 + u * 1024 + lane * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              c0 = PKFMA(wpair(w0, i), xq[u][i], c0);
-              c1 = PKFMA(wpair(w1, i), xq[u][i], c1);
-            }
-          }
-          float s0 = c0[0] + c0[1], s1 = c1[0] + c1[1];
-          wave_sum2(s0, s1);
-          release_slot(s0i, lane);
-          release_slot(s1i, lane);
-          if (lane == 0) { LF(part)[(2 * tt) * 4 + w] = s0; LF(part)[(2 * tt + 1) * 4 + w] = s1; }
+        for (int r = 0; r < 4; ++r) s[r] = c[r][0] + c[r][1];
+        wave_sum2(s[0], s[1]);
+        wave_sum2(s[2], s[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 4) {
+          const unsigned si = base + S_DN + 4 * lane + w;
+          LW(slot_gen)[si % RING] = si / RING + 1u;
+          LF(part)[lane * 4 + w] = lane == 0 ? s[0] : (lane == 1 ? s[1] : (lane == 2 ? s[2] : s[3]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((lu32*)LW(pcnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -532,17 +778,23 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
             v += LF(part)[lane * 4 + 1];
             v += LF(part)[lane * 4 + 2];
             v += LF(part)[lane * 4 + 3];
-            publish(G + GX + 4 * cu + lane, ep, sx[4 * cu + lane] + v * 1.f);
+            const float r = lane == 0 ? res[0] : (lane == 1 ? res[1] : (lane == 2 ? res[2] : res[3]));
+            publish(G + GX + 4 * cu + lane, ep, r + v * 1.f);
           }
         }
       }
       stamp(p, l, 8);
-      gather<4>(a, G + GX + w * 256, ep, sx + w * 256, lane, 0x400u | (unsigned)(p << 16) | (unsigned)(l << 12));
-      csync(a, sync_t, lane);
+      gather_x16(a, GX, ep, sxb, sync_t, w, x16, lane, 0x400u | (unsigned)(p << 16) | (unsigned)(l << 12));
       stamp(p, l, 9);
       base += SLOTS_LAYER;
     }
-    if (a.dbg_x && cu == 0) *reinterpret_cast<f32x4*>(a.dbg_x + (size_t)p * H + w * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(sx + w * 256 + lane * 4);
+    if (a.dbg_x && cu == 0 && w == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        *reinterpret_cast<f32x4*>(a.dbg_x + (size_t)p * H + lane * 8 + u * 512) = f32x4{x16[8 * u], x16[8 * u + 1], x16[8 * u + 2], x16[8 * u + 3]};
+        *reinterpret_cast<f32x4*>(a.dbg_x + (size_t)p * H + lane * 8 + u * 512 + 4) = f32x4{x16[8 * u + 4], x16[8 * u + 5], x16[8 * u + 6], x16[8 * u + 7]};
+      }
+    }
     if (p == 0) continue;
     // ---- head of codebook p: final norm, rows 2 t, 2 t + 1 of audio_head[p - 1], fused arg-max (EPI_ARGMAX / PRO_TOKNORM) ----
     asm volatile("" : "+v"(lane));
@@ -552,7 +804,7 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
       f32x4 la[2], lb[2];
       load_ln(a.final_norm, lane, la, lb);
       f32x2 xp[2][4];
-      normed_x(sx, la, lb, a.eps, lane, xp);
+      normed_x16(x16, la, lb, a.eps, xp);
       float bv = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll 1
@@ -588,21 +840,15 @@ __device__ __forceinline__ void consumer(const DecPersistArgs& a, char* smem, in
     }
     stamp(p, a.n_layers, 1);
     {
-      // every consumer reduces all 256 pairs itself: no LDS exchange, the token is wave-uniform in all four
-      u64 gv[8];
-      gather_regs<8>(a, G + GH, ep, gv, lane, 0x500u | (unsigned)(p << 16));
+      // every consumer reduces all 256 (value, index) pairs itself: no LDS exchange, the token is wave-uniform in all four
       float pv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pv[k] = __uint_as_float((unsigned)gv[k]);
-      // lane holds granule 64 k + lane: granules 2 c, 2 c + 1 = (value, index) of CU c sit in neighbouring lanes
+      gather_pairs<4>(a, ep, [&](int q) { return GH + 128 * q + 2 * lane; }, NoMid(), pv, lane, 0x500u | (unsigned)(p << 16));
       float bv = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        // neighbouring lanes hold (value, index) of one pair: even lane = value, odd lane = index
-        const float other = dpp_all<0xB1>(pv[k]);   // quad_perm [1,0,3,2]: swap with the neighbour
-        const float val = (lane & 1) ? other : pv[k];
-        const int idx = __float_as_int((lane & 1) ? pv[k] : other);
+      for (int k = 0; k < 4; ++k) {
+        const float val = pv[2 * k];
+        const int idx = __float_as_int(pv[2 * k + 1]);
         if (val > bv || (val == bv && idx < bi)) { bv = val; bi = idx; }
       }
       wave_argmax(bv, bi);

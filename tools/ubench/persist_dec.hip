@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&a.gran, (size_t)GTOT * 8));
   CK(hipMalloc(&a.err, 64)); CK(hipMemset(a.err, 0, 64));
   a.eps = 1e-5f; a.qscale = 1.0f / sqrtf(128.f); a.n_pass = n_pass; a.n_layers = n_layers; a.kv_only_pass0 = 1; a.flags = 0;
-  unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)32 * 5 * 16 * 8)); CK(hipMemset(dbg, 0, (size_t)32 * 5 * 16 * 8));
+  unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)(32 * 5 * 16 + 16) * 8)); CK(hipMemset(dbg, 0, (size_t)(32 * 5 * 16 + 16) * 8));
   float* dbg_x; CK(hipMalloc(&dbg_x, (size_t)32 * H * 4)); CK(hipMemset(dbg_x, 0, (size_t)32 * H * 4));
   if (int e = dpk::configure()) { printf("configure failed: %d\n", e); return 1; }
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -259,17 +259,16 @@ int main(int argc, char** argv) {
   // ---- timing + per-edge breakdown (CU 0, consumer 0; s_memrealtime = 10 ns ticks) -----------------------------------
   const int lp = n_pass * n_layers - (a.kv_only_pass0 ? 1 : 0);
   struct V { const char* name; int flags, nt; } vars[] = {
-      {"default", 0, 0}, {"nt weight stream", 0, 1}, {"no tag waits", 1, 0}, {"no DMA", 2, 0}, {"no tag waits, no DMA", 3, 0},
-      {"no tag waits, no DMA, no consumer barriers", 7, 0}, {"... and no act gather", 15, 0}, {"... and no attention arithmetic", 31, 0},
-      {"default, no act gather", 8, 0}};
-  const char* names[] = {"QKV (norm, dot, RoPE, publish)", "gather q/k/v + sync", "attention + sync", "o_proj + publish", "gather x' + sync",
-                         "gate/up + publish", "gather act (64 KB) + sync", "down + combine + publish", "gather x + sync"};
+      {"default", 0, 0}, {"loader not thinned during gathers", 64, 0}, {"poll sleep 1", 1 << 8, 0}, {"poll sleep 3", 3 << 8, 0}, {"nt weight stream", 0, 1}, {"no tag waits", 1, 0}, {"no DMA", 2, 0}, {"no tag waits, no DMA", 3, 0},
+      {"no tag waits, no DMA, no consumer barriers", 7, 0}, {"... and no act gather", 15, 0}, {"... and no attention arithmetic", 31, 0}};
+  const char* names[] = {"QKV (norm, dot, RoPE, publish)", "gather q/k/v", "attention + barrier", "o_proj + publish", "gather x'",
+                         "gate/up + publish", "gather act quarter", "down + combine + publish", "gather x"};
   for (const V& v : vars) {
     const double us = run(v.flags, v.nt, reps, false);
     CK(hipMemcpy(err, a.err, 8, hipMemcpyDeviceToHost));
     printf("%-44s %8.1f us per launch = %6.2f us per layer-pass (%d layer-passes + %d heads)  give-ups %u\n", v.name, us, us / lp, lp, n_pass - 1, err[0]);
     run(v.flags, v.nt, 2, true);
-    std::vector<unsigned long long> ts((size_t)32 * 5 * 16);
+    std::vector<unsigned long long> ts((size_t)32 * 5 * 16 + 16);
     CK(hipMemcpy(ts.data(), dbg, ts.size() * 8, hipMemcpyDeviceToHost));
     double sum[9] = {0}, sub[4] = {0}, tot = 0;
     int cnt = 0;
@@ -277,16 +276,17 @@ int main(int argc, char** argv) {
       for (int l = 0; l < n_layers; ++l) {
         const unsigned long long* t = &ts[((size_t)p * (n_layers + 1) + l) * 16];
         for (int e = 0; e < 9; ++e) sum[e] += (double)(t[e + 1] - t[e]) * 0.01;
-        sub[0] += (double)(t[10] - t[1]) * 0.01;    // q/k/v sweep alone
         sub[1] += (double)(t[11] - t[2]) * 0.01;    // tile wait + patch
         sub[2] += (double)(t[12] - t[11]) * 0.01;   // two heads
-        sub[3] += (double)(t[13] - t[6]) * 0.01;    // act sweep alone
+        sub[3] += (double)(t[3] - t[12]) * 0.01;    // consumer barrier
+        sub[0] += (double)((t[13] - t[5]) + (t[14] - t[13] > 0 ? 0 : 0)) * 0.01;   // gate/up: until the first group of slots has landed
         ++cnt;
       }
     if (cnt) {
       printf("    ");
       for (int e = 0; e < 9; ++e) { printf("%s %.2f | ", names[e], sum[e] / cnt); tot += sum[e] / cnt; }
-      printf("total %.2f\n    sub: q/k/v sweep %.2f, K/V tile wait + patch %.2f, two heads %.2f, act sweep %.2f;", tot, sub[0] / cnt, sub[1] / cnt, sub[2] / cnt, sub[3] / cnt);
+      const unsigned long long* lp_ = &ts[(size_t)n_pass * (n_layers + 1) * 16];
+      printf("total %.2f\n    sub: K/V tile wait + patch %.2f, two heads %.2f, barrier %.2f, gate/up until slots 0-15 landed %.2f; loader of CU 0: %.0f us blocked on a full ring, %.0f us in the 32-in-flight limit, %.0f us in all, %llu fills;", tot, sub[1] / cnt, sub[2] / cnt, sub[3] / cnt, sub[0] / cnt, lp_[0] * 0.01, lp_[1] * 0.01, lp_[2] * 0.01, lp_[3]);
       double hs[3] = {0};
       int hc = 0;
       for (int p = 2; p < n_pass; ++p) {
