@@ -162,12 +162,19 @@ class _CSMTrainLoss(torch.autograd.Function):
         out, grads = model.loss_and_grads(input_ids, attention_mask, labels)
         ctx.grads = [grads[n] for n in names]
         ctx.dtypes = [p.dtype for p in params]
-        ctx.mark_non_differentiable(out.backbone_loss, out.decoder_loss)
-        return out.loss.clone(), out.backbone_loss.clone(), out.decoder_loss.clone()
+        loss, bl, dl = out.loss.clone(), out.backbone_loss.clone(), out.decoder_loss.clone()
+        ctx.mark_non_differentiable(bl, dl)      # the tensors that are RETURNED (marking the originals had no effect)
+        return loss, bl, dl
 
     @staticmethod
     def backward(ctx, g_loss, g_bl, g_dl):
-        gs = [(g * g_loss).to(dt) for g, dt in zip(ctx.grads, ctx.dtypes)]
+        grads, ctx.grads = ctx.grads, None      # one fp32 copy of every gradient (6 GB on csm-1b): released with this call
+        if grads is None:
+            raise RuntimeError("backward through CSMModel.forward(labels=...) a second time: the gradients were handed out once")
+        gs = []
+        for i, dt in enumerate(ctx.dtypes):
+            gs.append((grads[i] * g_loss).to(dt))
+            grads[i] = None
         return (None, None, None, None, None, *gs)
 
 
@@ -198,6 +205,8 @@ class CSMModel(nn.Module):
         self.requires_grad_(False)
         self._using_kv_cache = False
         self._engine: Optional[Engine] = None
+        self._engine_sig = None
+        self._plist = None
         self._epoch = 0
         self._frame_pending = False
         self._caps = dict(max_batch=1, max_len=0, max_frames=0, max_prefill_rows=0)
@@ -258,7 +267,15 @@ class CSMModel(nn.Module):
                   os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
 
     # ---- engine management ---------------------------------------------------------------------------------
+    def _param_signature(self):
+        """(storage address, version counter) of every parameter: changes when a parameter is replaced or written in place."""
+        ps = getattr(self, "_plist", None)
+        if ps is None or len(ps) != sum(1 for _ in self.parameters()):
+            ps = self._plist = list(self.parameters())
+        return tuple((q.data_ptr(), q._version) for q in ps)
+
     def _drop_engine(self):
+        self._plist = None
         if getattr(self, "_engine", None) is not None:
             self._engine.close()
             self._engine = None
@@ -291,6 +308,16 @@ class CSMModel(nn.Module):
         p = next(self.parameters())
         if p.device.type != "cuda":
             raise RuntimeError("CSMModel must be on an AMD GPU (model.to('cuda')): csm_hf_amd has no CPU path")
+        # The engine multiplies PACKED copies of the parameters (q/k/v concatenated, gate/up interleaved, heads transposed,
+        # transposed copies for the backward pass) next to aliases of the unpacked ones.  An in-place update of a parameter
+        # (`optimizer.step()`, `p.data.copy_()`, `p.add_()`) bumps its version counter: the copies are then stale and the
+        # engine is rebuilt from the live parameters before anything is computed (the next forward / backward
+        # silently mixed updated o_proj / down_proj / embeddings with stale qkv / gate-up / heads).
+        sig = self._param_signature()
+        if self._engine is not None and sig != self._engine_sig:
+            if cont:
+                raise ValueError("parameters were modified in place while a KV cache is live: call reset_caches() first")
+            self._drop_engine()
         c = self._caps
         if self._engine is not None and self._engine.fp8 != (self.weight_format == "fp8"):
             if cont:
@@ -319,6 +346,7 @@ class CSMModel(nn.Module):
                 eng.adopt_state(old)
                 old.close()
             self._engine = eng
+            self._engine_sig = sig
         if self.prefill_precision not in ("exact", "bf16", "mxfp8"):
             raise ValueError(f"prefill_precision must be 'exact', 'bf16' or 'mxfp8', got {self.prefill_precision!r}")
         want = 1 if self.prefill_precision in ("bf16", "mxfp8") else 0     # mxfp8: attention and the rest as in bf16 mode

@@ -11,9 +11,12 @@ import sys
 
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
+    # DECODE kernels only.  bench.py also runs prefills in its untimed region: `attn_prefill_*` matched the old '%attn_%'
+    # pattern and put 0.74 GB per step of prefill attention into the round-3 record.
     q = ("select name, count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%gemv%' or "
-         "name like '%attn_%' or name like 'sample_kernel%' or name like '%embed_sum%') and name not like '%at::native%' "
-         "group by name order by 3 desc")
+         "name like '%attn_decode%' or name like '%attn_combine%' or name like '%attn_oproj%' or name like '%gemm16_kernel%' or "
+         "name like '%gemm32_kernel%' or name like '%dec_persist%' or name like 'sample_kernel%' or name like '%embed_sum%') "
+         "and name not like '%at::native%' and name not like '%prefill%' group by name order by 3 desc")
     return list(db.cursor().execute(q, (counter,)))
 
 
@@ -21,7 +24,7 @@ frames = float(sys.argv[2])
 rows = per_kernel(sys.argv[1], "FETCH_SIZE")
 raw_kib = sum(r[2] for r in rows)
 out = {
-    "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, attn_*, sample, embed_sum)",
+    "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, gemm16 / gemm32, attn_decode / combine / oproj, dec_persist, sample, embed_sum; no prefill kernel)",
     "frames_profiled": frames,
     "fetch_kib_raw_per_step": raw_kib / frames,
     "gfx950_wide_read_correction": 2.0,

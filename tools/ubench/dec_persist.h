@@ -1,4 +1,7 @@
-// Persistent decoder engine (round 4): the reference's 31-step inner decoder loop of one frame
+// EXPERIMENT (round 4, VERDICT r3 "next round" item 1, stage (a)-(c)) -- measured, lost, NOT part of libcsm_hip.so: see
+// profiles/r04_persistent_decoder.md.  Kept with its bench (persist_dec.hip) so that the numbers can be reproduced.
+//
+// Persistent decoder engine: the reference's 31-step inner decoder loop of one frame
 // (modeling_csm.py:555-576, and its first two-position forward :534-552 run as positions 0 and 1) as ONE launch at
 // B = 1, greedy -- instead of ~500 dependent launches (QKV -> attention + o_proj -> gate/up -> down per layer-pass,
 // head per pass), each of which pays a kernel boundary plus a cold activation round trip for 2-33 MB of weights.
@@ -887,6 +890,3 @@ static inline int launch(hipStream_t st, const DecPersistArgs& a, int nt) {
 }  // namespace dpk
 #endif  // CSM_DEC_PERSIST_KERNEL
 
-// 0 on success; -2 = shape / device not covered (caller keeps the launch chain)
-int launch_dec_persist(hipStream_t st, const DecPersistArgs& a, int nt);
-int configure_dec_persist();

@@ -1,4 +1,4 @@
-// Stage (a)-(c) bench + checker of the persistent decoder engine (csm-hf_amd/csrc/dec_persist.h) on synthetic csm-1b
+// Stage (a)-(c) bench + checker of the persistent decoder engine (dec_persist.h, this directory) on synthetic csm-1b
 // decoder weights: ONE launch runs n_pass positions x n_layers layers (+ the fused arg-max head of every position >= 1)
 // at B = 1.  The launch chain it replaces costs ~19 us per decoder layer-pass in the replaying frame graph
 // (profiles/r03_b1_step_timeline.md, streamer on); VERDICT r3's gate: go if a layer-pass costs <= 16 us here.
@@ -6,7 +6,7 @@
 //   ./persist_dec [n_pass=32] [n_layers=4] [reps=20] [check_passes=32]
 // prints: give-ups, the CPU (double) check of the residual stream after every pass + the greedy tokens, us per launch and
 // per layer-pass for {default, nt weights, no tag waits, no DMA, neither}, and the per-edge stamp breakdown of CU 0.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../csm-hf_amd/csrc persist_dec.hip -o persist_dec
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../csm-hf_amd/csrc persist_dec.hip -o persist_dec -lpthread
 #include <hip/hip_runtime.h>
 
 #include <cmath>
