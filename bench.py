@@ -180,6 +180,41 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
     return out
 
 
+def traffic_record(batch: int, ctx: int, weights: str):
+    """the committed PMC record (profiles/hbm_traffic.json) of this workload, or None"""
+    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        recs = json.load(open(pmc)).get("records", [])
+    except Exception:
+        return None
+    for r in recs:
+        if r.get("batch") == batch and r.get("ctx") == ctx and r.get("weights", "bf16") == weights:
+            return r
+    return None
+
+
+def pin_to_gpu_numa_node(local: int):
+    """Keep this rank's host thread (one hipGraph replay loop per GPU, eight on a node) on the NUMA node of its GPU.
+    Returns a short description for the record; never fails the run."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return f"gpu {bdf}: no NUMA node reported, affinity unchanged"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"gpu {bdf}: node {node} has no allowed CPU, affinity unchanged"
+        os.sched_setaffinity(0, cpus)
+        return f"gpu {bdf}: NUMA node {node}, {len(cpus)} CPUs"
+    except Exception as ex:      # no sysfs entry / not permitted: run unpinned
+        return f"unpinned ({type(ex).__name__})"
+
+
 def _cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -288,7 +323,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
             dist_backend = "nccl"
     dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
+    torch.cuda.set_device(dev)      # before the first allocation of this process: everything below lives on `dev`
+    affinity = pin_to_gpu_numa_node(local)
 
     cfg = CSMConfig()
     B, K, W = a.batch, a.steps, a.warmup
@@ -349,10 +385,14 @@ def main():
     hip_ms = eng.last_generate_ms()
     print(f"[bench] rank {rank}: prefill {prefill_ms:.1f} ms, {K} steps wall {wall:.3f}s hip {hip_ms:.1f} ms", file=sys.stderr, flush=True)
 
-    tm = torch.tensor([wall, hip_ms / 1e3], dtype=torch.float64, device=dev)
+    # host-side replay overhead of THIS rank: wall time of the K replays minus the HIP-event time of the same replays
+    host_over = (wall - hip_ms / 1e3) / K * 1e3
+    tm = torch.tensor([wall, hip_ms / 1e3, host_over], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    wall_max, hip_max = float(tm[0]), float(tm[1])
+    wall_max, hip_max, host_over_max = float(tm[0]), float(tm[1]), float(tm[2])
+    from csm_hf_amd.engine import live_engines
+    assert live_engines() == 1, f"rank {rank}: {live_engines()} engines alive in the timed process (one engine per process and GPU)"
 
     pf_stats = eng.prefetch_stats()
     toks = eng.read_frames(0, W + K)
@@ -397,6 +437,11 @@ def main():
             "prefill_ms_mxfp8": None if prefill_ms_mx is None else round(prefill_ms_mx, 2),
             "prefill_ms_mxfp8_min": None if prefill_min_mx is None else round(prefill_min_mx, 2),
             "hip_event_ms_per_step": round(step_s * 1e3, 4),
+            "host_overhead_ms_per_step_max_over_ranks": round(host_over_max, 4),   # wall - HIP events: graph-replay jitter of the slowest host thread
+            "host_affinity_rank0": affinity,
+            "multi_gpu_note": ("one process per GPU, rows sharded, no data-path collective (DESIGN section 6); "
+                               + ("this line is a 1-GPU measurement -- no N > 1 number has been measured on hardware by the builder"
+                                  if world == 1 else f"{world} ranks over {dist_backend}")),
             "setup_s": round(t_setup, 1),
             "roofline": {"bound": "hbm", "kernel": "frame-step hipGraph (decoder loop + backbone step)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -415,20 +460,20 @@ def main():
                     "name": "gemv1_kernel<bf16, NORM, SWIGLU> (decoder gate/up, 128 launches/step)",
                     "algorithmic_bytes_per_launch": wb, "us_per_launch_chain": round(us, 3),
                     "achieved": round(wb / us / 1e3, 1), "unit": "GB/s", "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4),
-                    "share_of_step_time": round(128 * us / (step_s * 1e6), 3)}
+                    "share_of_step_time": round(128 * us / (step_s * 1e6), 3),
+                    "how": "side chain of 200 dependent launches of this kernel (csm_bench_gemv), NOT read from the step; the "
+                           "in-step rocprofv3 trace (profiles/r03_b1_step_timeline.md: 7.21 us start-to-start) agrees"}
             except Exception as ex:      # never let the side measurement break the bench line
                 out["roofline"]["dominant_kernel"] = {"error": str(ex)[:200]}
-        # `traffic` stays null: PMC counters cannot be read inside this process.  The separately collected rocprofv3
-        # --pmc measurement of this same command (tools/collect_pmc.sh) is quoted as `traffic_static`, labelled as such.
-        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("ctx") == a.ctx and a.weights == "bf16":
-                    out["roofline"]["traffic_static"] = {"hbm_bytes_per_step": rec["hbm_bytes_per_step"],
-                                                         "source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc run of this command)"}
-            except Exception:
-                pass
+        # `traffic`: HBM bytes per frame-step from the PMC counters.  Counters cannot be read inside this process, so the
+        # figure is the separately collected rocprofv3 --pmc measurement of THIS command (tools/collect_pmc.sh: FETCH_SIZE
+        # and WRITE_SIZE in their own passes, FETCH_SIZE x 2 for gfx950's wide reads, decode kernels only), committed as
+        # profiles/hbm_traffic.json; null when no record matches the workload of this run.
+        rec = traffic_record(B, a.ctx, a.weights)
+        if rec is not None:
+            out["roofline"]["traffic"] = rec["hbm_bytes_per_step"]
+            out["roofline"]["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_step"] / float(by), 3)
+            out["roofline"]["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
         # parity of the benchmarked run against the reference's golden vectors (same context at rank 0, B=1)
         gpath = os.path.join(ROOT, "tests", "golden", "csm1b_cfg2_bf16w_fp32.npz")
         if B == 1 and a.ctx == 512 and a.topk == 1 and a.weights == "bf16" and os.path.exists(gpath):
@@ -454,6 +499,10 @@ def main():
         c4 = run_config4(model, cfg, rank, world, dist, dev, a.ctx, a.config4_frames)
     if rank == 0:
         if c4 is not None:
+            rec16 = traffic_record(16, a.ctx, "bf16")      # PMC record of the per-GPU shape of the weak leg (--batch 16)
+            if rec16 is not None and c4["weak"]["rows_per_gpu"] == 16:
+                c4["weak"]["traffic"] = rec16["hbm_bytes_per_step"]
+                c4["weak"]["traffic_source"] = rec16.get("source", "profiles/hbm_traffic.json")
             out["config4"] = c4
         print(json.dumps(out), flush=True)
     if dist is not None:

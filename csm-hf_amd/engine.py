@@ -286,6 +286,14 @@ def pack_weights(cfg: CSMConfig, sd: Dict[str, torch.Tensor], device, wdtype: to
     return packed
 
 
+_LIVE = 0
+
+
+def live_engines() -> int:
+    """engines of this process that hold a native handle (bench.py asserts ONE per process: one process per GPU)"""
+    return _LIVE
+
+
 class Engine:
     """One engine = one GPU, one stream, one resident batch."""
 
@@ -326,6 +334,8 @@ class Engine:
         torch.cuda.set_device(self.device)
         torch.cuda.current_stream().synchronize()
         _ck(self.lib, self.lib.csm_engine_create(C.byref(ec), self.device.index or 0, None, C.byref(self._h)))
+        global _LIVE
+        _LIVE += 1
         self.packed = packed if packed is not None else pack_weights(cfg, state_dict, self.device, dtype, max_len, fp8=self.fp8)
         if bool(self.packed.get("fp8", False)) != self.fp8:
             raise ValueError("packed weights were built for a different weight_format")
@@ -405,9 +415,11 @@ class Engine:
         self.has_mx = True
 
     def close(self):
+        global _LIVE
         if getattr(self, "_h", None) and self._h.value:
             self.lib.csm_engine_destroy(self._h)
             self._h = C.c_void_p()
+            _LIVE -= 1
 
     def __del__(self):
         try:

@@ -9,19 +9,27 @@ import sqlite3
 import sys
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, frames):
     db = sqlite3.connect(path)
     # DECODE kernels only.  bench.py also runs prefills in its untimed region: `attn_prefill_*` matched the old '%attn_%'
     # pattern and put 0.74 GB per step of prefill attention into the round-3 record.
-    q = ("select name, count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%gemv%' or "
+    q = ("select name, counter_value from pmc_events where counter_name=? and (name like '%gemv%' or "
          "name like '%attn_decode%' or name like '%attn_combine%' or name like '%attn_oproj%' or name like '%gemm16_kernel%' or "
          "name like '%gemm32_kernel%' or name like '%dec_persist%' or name like 'sample_kernel%' or name like '%embed_sum%') "
-         "and name not like '%at::native%' and name not like '%prefill%' group by name order by 3 desc")
-    return list(db.cursor().execute(q, (counter,)))
+         "and name not like '%at::native%' and name not like '%prefill%'")
+    per = {}
+    for name, v in db.cursor().execute(q, (counter,)):
+        per.setdefault(name, []).append(v)
+    rows = []
+    for name, vs in per.items():
+        if "embed_sum" in name:      # the same kernel embeds the CONTEXT in every prefill (rows x 33 table rows, 35 MB - 1 GB
+            vs = sorted(vs)[:int(frames)]   # per launch): only the one-row-per-sequence launches of the frame-steps count
+        rows.append((name, len(vs), sum(vs)))
+    return sorted(rows, key=lambda r: -r[2])
 
 
 frames = float(sys.argv[2])
-rows = per_kernel(sys.argv[1], "FETCH_SIZE")
+rows = per_kernel(sys.argv[1], "FETCH_SIZE", frames)
 raw_kib = sum(r[2] for r in rows)
 out = {
     "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, gemm16 / gemm32, attn_decode / combine / oproj, dec_persist, sample, embed_sum; no prefill kernel)",
@@ -32,7 +40,7 @@ out = {
     "top_kernels": [{"kernel": r[0][:80], "launches": r[1], "avg_MB_corrected": round(2.0 * r[2] / r[1] / 1024, 3)} for r in rows[:8]],
 }
 if len(sys.argv) > 3:
-    w = per_kernel(sys.argv[3], "WRITE_SIZE")
+    w = per_kernel(sys.argv[3], "WRITE_SIZE", frames)
     out["write_kib_raw_per_step"] = sum(r[2] for r in w) / frames
 out["hbm_bytes_per_step"] = out["hbm_read_bytes_per_step"] + int(out.get("write_kib_raw_per_step", 0) * 1024)
 print(json.dumps(out, indent=1))
