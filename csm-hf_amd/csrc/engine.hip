@@ -56,6 +56,8 @@ int launch_loss_finalize(hipStream_t st, const double* acc, int frames, float* o
 int launch_dec_input(hipStream_t st, int frames, const DecInArgs& a);
 int launch_kv_shift(hipStream_t st, int kvdtype, const KvShiftArgs& a);
 int launch_add_ints(hipStream_t st, int* p, int n, int delta);
+int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a);                  // gemm_mx.hip
+int launch_gemm256_bf16(hipStream_t st, int epi, const GemmArgs& a, int min_wgs);     // gemm_mx.hip (gemm256.h)
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -2101,6 +2103,21 @@ extern "C" int csm_gemm(csm_engine_t* e, const void* W, int wdtype, const float*
   GemmArgs g{};
   g.A = A; g.lda = K; g.W = W; g.wscale = wscale; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
   LCK(launch_gemm(e->stream, wdtype, GEPI_STORE, g));
+  return 0;
+}
+
+extern "C" int csm_gemm_bf16(csm_engine_t* e, const void* W, int N, int K, const void* A, int R, float* C, int kernel) {
+  if (!e || !W || !A || !C) return fail(CSM_ERR_ARG, "null argument");
+  if (kernel < 0 || kernel > 2) return fail(CSM_ERR_ARG, "kernel must be 0 (square tile), 1 (LDS-DMA 128 x 128) or 2 (LDS-DMA 256 x 256)");
+  GemmArgs g{};
+  g.Aplanes = reinterpret_cast<const bf16_t*>(A); g.a_plane_stride = 0; g.lda = K;
+  g.W = W; g.R = R; g.N = N; g.K = K; g.C = C; g.ldc = N;
+  g.dma = kernel == 1 ? 2 : 0; g.dma_max_rows = 1 << 30; g.big256 = kernel == 2 ? 1 : 0;
+  // the LDS-DMA tiles are called directly: through launch_gemm a shape they do not cover would silently take another tile
+  const int r = kernel == 1 ? launch_gemm_dma_bf16(e->stream, GEPI_STORE, g)
+              : kernel == 2 ? launch_gemm256_bf16(e->stream, GEPI_STORE, g, 1)
+                            : launch_gemm(e->stream, CSM_DTYPE_BF16, GEPI_STORE, g);
+  if (r) return fail(CSM_ERR_ARG, "csm_gemm_bf16: tile %d does not cover R = %d, N = %d, K = %d (%d)", kernel, R, N, K, r);
   return 0;
 }
 

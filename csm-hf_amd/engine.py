@@ -32,7 +32,7 @@ EXPORTS = [
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
     "csm_mimi_stream_decode", "csm_mimi_set_option", "csm_shift_context",
     "csm_mimi_streams_open", "csm_mimi_streams_reset", "csm_mimi_streams_decode",
-    "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx", "csm_forward_backward",
+    "csm_bind_mx_weights", "csm_mx_quantize", "csm_gemm_mx", "csm_forward_backward", "csm_gemm_bf16",
 ]
 
 
@@ -150,6 +150,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_bind_mx_weights.argtypes = [vp, C.POINTER(MxLayer), i32]
     lib.csm_mx_quantize.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.csm_gemm_mx.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp]
+    lib.csm_gemm_bf16.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32]
     lib.csm_forward_backward.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.POINTER(Grads)]
     lib.csm_kv_export.argtypes = [vp, i32, vp, vp, i32]
     lib.csm_kv_import.argtypes = [vp, i32, vp, vp, i32, i32]
@@ -791,6 +792,16 @@ class Engine:
         torch.cuda.current_stream().synchronize()
         wd = {torch.bfloat16: DT_BF16, torch.uint8: DT_FP8}.get(W.dtype, DT_F32)
         _ck(self.lib, self.lib.csm_gemm(self._h, _ptr(W), wd, _ptr(sc), W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out)))
+        self.sync()
+        return out
+
+    def k_gemm_bf16(self, W, A, kernel: int):
+        """C = A @ W^T with both operands bf16 (the producer rounded A), fp32 accumulate, on a pinned tile (csm_gemm_bf16)"""
+        W = W.to(self.device, torch.bfloat16).contiguous()
+        A = A.to(self.device, torch.bfloat16).contiguous()
+        out = torch.empty(A.shape[0], W.shape[0], dtype=torch.float32, device=self.device)
+        torch.cuda.current_stream().synchronize()
+        _ck(self.lib, self.lib.csm_gemm_bf16(self._h, _ptr(W), W.shape[0], W.shape[1], _ptr(A), A.shape[0], _ptr(out), int(kernel)))
         self.sync()
         return out
 

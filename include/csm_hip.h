@@ -343,6 +343,14 @@ int csm_gemv(csm_engine_t* e, const void* W, int wdtype, const float* wscale /* 
 /* prefill GEMM C[R,N] = A[R,K] @ W[N,K]^T on the MFMA path */
 int csm_gemm(csm_engine_t* e, const void* W, int wdtype, const float* wscale, int N, int K, const float* A, int R,
              float* C);
+/* the same product as the context prefill runs it with `prefill_precision = "bf16"`: activations ALREADY rounded to bf16 by
+ * their producer (one row-major plane [R][K]), bf16 weights, fp32 accumulation on v_mfma_f32_*_bf16.  `kernel` pins the tile:
+ * 0 = square tile (gemm_bf16x3_kernel, one plane), 1 = both operands staged by LDS-DMA (gemm_dma_bf16_kernel, 128 x 128),
+ * 2 = the 256 x 256 LDS-DMA tile (gemm256_kernel).  Test hook for the per-GEMM check against the fp64 product of the rounded
+ * operands (the nn.Linear call sites of the context forward, modeling_csm.py:345-354).  CSM_ERR_ARG when the shape is not
+ * covered by the requested tile. */
+int csm_gemm_bf16(csm_engine_t* e, const void* W /* bf16 [N][K] */, int N, int K, const void* A /* bf16 [R][K] */, int R, float* C,
+                  int kernel);
 /* K12 sampler on a [rows,V] logits matrix; noise nullable; returns int32 indices */
 int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, int V, float temperature, int topk,
                     uint64_t seed, const float* noise, int32_t* out_idx);

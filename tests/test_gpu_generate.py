@@ -572,6 +572,122 @@ def test_csm1b_config5_fp8_long_context_500_frames(csm1b_bf16):
     assert torch.equal(a8.permute(1, 0, 2), toks8)          # the recorded tokens are the argmax of the traced logits
 
 
+def test_csm1b_config5_mxfp8_prefill_pinned_at_full_size(csm1b_bf16):
+    """BASELINE configs[4] as it is benchmarked (`bench.py --weights fp8`): fp8 weights, the 2048-frame context prefilled with
+    `prefill_precision = "mxfp8"` (backbone linears on v_mfma_scale_f32_16x16x128_f8f6f4, MX-fp8 weights AND activations), then
+    500 generated frames.  Round 3 tied this arithmetic to the oracle only on the tiny model.
+
+    What CAN be pinned at this size, measured first (tools/mx_pin_probe.py, profiles/r04_mx_pin_probe.txt): the 16-layer
+    random-weight network with e4m3 activations is CHAOTIC -- the oracle with the OCP-MX rounding wrapped around its backbone
+    linears (oracle/mx_sim.py) moves by 0.13-0.21 rel-L2 on last_hidden_state when 2e-7 RELATIVE noise (below one fp32 ulp)
+    is put in front of every quantiser, 0.21-0.23 with 2e-5 (the matrix instruction's accumulation class): an element that
+    crosses an e4m3 rounding step moves by 6 %, and the random network amplifies it to the size of the format's own distance
+    from fp32 (0.32).  No implementation can sit closer to that oracle than the oracle sits to itself.  So:
+    (i) per operation, at the config's own shapes (2048 rows x the four backbone linears): quantiser bytes + scales bit-exact
+        vs mx_sim, GEMM within 5e-5 of sum |a||b| of the fp64 product of the dequantised operands (both tiles) -- this is the
+        pin of the arithmetic;
+    (ii) end to end: engine (exact attention) vs oracle+MX  <=  1.25 x the oracle's own distance to itself under 2e-5 noise
+        (measured in this test) and <= 0.30 absolute (stated budget); the mode as shipped (bf16-pipe attention) <= 0.30;
+    (iii) accuracy class: distance to the bf16-activation mode and to the exact mode on the same weights in 0.15 .. 0.45;
+    (iv) the 500 frames generated from the MX context, teacher-forced through the exact-prefill engine: arg-max agreement
+        where that run's top-1 margin exceeds 1.0 >= 90 % (measured 100 %) and >= 80 % over all 16 000 samples (measured 88 %:
+        random-weight logits have small margins), and the recorded tokens are the arg-max of the traced logits (the
+        decode path itself is the exact fp8-weight path validated in the test above)."""
+    from oracle import mx_sim as MX
+    cfg = csm1b_bf16.config
+    sd = {k: v.detach() for k, v in csm1b_bf16.state_dict().items()}
+    ids, mask = synth_context(cfg, 1, 256, 1792, seed=5)
+    n = 500
+    m = csm1b_bf16
+    m.weight_format = "fp8"
+    try:
+        m.setup_caches(1, max_seq_len=2048 + n + 8, max_frames=n + 8)
+        m.prefill_precision = "mxfp8"
+        toks_mx, lt_mx, ht_mx = traced_generate(m, ids, mask, n)                      # (ii) + (iv): the mode as shipped
+        eng = m._engine
+        # (i) per operation at 2048 rows
+        g = torch.Generator().manual_seed(11)
+        lc = cfg.backbone_config
+        H, F_, A_ = lc.hidden_size, lc.intermediate_size, (lc.num_attention_heads + 2 * lc.num_key_value_heads) * (lc.hidden_size // lc.num_attention_heads)
+        for N, K in ((A_, H), (H, H), (2 * F_, H), (H, F_)):
+            X = torch.randn(2048, K, generator=g) * torch.exp2(torch.randint(-4, 5, (2048, 1), generator=g).float())
+            Wm = torch.randn(N, K, generator=g) * 0.02
+            q, s_ = eng.k_mx_quantize(X)
+            wq_, ws_ = MX.mx_quantize(X)
+            assert torch.equal(q.cpu(), wq_) and torch.equal(s_.cpu(), ws_), (N, K)
+            wq, ws = MX.mx_quantize(Wm)
+            Ad, Wd = MX.mx_dequantize(wq_, ws_).to(DEV).double(), MX.mx_dequantize(wq, ws).to(DEV).double()
+            want = Ad @ Wd.T
+            bound = (Ad.abs() @ Wd.abs().T) * 5e-5 + 1e-30
+            for big in (0, 256):                      # 128 x 128 tile, then the 256 x 256 tile where it covers the launch
+                eng.set_option("gemm_256", big)
+                got = eng.k_gemm_mx(wq, ws, wq_, ws_).double()
+                assert bool(((got - want).abs() <= bound).all()), (N, K, big, float(((got - want).abs() / bound).max()))
+            eng.set_option("gemm_256", 256)
+            del Ad, Wd, want, bound, got
+        eng.set_option("prefill_bf16_attn", 0)
+        _, lt_strict, ht_strict = traced_generate(m, ids, mask, 1)                    # (ii): exact attention
+        m._engine.set_option("prefill_bf16_attn", 1)
+        m.prefill_precision = "bf16"
+        _, _, ht_b = traced_generate(m, ids, mask, 1)
+        m.prefill_precision = "exact"
+        _, lt_x, ht_x = traced_generate(m, ids, mask, n, forced=toks_mx)              # exact context, teacher-forced
+    finally:
+        m.prefill_precision = "exact"
+        m.weight_format = "native"
+        m._drop_engine()
+    # the oracle's checkpoint: heads / projection hold the fp8 values the engine multiplies with, the backbone linears the
+    # checkpoint's own bf16 values (the MX copies are quantised from those, Engine.enable_mx)
+    sdq = _fp8_roundtrip_state_dict(cfg, sd)
+    for k, v in sd.items():
+        if k.startswith("backbone.layers.") and k.endswith("_proj.weight"):
+            sdq[k] = v.float()
+    sdc = {k: v.cpu() for k, v in sdq.items()}
+    lin = [v for k, v in sdc.items() if k.startswith("backbone.layers.") and k.endswith("_proj.weight")]
+
+    class noisy(MX.mx_linears):          # the same simulation with 2e-5 relative noise in front of every activation quantiser
+        def __enter__(self):
+            self.orig = self.O.F.linear
+            gen = torch.Generator().manual_seed(3)
+
+            def lin_(x, w, b=None):
+                if w.data_ptr() not in self.keys:
+                    return self.orig(x, w, b)
+                if w.data_ptr() not in self.cache:
+                    self.cache[w.data_ptr()] = MX.mx_round(w)
+                return self.orig(MX.mx_round(x * (1.0 + 2e-5 * torch.randn(x.shape, generator=gen))), self.cache[w.data_ptr()], b)
+            self.O.F.linear = lin_
+            return self
+
+    with torch.inference_mode():
+        with MX.mx_linears(O, lin):
+            lh, lg, _ = O.forward(sdc, cfg, ids, mask)
+        with noisy(O, lin):
+            lh_n, _, _ = O.forward(sdc, cfg, ids, mask)
+    self_dist = rel_l2(lh_n, lh)
+    d_strict, d_ship = rel_l2(ht_strict[0], lh), rel_l2(ht_mx[0], lh)
+    d_bf16, d_exact = rel_l2(ht_mx[0], ht_b[0]), rel_l2(ht_mx[0], ht_x[0])
+    am = int(lt_strict[0, 0, 0].argmax(-1))
+    rank = int((lg[0] > lg[0, am]).sum())
+    tv = torch.topk(lt_x, 2, -1)[0]
+    margin = tv[..., 0] - tv[..., 1]
+    a_mx, a_x = lt_mx.argmax(-1), lt_x.argmax(-1)
+    safe = margin > 1.0
+    agree_safe = float((a_mx[safe] == a_x[safe]).float().mean()) if bool(safe.any()) else 1.0
+    agree_all = float((a_mx == a_x).float().mean())
+    by_margin = {t: (round(float((a_mx[margin > t] == a_x[margin > t]).float().mean()), 4), int((margin > t).sum())) for t in (0.1, 0.25, 0.5)}
+    print("    arg-max agreement (fraction, samples) by exact-run margin:", by_margin)
+    print(f"config 5 mxfp8 @ 2048 frames: last_h vs oracle+MX strict {d_strict:.3e}, shipped {d_ship:.3e}; oracle+MX vs itself under 2e-5 "
+          f"noise {self_dist:.3e}; vs bf16 mode {d_bf16:.3e}, vs exact {d_exact:.3e}; the engine's c0 arg-max is rank {rank} of the oracle+MX "
+          f"logits; 500 frames arg-max agreement with the exact context: {agree_all:.4f} overall, {agree_safe:.4f} where margin > 1.0 "
+          f"({int(safe.sum())} of {safe.numel()} samples)")
+    assert d_strict <= 1.25 * self_dist and d_strict < 0.30, (d_strict, self_dist)
+    assert d_ship < 0.30, d_ship
+    assert 0.15 < d_bf16 < 0.45 and 0.15 < d_exact < 0.45, (d_bf16, d_exact)
+    assert agree_safe >= 0.90 and agree_all >= 0.80, (agree_safe, agree_all)     # measured 1.000 / 0.881
+    assert torch.equal(a_mx.permute(1, 0, 2), toks_mx)
+
+
 def test_csm1b_batch16_topk50_sampling_distribution(csm1b_bf16):
     """config 3 (B=16, topk=50, T=1.0, device Philox): codebook-0 samples follow softmax(top-50 logits).
     All 16 rows share one context, so the 16 x 8 seeds = 128 draws come from the same distribution."""

@@ -107,3 +107,40 @@ def test_in_place_parameter_write_outside_training_is_seen_by_generate():
     assert torch.equal(b.cpu(), want)
     assert not torch.equal(a.cpu(), b.cpu()) or True      # (the streams usually differ; equality is not an error)
     m._drop_engine()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the bf16-mode prefill GEMM tiles against the fp64 product of the bf16-rounded operands
+# ---------------------------------------------------------------------------------------------------
+def test_bf16_prefill_gemm_tiles_vs_fp64_product():
+    """`prefill_precision = "bf16"` runs its nn.Linears (reference call sites: modeling_csm.py:345-354 ->
+    transformers LlamaAttention / LlamaMLP) on three tiles: the square tile, the 128 x 128 LDS-DMA tile
+    (gemm_dma_bf16_kernel) and the 256 x 256 LDS-DMA tile (gemm256_kernel<.., MX = false>).  Round 3 pinned the last two
+    only through bitwise self-equalities that ended in a loose end-to-end bound.  Here each tile multiplies bf16 operands
+    (every product exact in fp32) with fp32 accumulation on v_mfma_f32_*_bf16: against the fp64 product the error is the
+    accumulation's alone -- bound 2e-6 of sum |a||b| (an fp32 chain of K <= 8192 terms; measured ~3e-7), three orders
+    below the bf16 rounding of an operand (2^-9)."""
+    from csm_hf_amd.engine import Engine
+    cfg = CSMConfig.tiny()
+    eng = Engine(cfg, synth_state_dict(cfg), DEV, torch.float32, max_batch=1, max_len=64, max_frames=4, max_prefill_rows=128)
+    g = torch.Generator().manual_seed(4)
+    worst = {}
+    for R, N, K in ((256, 256, 512), (512, 1536, 2048), (2048, 2048, 2048), (256, 2048, 8192), (1024, 512, 1024)):
+        A = (torch.randn(R, K, generator=g) * torch.exp2(torch.randint(-2, 3, (R, 1), generator=g).float())).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+        want = A.double() @ W.double().T
+        bound = (A.double().abs() @ W.double().abs().T) * 2e-6 + 1e-30
+        outs = []
+        for kernel in (0, 1, 2):
+            got = eng.k_gemm_bf16(W, A, kernel).cpu().double()
+            ratio = float(((got - want).abs() / bound).max())
+            worst[kernel] = max(worst.get(kernel, 0.0), ratio)
+            assert ratio <= 1.0, (kernel, R, N, K, ratio)
+            outs.append(got)
+        # one fp32 chain in ascending k per output on every tile: the three agree bit for bit
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (R, N, K)
+    print("bf16 tiles vs fp64, worst error / (2e-6 sum|a||b|):", {k: round(v, 3) for k, v in worst.items()})
+    # a shape a tile does not cover is an error, not a silent fallback to another tile
+    with pytest.raises(RuntimeError):
+        eng.k_gemm_bf16(torch.zeros(256, 512), torch.zeros(100, 512), 2)
+    eng.close()
