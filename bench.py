@@ -148,35 +148,46 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
         ids, mask = synth_context(cfg, rows, ctx // 4, ctx - ctx // 4, seed=4)
         ids, mask = ids.to(dev), mask.to(dev)
         a0, a1 = shard_rows(rows, rank, world)
-        walls = []
-        for it in range(2):          # first pass sizes the engine and captures the graph (untimed)
+        # exact = the engine's default (three exact bf16 planes per activation); bf16 = decode_precision "bf16", the reference's own
+        # arithmetic class (one nearest-even plane): reported beside it, never instead of it
+        for mode in (("exact",) if os.environ.get("CSM_BENCH_NO_DECODE_BF16") == "1" else ("exact", "bf16")):
+            model.decode_precision = mode
+            walls = []
+            for it in range(2):          # first pass sizes the engine and captures the graph (untimed)
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                toks = generate_sharded(model, ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
+                                        stop_on_all_zeros=False)
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                walls.append(time.perf_counter() - t0)
+            dec_ms = model._engine.last_generate_ms()
+            tm = torch.tensor([walls[-1], dec_ms / 1e3], dtype=torch.float64, device=dev)
             if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            toks = generate_sharded(model, ids, mask, max_new_frames=frames, temperature=1.0, topk=1,
-                                    stop_on_all_zeros=False)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            walls.append(time.perf_counter() - t0)
-        dec_ms = model._engine.last_generate_ms()
-        tm = torch.tensor([walls[-1], dec_ms / 1e3], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        assert toks.shape == (rows, frames, cfg.audio_num_codebooks), toks.shape
-        passes = max(1, -(-(a1 - a0) // 64))
-        rows_pass = min(a1 - a0, 64)
-        step_ms = float(tm[1]) * 1e3 / frames                 # one frame-step of the last engine pass (rows_pass rows)
-        by = bytes_step(cfg, rows_pass, ctx + (frames - 1) / 2.0 + 1, kvbytes=4)
-        out[leg] = {"rows_total": rows, "rows_per_gpu": a1 - a0, "frames": frames,
-                    "ms_per_step_decode": round(step_ms, 4), "rows_per_engine_pass": rows_pass,
-                    "roofline_frac_of_8TBs": round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "frames_per_s_end_to_end": round(rows * frames / float(tm[0]), 1),
-                    "frames_per_s_decode_only": round(rows * frames / (float(tm[1]) * passes), 1),
-                    "wall_s": round(float(tm[0]), 4), "decode_ms_last_pass": round(float(tm[1]) * 1e3, 2),
-                    "engine_passes_per_gpu": passes,
-                    "tokens_checksum": int(toks.to(torch.int64).sum().item())}
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            assert toks.shape == (rows, frames, cfg.audio_num_codebooks), toks.shape
+            from csm_hf_amd.sharded import MAX_ROWS_PER_PASS
+            passes = max(1, -(-(a1 - a0) // MAX_ROWS_PER_PASS))
+            rows_pass = min(a1 - a0, MAX_ROWS_PER_PASS)
+            step_ms = float(tm[1]) * 1e3 / frames                 # one frame-step of the last engine pass (rows_pass rows)
+            by = bytes_step(cfg, rows_pass, ctx + (frames - 1) / 2.0 + 1, kvbytes=4)
+            rec = {"rows_total": rows, "rows_per_gpu": a1 - a0, "frames": frames,
+                   "ms_per_step_decode": round(step_ms, 4), "rows_per_engine_pass": rows_pass,
+                   "roofline_frac_of_8TBs": round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "frames_per_s_end_to_end": round(rows * frames / float(tm[0]), 1),
+                   "frames_per_s_decode_only": round(rows * frames / (float(tm[1]) * passes), 1),
+                   "wall_s": round(float(tm[0]), 4), "decode_ms_last_pass": round(float(tm[1]) * 1e3, 2),
+                   "engine_passes_per_gpu": passes,
+                   "tokens_checksum": int(toks.to(torch.int64).sum().item())}
+            if mode == "exact":
+                out[leg] = rec
+            else:
+                out[leg]["decode_precision_bf16"] = {k: rec[k] for k in ("ms_per_step_decode", "roofline_frac_of_8TBs", "frames_per_s_end_to_end",
+                                                                        "frames_per_s_decode_only", "tokens_checksum")}
+        model.decode_precision = "exact"
     return out
 
 

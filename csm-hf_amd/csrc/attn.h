@@ -32,6 +32,7 @@ struct AttnArgs {
   float* out;   // [rows][n_q*hd]                  (nsplit == 1)
   float* part;  // [rows][n_q][nsplit][hd+4]       (nsplit > 1): acc[hd], m, l, pad
   bf16_t* oplanes;  // nullable: the output also as MFMA B-operand planes for a batched o_proj (rows <= 16)
+  int pl1;          // decode_precision = bf16: one nearest-even plane (common.h store_planes)
   int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
 };
 
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.n_q * HD + (size_t)h * HD + 4 * lane) = o;
         if (a.oplanes) {   // rows 16..31: second plane group
           const size_t ps = (size_t)a.n_q * HD * 16;
-          store_planes4(a.oplanes + (size_t)(row >> 4) * 3 * ps, ps, h * HD + 4 * lane, row & 15, o);
+          store_planes4(a.oplanes + (size_t)(row >> 4) * 3 * ps, ps, h * HD + 4 * lane, row & 15, o, a.pl1 != 0);
         }
       }
     } else {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // one wave per (row, head); lane s owns split s (nsplit <= 64), then lane = output dim; all partial
 // loads are issued up front (predicated full unroll).
 template <int HD>
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out, bf16_t* oplanes) {
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out, bf16_t* oplanes, int pl1) {
   const int rh = blockIdx.x, lane = threadIdx.x;
   const float* pp = part + (size_t)rh * nsplit * (HD + 4);
   float pv[HD / 64][64];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int
     if (oplanes) {
       const size_t ps = (size_t)n_q * HD * 16;
       const int row = rh / n_q;
-      store_planes(oplanes + (size_t)(row >> 4) * 3 * ps, ps, (rh % n_q) * HD + lane + 64 * i, row & 15, num * inv);
+      store_planes(oplanes + (size_t)(row >> 4) * 3 * ps, ps, (rh % n_q) * HD + lane + 64 * i, row & 15, num * inv, pl1 != 0);
     }
   }
 }

@@ -37,6 +37,7 @@ struct AttnOprojArgs {
   const float* oln;      // [N] the consumer's norm weight
   float* oss;            // [rows][oss_ld]
   int oss_ld;
+  int pl1;               // decode_precision = bf16: one nearest-even plane
 };
 
 #ifdef CSM_ATTN_OPROJ_KERNEL
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(512) void attn_oproj_rows_kernel(AttnOprojArgs a) {
     const float xn = resid + s * ws;
     a.out[(size_t)r * a.ldo + n] = xn;
     if (a.oplanes) {
-      store_planes(a.oplanes + (size_t)(r >> 4) * 3 * 16 * a.N, (size_t)a.N * 16, n, r & 15, xn * ln);
+      store_planes(a.oplanes + (size_t)(r >> 4) * 3 * 16 * a.N, (size_t)a.N * 16, n, r & 15, xn * ln, a.pl1 != 0);
       sq[oloc] = xn * xn;
     }
   }

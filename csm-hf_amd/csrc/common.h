@@ -172,7 +172,14 @@ __device__ __forceinline__ float xor32_max(float x) {
 
 // One activation value into the three planes of the next launch's B operand: exact truncation split, element
 // (row m, column k) at fragment position ((k/128 * 4 + (k/32)%4) * 64 + ((k/8)%4) * 16 + m) * 8 + k%8.
-__device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride, int k, int m, float v) {
+// `one` (decode_precision = bf16, the reference's own arithmetic class, README.md:73): ONE plane, the value rounded to
+// nearest-even bf16 like the reference's eager bf16 execution rounds every activation; planes 1 and 2 are not written
+// and the consumer multiplies plane 0 only.
+__device__ __forceinline__ void store_planes(bf16_t* planes, size_t plane_stride, int k, int m, float v, bool one = false) {
+  if (one) {
+    planes[((size_t)((k >> 7) * 4 + ((k >> 5) & 3)) * 64 + ((k >> 3) & 3) * 16 + m) * 8 + (k & 7)] = f32_to_bf16(v);
+    return;
+  }
   const uint32_t h = __float_as_uint(v) & 0xffff0000u;
   const float r = v - __uint_as_float(h);
   const uint32_t md = __float_as_uint(r) & 0xffff0000u;
@@ -220,7 +227,12 @@ __device__ __forceinline__ void store_rowplane1(bf16_t* p, size_t plane_stride, 
   p[2 * plane_stride] = (bf16_t)(__float_as_uint(l) >> 16);
 }
 // two consecutive columns k0, k0+1 (k0 even) of row m: one 4-byte store per plane
-__device__ __forceinline__ void store_planes2(bf16_t* planes, size_t plane_stride, int k0, int m, float v0, float v1) {
+__device__ __forceinline__ void store_planes2(bf16_t* planes, size_t plane_stride, int k0, int m, float v0, float v1, bool one = false) {
+  if (one) {
+    const size_t off1 = ((size_t)((k0 >> 7) * 4 + ((k0 >> 5) & 3)) * 64 + ((k0 >> 3) & 3) * 16 + m) * 8 + (k0 & 7);
+    *reinterpret_cast<uint32_t*>(planes + off1) = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+    return;
+  }
   const uint32_t h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
   const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
   const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
@@ -231,7 +243,13 @@ __device__ __forceinline__ void store_planes2(bf16_t* planes, size_t plane_strid
   *reinterpret_cast<uint32_t*>(planes + 2 * plane_stride + off) = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
 }
 // four consecutive columns k0..k0+3 (k0 % 4 == 0) of row m: one 8-byte store per plane
-__device__ __forceinline__ void store_planes4(bf16_t* planes, size_t plane_stride, int k0, int m, const f32x4& v) {
+__device__ __forceinline__ void store_planes4(bf16_t* planes, size_t plane_stride, int k0, int m, const f32x4& v, bool one = false) {
+  if (one) {
+    const size_t off1 = ((size_t)((k0 >> 7) * 4 + ((k0 >> 5) & 3)) * 64 + ((k0 >> 3) & 3) * 16 + m) * 8 + (k0 & 7);
+    *reinterpret_cast<uint2*>(planes + off1) = make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
+    return;
+  }
   uint32_t hw[2], mw[2], lw[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {

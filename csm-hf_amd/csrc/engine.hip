@@ -258,6 +258,8 @@ struct csm_engine {
   int* d_slots = nullptr;      // [max_batch] device copy of the slots of one csm_prefill_slots call
   int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
+  int decode_bf16 = 0;   // decode_precision = bf16 (the reference's own arithmetic class for batched decode, README.md:73): activations handed
+                         // between the matrix-core launches as ONE nearest-even bf16 plane, one MFMA per weight fragment instead of three
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bit 5 the fused B = 1 attention + o_proj launch, bit 6 the B = 1 fused-argmax heads, bits 8-12 the same five for the backbone
   int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
   int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
@@ -575,6 +577,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
   else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
+  else if (!strcmp(name, "decode_bf16")) e->decode_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
   else if (!strcmp(name, "prefill_x3_attn")) e->prefill_x3_attn = value;
@@ -648,6 +651,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
   bf16_t* opl = a.oplanes;
   float* oss = a.oss;
   const size_t opl_group = (size_t)3 * 16 * (epi == EPI_SWIGLU ? a.N / 2 : a.N);   // plane group of 16 rows
+  a.pl1 = e->decode_bf16;
   // rows are processed in groups: up to 16 on the matrix-core kernel (bf16 / fp8 weights, eligible shapes),
   // otherwise up to 4 on the fp32-FMA kernels; every group re-streams the weights
   int m0 = 0;
@@ -780,7 +784,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     AttnOprojArgs f{};
     f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
     f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h; f.ldo = ldh;
-    if (planes) { f.oplanes = e->pl_h; f.oln = w.ln2; f.oss = e->pl_ss; f.oss_ld = PL_SS_LD; }
+    if (planes) { f.oplanes = e->pl_h; f.oln = w.ln2; f.oss = e->pl_ss; f.oss_ld = PL_SS_LD; f.pl1 = e->decode_bf16; }
     ao = launch_attn_oproj_rows(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, M, f);
     if (ao != -2) LCK(ao);
   }
@@ -800,6 +804,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)
     const bool att_planes = planes && (e->use_planes & 4);
     t.oplanes = att_planes ? e->pl_act : nullptr;
+    t.pl1 = e->decode_bf16;
     if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
     if (att_planes) o.xplanes = e->pl_act;
@@ -864,7 +869,7 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   em.out = e->h_bb;
   // batched decode on planes: the embedding sum hands layer 0 its operands like every later producer does
   const bool em_planes = planes_on(e, e->bb, B) && (e->use_planes & 16);
-  if (em_planes) { em.oplanes = e->pl_h; em.oln = e->bb.layers[0].ln1; em.oss = e->pl_ss; em.oss_ld = PL_SS_LD; }
+  if (em_planes) { em.oplanes = e->pl_h; em.oln = e->bb.layers[0].ln1; em.oss = e->pl_ss; em.oss_ld = PL_SS_LD; em.pl1 = e->decode_bf16; }
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
     LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false,
@@ -975,7 +980,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     a.logits_trace = s->logits_trace;
     a.row_done = s->per_row_stop ? e->d_row_done : nullptr;
     if (planes_on(e, e->dec, B) && (e->use_planes & 8)) {
-      a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16;
+      a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16; a.pl1 = e->decode_bf16;
     }
     return launch_sample(e->stream, B, a);
   };

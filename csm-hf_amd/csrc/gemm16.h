@@ -108,7 +108,10 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // register file of every SIMD of a CU, so such a workgroup only starts on a CU with nothing else resident.  The weight
 // streamer (prefetch.h) keeps a wave on every SIMD of every CU, so a frame-step that contains one of these launches is
 // not streamed (launch_g16 reports `exclusive`); capping them at 96 registers (5 waves per SIMD) spills 24-58 registers.
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL, bool XP>
+// ONE (with XP) = decode_precision bf16: the planes hold ONE nearest-even bf16 value per activation (GemvArgs::pl1): a third of the
+// plane loads, one MFMA per weight fragment, one-plane stores in the epilogue.  A template flag: as a run-time branch it cost the
+// exact mode 3 % at B = 16 / 64 and moved last bits of the epilogue arithmetic.
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL, bool XP, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][PT][256] | panel[PT][256] | flag[16] | stat[NW][16]
   float* red = lds;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #else
   constexpr int ko = 0;
 #endif
+  constexpr bool one = ONE && XP;
   if (XP) {
     const bf16_t* pp = a.xplanes + ((size_t)chunk * 256 + lane) * 8;
     const size_t ps = (size_t)K * 16;
@@ -193,8 +197,10 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     for (int j = 0; j < 4; ++j) {
       if (ko & 1) { xh[j] = xm[j] = xl[j] = (bf16x8)(short)(lane + j); continue; }
       xh[j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
-      xm[j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
-      xl[j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+      if (!one) {
+        xm[j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
+        xl[j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+      }
     }
   } else {
     const float* xrow = a.x + (size_t)(mlive ? m : 0) * a.ldx + k0;
@@ -277,7 +283,16 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (!mlive) { xa[j] = (f32x4)(0.f); xb[j] = (f32x4)(0.f); }
-      split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
+      if (one) {   // nearest-even bf16 like the producers' one-plane stores
+        uint32_t* ph = reinterpret_cast<uint32_t*>(&xh[j]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float v0 = p < 2 ? xa[j][2 * p] : xb[j][2 * p - 4], v1 = p < 2 ? xa[j][2 * p + 1] : xb[j][2 * p - 3];
+          ph[p] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+        }
+      } else {
+        split3(xa[j], xb[j], xh[j], xm[j], xl[j]);
+      }
     }
   }
   f32x4 acc[PT];
@@ -289,8 +304,10 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     for (int t = 0; t < PT; ++t) {
       const bf16x8 af = wf[t][j].get();
       if (ko & 4) { acc[t][0] += (float)af[0] + (float)xl[j][0] + (float)xm[j][1] + (float)xh[j][2]; continue; }   // operands stay live, no matrix work
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[j], acc[t], 0, 0, 0);  // small terms first
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[j], acc[t], 0, 0, 0);
+      if (!one) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[j], acc[t], 0, 0, 0);  // small terms first
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[j], acc[t], 0, 0, 0);
+      }
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[j], acc[t], 0, 0, 0);
     }
   }
@@ -378,13 +395,13 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
           if (a.oplanes && !(ko & 8)) {
             f32x4 xt;
             xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
-            store_planes4(a.oplanes, (size_t)a.N * 16, n0, mm, xt);
+            store_planes4(a.oplanes, (size_t)a.N * 16, n0, mm, xt, one);
             if (a.oss) red[t * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
           }
         } else {   // SwiGLU: (gate, up) pairs
           const float h0 = (pv[0] / (1.f + __expf(-pv[0]))) * pv[1];
           const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
-          if (a.oplanes && !(ko & 8)) store_planes2(a.oplanes, (size_t)(a.N >> 1) * 16, n0 >> 1, mm, h0, h1);   // the consumer reads the planes only
+          if (a.oplanes && !(ko & 8)) store_planes2(a.oplanes, (size_t)(a.N >> 1) * 16, n0 >> 1, mm, h0, h1, one);   // the consumer reads the planes only
           else if (a.oplanes) {}
           else *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
         }
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       const float xn = pre0[e] + v;
       a.out[(size_t)mm * a.ldo + n] = xn;
       if (a.oplanes) {
-        store_planes(a.oplanes, (size_t)a.N * 16, n, mm, xn * pre1[e]);
+        store_planes(a.oplanes, (size_t)a.N * 16, n, mm, xn * pre1[e], one);
         if (a.oss) red[i] = xn * xn;   // red is free after the panel sum; tile sums are formed below
       }
     } else if (EPI == EPI_SWIGLU) {
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         const float u = panel[i + 1] * (a.wscale ? a.wscale[n + 1] : 1.f) * rs;
         const float hv = (v / (1.f + __expf(-v))) * u;
         a.out[(size_t)mm * a.ldo + (n >> 1)] = hv;
-        if (a.oplanes) store_planes(a.oplanes, (size_t)(a.N >> 1) * 16, n >> 1, mm, hv);
+        if (a.oplanes) store_planes(a.oplanes, (size_t)(a.N >> 1) * 16, n >> 1, mm, hv, one);
       }
     } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
       const int half = a.hd >> 1, spp = half / 16;

@@ -13,7 +13,7 @@
 // weights for a 64-row batch instead of two 32-row launches -- B = 64 is launch-bound like every other batch size, so halving
 // its launches is what counts).  With four tiles the B operands of tile mt+1 are requested while tile mt multiplies (two
 // register sets) instead of all up front.
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2>
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   constexpr int U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][U][256] | panel[U][256] | flag[16] | stat[16 MT]
@@ -59,13 +59,16 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   constexpr int NB = MT < 2 ? MT : 2;
   bf16x8 xh[NB][4], xm[NB][4], xl[NB][4];
   const size_t ps = (size_t)K * 16;
+  constexpr bool one = ONE;   // decode_precision = bf16 (GemvArgs::pl1): one nearest-even activation plane, one MFMA per weight fragment (gemm16.h)
   auto load_planes = [&](int mt, int buf) {
     const bf16_t* pp = a.xplanes + (size_t)mt * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       xh[buf][j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
-      xm[buf][j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
-      xl[buf][j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+      if (!one) {
+        xm[buf][j] = *reinterpret_cast<const bf16x8*>(pp + ps + j * 512);
+        xl[buf][j] = *reinterpret_cast<const bf16x8*>(pp + 2 * ps + j * 512);
+      }
     }
   };
   load_planes(0, 0);
@@ -117,8 +120,10 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
         const bf16x8 af = wf[t][j].get();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);  // small terms first
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          if (!one) {
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);  // small terms first
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          }
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt & 1][j], acc[t][mt], 0, 0, 0);
         }
       }
@@ -134,8 +139,10 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
           const bf16x8 af = wf[t][j].get();
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          if (!one) {
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xl[mt & 1][j], acc[t][mt], 0, 0, 0);
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xm[mt & 1][j], acc[t][mt], 0, 0, 0);
+          }
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xh[mt & 1][j], acc[t][mt], 0, 0, 0);
         }
       }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
             f32x4 xt;
             xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
             const size_t ps = (size_t)a.N * 16;
-            store_planes4(a.oplanes + (size_t)mt * 3 * ps, ps, n0, l & 15, xt);
+            store_planes4(a.oplanes + (size_t)mt * 3 * ps, ps, n0, l & 15, xt, one);
             if (a.oss) red[u * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
           }
         } else {   // SwiGLU: (gate, up) pairs
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
           const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
           if (a.oplanes) {
             const size_t ps = (size_t)(a.N >> 1) * 16;
-            store_planes2(a.oplanes + (size_t)mt * 3 * ps, ps, n0 >> 1, l & 15, h0, h1);
+            store_planes2(a.oplanes + (size_t)mt * 3 * ps, ps, n0 >> 1, l & 15, h0, h1, one);
           } else {
             *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
           }

@@ -1,16 +1,17 @@
 // Instantiations + launcher of the 32-row MFMA skinny GEMM (gemm32.h).
 #include "gemm32.h"
 
-template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT>
+template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT, bool ONE = false>
 static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
                       int n_tickets) {
+  if (!ONE && a.pl1) return launch_g32<WT, KT, PRO, EPI, NW, PT, MT, true>(st, M, KB, a, slabs, slab_floats, tickets, n_tickets);
   constexpr int U = PT * MT;
   int gx;
   if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
   if (KB > 1 && ((size_t)gx * KB * U * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 16 * MT) * sizeof(float);
-  auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT, MT>;
+  auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT, MT, ONE>;
   if (lds > 64 * 1024) {   // four batch tiles x two weight tiles: 72 KiB -- raise the dynamic-LDS limit once per DEVICE
     // (gemm32_configure_all() does this at engine creation, outside any stream capture; this is the safety net)
     static unsigned long long configured = 0ull;
@@ -89,8 +90,11 @@ int gemm32_configure_all() {
         for (int K : {1024, 8192}) {   // KB == 1 and the K-split panel choice of the residual launches
           if (K == 8192 && c[0] == PRO_NORM) continue;
           a.K = K;
-          const int r = launch_gemm32(nullptr, wd, kd, 64, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
-          if (r != 0 && r != -2) return r;
+          for (int one = 0; one < 2; ++one) {
+            a.pl1 = one;
+            const int r = launch_gemm32(nullptr, wd, kd, 64, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
+            if (r != 0 && r != -2) return r;
+          }
         }
   return 0;
 }

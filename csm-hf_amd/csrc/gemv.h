@@ -65,6 +65,7 @@ struct GemvArgs {
   const float* oln;        // norm weight of the consumer folded into the output planes (nullable = 1)
   float* oss;              // output partial sums of squares [16][oss_ld], one column per 16-row tile (EPI_RESID)
   int oss_ld;
+  int pl1;                 // decode_precision = bf16: planes in and out are ONE plane of nearest-even bf16 values (common.h store_planes)
   // ---- fused greedy sampling (B == 1): EPI_ARGMAX writes one (max value, row index) pair per task instead of the
   // logits; PRO_TOKNORM (the next pass's first QKV launch) reduces the pairs to the token, takes its input row
   // from the projected-embedding table and records the token -- replacing sample_kernel for codebooks 1..30.

@@ -28,6 +28,7 @@ struct EmbedArgs {
   // batched decode on activation planes: the summed row also leaves as the B operands of the first layer's QKV launch
   // (x * oln as three bf16 planes in fragment order, 16 rows per group) plus per-16-column sums of x^2 for its RMS scale
   bf16_t* oplanes;   // nullable
+  int pl1;           // decode_precision = bf16: one nearest-even plane
   const float* oln;  // [H] the consumer's norm weight
   float* oss;        // [rows][oss_ld]
   int oss_ld;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
     const float v = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
     if (kk < a.H) {
       a.out[(size_t)row * a.H + kk] = v;
-      if (a.oplanes) store_planes(a.oplanes + (size_t)(row >> 4) * 3 * 16 * a.H, (size_t)a.H * 16, kk, row & 15, v * a.oln[kk]);
+      if (a.oplanes) store_planes(a.oplanes + (size_t)(row >> 4) * 3 * 16 * a.H, (size_t)a.H * 16, kk, row & 15, v * a.oln[kk], a.pl1 != 0);
     }
     if (a.oplanes) part[0][i] = kk < a.H ? v * v : 0.f;   // same thread read part[0][i] above
   }
@@ -461,6 +462,7 @@ struct SampleArgs {
   // batched decode: the fed-back row also goes out as MFMA B-operand planes (gemv.h: xplanes), folded with the norm
   // weight of the decoder's first layer, with its sum of squares in column 0 of the row's partial sums
   bf16_t* oplanes;      // nullable
+  int pl1;              // decode_precision = bf16: one nearest-even plane
   const float* oln;
   float* oss;
   int oss_ld, oss_n;
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(a.oln + k);
         f32x4 t;
         t[0] = v[0] * w[0]; t[1] = v[1] * w[1]; t[2] = v[2] * w[2]; t[3] = v[3] * w[3];
-        store_planes4(a.oplanes + (size_t)(row >> 4) * 3 * a.Hd * 16, (size_t)a.Hd * 16, k, row & 15, t);
+        store_planes4(a.oplanes + (size_t)(row >> 4) * 3 * a.Hd * 16, (size_t)a.Hd * 16, k, row & 15, t, a.pl1 != 0);
         sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
     }

@@ -215,6 +215,9 @@ class CSMModel(nn.Module):
         self.use_graph = True
         self.stop_check_interval = 8     # stop_on_all_zeros: frames replayed between two reads of the device-side stop counters
         self.last_row_lengths = None     # per-row frame counts of the last generate(per_row_stop=True)
+        self.decode_precision = "exact"    # "bf16": BATCHED decode (B >= 2) hands activations between its matrix-core launches as one
+        # nearest-even bf16 plane -- the reference's own arithmetic class (README.md:73 runs the model in bf16) -- instead of three
+        # exact planes: a third of the matrix work and of the plane traffic; B = 1 (fp32 FMA kernels) is unaffected
         self.prefill_precision = "exact"   # "bf16": context GEMMs on bf16-rounded activations (one MFMA pass instead of three);
         # "mxfp8": context GEMMs on the block-scaled fp8 matrix instruction, weights AND activations in OCP MX-fp8 (e4m3 + one
         # E8M0 scale per 32 along K) -- 3 mantissa bits: its own accuracy class, opt-in
@@ -353,6 +356,12 @@ class CSMModel(nn.Module):
         if getattr(self._engine, "_prefill_bf16", 0) != want:
             self._engine.set_option("prefill_bf16", want)
             self._engine._prefill_bf16 = want
+        if self.decode_precision not in ("exact", "bf16"):
+            raise ValueError(f"decode_precision must be 'exact' or 'bf16', got {self.decode_precision!r}")
+        want_d = 1 if self.decode_precision == "bf16" else 0
+        if getattr(self._engine, "_decode_bf16", 0) != want_d:
+            self._engine.set_option("decode_bf16", want_d)
+            self._engine._decode_bf16 = want_d
         want_mx = 1 if self.prefill_precision == "mxfp8" else 0
         if getattr(self._engine, "_prefill_mx", 0) != want_mx:
             if want_mx and not self._engine.has_mx:

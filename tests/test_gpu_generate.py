@@ -292,6 +292,42 @@ def test_csm1b_config1_bf16_weights(gold, csm1b_bf16):
     assert in_top4.mean() > 0.99
 
 
+def test_csm1b_decode_precision_bf16_batched_vs_reference_bf16(gold, csm1b_bf16):
+    """`decode_precision = "bf16"` (VERDICT r3 missing 2): batched decode with ONE nearest-even bf16 activation plane per
+    hand-off -- the reference's own arithmetic class (README.md:73: the model runs in bf16, every nn.Linear of
+    modeling_csm.py:156-167, 545-576 sees bf16 activations).  SURVEY 8-c protocol, teacher-forced with the tokens of the
+    reference's OWN bf16 run (fixture csm1b_cfg1_bf16) on a batch of 3 equal rows (matrix-core kernels): last_h rel-L2 <= 5e-2,
+    top logits within 0.1, arg-max inside the reference's top-4 for > 99 % of the samples; the rows of the batch agree
+    bit for bit; and the mode sits between the exact engine and the bf16 reference: its distance to the EXACT engine
+    (same tokens) is reported and must be a bf16-class distance (1e-4 .. 5e-2), i.e. the switch did something and not more
+    than bf16 rounding."""
+    m = csm1b_bf16
+    gb = gold("csm1b_cfg1_bf16")
+    g = gold("csm1b_cfg1_bf16w_fp32")
+    ids1, mask1 = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    ids, mask = ids1.repeat(3, 1, 1), mask1.repeat(3, 1, 1)
+    forced = torch.from_numpy(gb["tokens"]).repeat(3, 1, 1)
+    try:
+        _, lt_x, ht_x = traced_generate(m, ids, mask, 8, forced=forced)
+        m.decode_precision = "bf16"
+        _, lt_b, ht_b = traced_generate(m, ids, mask, 8, forced=forced)
+    finally:
+        m.decode_precision = "exact"
+        m._drop_engine()
+    assert torch.equal(lt_b[:, 0], lt_b[:, 1]) and torch.equal(lt_b[:, 0], lt_b[:, 2])     # equal rows stay equal
+    ref_h = torch.from_numpy(gb["last_h"])                                             # [n, 1, H]
+    d_ref = rel_l2(ht_b[:, :1], ref_h)
+    d_exact = rel_l2(ht_b, ht_x)
+    top_idx, top_val = gb["top_idx"], gb["top_vals"]                                   # [n, 1, C, 4]
+    mine = lt_b[:, :1]
+    err = np.abs(np.take_along_axis(mine.numpy(), top_idx, -1) - top_val).max()
+    in_top4 = (mine.argmax(-1).numpy()[..., None] == top_idx).any(-1).mean()
+    print(f"decode_precision=bf16, B = 3: last_h vs the reference's bf16 run {d_ref:.3e} (exact engine: {rel_l2(ht_x[:, :1], ref_h):.3e}), vs the exact "
+          f"engine {d_exact:.3e}; top-logit |err| {err:.3f}; arg-max in the reference's top-4: {in_top4:.4f}")
+    assert d_ref < 5e-2 and err < 0.1 and in_top4 > 0.99
+    assert 1e-4 < d_exact < 5e-2, d_exact
+
+
 def test_csm1b_prefill512_hidden_state(gold, csm1b_bf16):
     m = csm1b_bf16
     g = gold("csm1b_prefill512_bf16w_fp32")
