@@ -12,6 +12,16 @@ cache by the difference (`csm_shift_context`: keys re-rotated, RoPE is relative,
 rounding only) and the batch's shared length grows to the new context's; the cache is re-homed into a larger engine
 first when it lacks the room.  A row that finds no queued utterance stays idle (frozen by the per-row stop) and is
 offered the queue again after every chunk.
+
+Bounds (round 4).  Growth by re-homing is CAPPED: a queued context that would move the resident rows by more than
+`max_shift` positions, push the batch's shared length beyond `max_total_len`, or be the `max_shifts_per_batch`-th move of
+this batch stays at the head of the queue (FIFO: nothing overtakes it) and opens the NEXT batch once the running one has
+drained -- instead of doubling the cache without limit.  (With a bf16 KV cache every move rounds the resident keys to
+bf16 once more: `max_shifts_per_batch` bounds that accumulation too; the fp32 default cache re-rotates in fp32.)  Joins are
+BUDGETED per chunk (`join_budget_rows` context frames prefilled between two chunks): a burst of joins cannot hold the
+resident rows' next chunk back by more than one budget's prefill.  Real time is 12.5 frames/s per stream (80 ms per frame,
+/root/reference/ARCHITECTURE.md:44): `latency` records per request the time to its first frame, every inter-chunk gap and
+the chunks delivered later than chunk length x 80 ms after their predecessor.
 """
 from __future__ import annotations
 
@@ -23,7 +33,9 @@ import torch
 
 class ContinuousBatcher:
     def __init__(self, model, batch_size: int, temperature: float = 1.0, topk: int = 50, max_new_frames: int = 100,
-                 check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None, audio_decoder=None):
+                 check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None, audio_decoder=None,
+                 max_shift: int = 1024, max_total_len: int = 16384, max_shifts_per_batch: int = 8, join_budget_rows: int = 4096,
+                 frame_seconds: float = 0.08, clock=None):
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
         self.model = model
@@ -44,6 +56,15 @@ class ContinuousBatcher:
         self.joined_together = 0       # ... how many utterances joined that way (statistics)
         self.joined_mid_batch = 0      # utterances that took over a row of a running batch (statistics)
         self.shifted_for_long_context = 0   # joins whose context was longer than the running batch (resident rows moved up)
+        self.max_shift, self.max_total_len, self.max_shifts_per_batch = int(max_shift), int(max_total_len), int(max_shifts_per_batch)
+        self.join_budget_rows = int(join_budget_rows)
+        self.deferred_to_next_batch = 0     # long contexts that were refused as a join and opened the next batch instead
+        self.joins_deferred_by_budget = 0   # joins that waited one more chunk because the chunk's prefill budget was spent
+        self.frame_seconds = float(frame_seconds)
+        import time as _time
+        self._clock = clock or _time.perf_counter
+        # per request: submit time, time to first frame, gaps between consecutive chunk deliveries, late chunks (gap > frames x 80 ms)
+        self.latency: Dict[int, dict] = {}
 
     def submit(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: Optional[int] = None) -> int:
         """input_ids / attention_mask `[T, 33]` (or `[1, T, 33]`) of ONE utterance; returns its request id."""
@@ -54,7 +75,37 @@ class ContinuousBatcher:
         rid = self._next_id
         self._next_id += 1
         self._queue.append((rid, input_ids.cpu(), attention_mask.cpu(), int(max_new_frames or self.default_budget)))
+        self.latency[rid] = {"t_submit": self._clock(), "t_first_frame": None, "ttff_s": None, "t_last": None, "chunk_gaps_s": [],
+                             "late_chunks": 0, "chunks": 0}
         return rid
+
+    def _delivered(self, rid: int, frames: int, now: float):
+        """`frames` (> 0) frames of request `rid` reached the caller at `now`"""
+        L = self.latency[rid]
+        if L["t_first_frame"] is None:
+            L["t_first_frame"] = now
+            L["ttff_s"] = now - L["t_submit"]
+        else:
+            gap = now - L["t_last"]
+            L["chunk_gaps_s"].append(gap)
+            if gap > frames * self.frame_seconds:
+                L["late_chunks"] += 1
+        L["t_last"] = now
+        L["chunks"] += 1
+
+    def latency_summary(self) -> dict:
+        """time to first frame and inter-chunk gaps over all finished requests (seconds): p50 / p99 / max, late chunks"""
+        import statistics
+        tt = sorted(v["ttff_s"] for v in self.latency.values() if v["ttff_s"] is not None)
+        gaps = sorted(g for v in self.latency.values() for g in v["chunk_gaps_s"])
+
+        def q(xs, p):
+            return xs[min(len(xs) - 1, int(p * len(xs)))] if xs else None
+        return {"requests": len(tt), "ttff_s": {"p50": q(tt, 0.5), "p99": q(tt, 0.99), "max": tt[-1] if tt else None,
+                                                "mean": statistics.fmean(tt) if tt else None},
+                "inter_chunk_gap_s": {"p50": q(gaps, 0.5), "p99": q(gaps, 0.99), "max": gaps[-1] if gaps else None},
+                "chunk_deadline_s": self.check_every * self.frame_seconds,
+                "late_chunks": sum(v["late_chunks"] for v in self.latency.values()), "chunks": sum(v["chunks"] for v in self.latency.values())}
 
     # ------------------------------------------------------------------------------------------------------------
     def run(self) -> Dict[int, torch.Tensor]:
@@ -98,6 +149,7 @@ class ContinuousBatcher:
             dec.streams_open(B)
             spf = dec.cfg.samples_per_frame
             waves = [[] for _ in range(B)]
+        self._shifts_this_batch = 0
         while any(r is not None for r in rows):
             if eng.frames + k > eng.max_frames:
                 eng.rewind_frames()                 # every frame so far has been read out
@@ -111,9 +163,13 @@ class ContinuousBatcher:
             if dec is not None:
                 # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of
                 # idle / finished rows are decoded too and dropped; ids beyond the codec's codebook cannot come from a real model)
-                codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k]
+                live = [b for b, r in enumerate(rows) if r is not None]
+                if live and int(toks_dev[live].max()) >= dec.cfg.codebook_size:
+                    raise ValueError(f"generated token id {int(toks_dev[live].max())} is outside the codec's codebook ({dec.cfg.codebook_size})")
+                codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k] (the clamp only touches idle rows)
                 step = max(1, dec.max_frames // B)
                 wav = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1).cpu()   # [B, 1, k * spf]
+            now = self._clock()
             for b, r in enumerate(rows):
                 if r is None:
                     continue
@@ -127,6 +183,8 @@ class ContinuousBatcher:
                     took += 1
                 if wav is not None and took:
                     waves[b].append(wav[b, 0, :took * spf])
+                if took:
+                    self._delivered(r[0], took, now)
                 if done or len(r[2]) >= r[1]:
                     results[r[0]] = torch.stack(r[2]) if r[2] else torch.zeros(0, C, dtype=torch.long)
                     if dec is not None:
@@ -137,14 +195,19 @@ class ContinuousBatcher:
             # go through ONE slot prefill where that fits (contexts no longer than the batch, max_prefill_rows in total): the
             # running batch waits for one short prefill instead of one per join
             idle = [b for b in range(B) if rows[b] is None]
+            self._budget_left = self.join_budget_rows        # context frames that may be prefilled before the next chunk
             if self.joint_joins and len(idle) >= 2 and len(self._queue) >= 2:
                 eng = self._join_many(eng, rows, idle, k, dec)
                 idle = [b for b in range(B) if rows[b] is None]
             for b in idle:
-                if self._queue:
-                    rows[b], eng = self._join(eng, b, k)
-                    if dec is not None:
-                        dec.streams_reset(b)        # the row's audio stream starts from silence with the new utterance
+                if not self._queue:
+                    break
+                st, eng = self._join(eng, b, k, any(r is not None for r in rows))
+                if st is None:                      # the head of the queue waits (budget spent / growth cap): FIFO, nothing overtakes it
+                    break
+                rows[b] = st
+                if dec is not None:
+                    dec.streams_reset(b)        # the row's audio stream starts from silence with the new utterance
         m._epoch += 1
 
     def _join_many(self, eng, rows, idle, k, dec):
@@ -161,6 +224,9 @@ class ContinuousBatcher:
             S = item[1].shape[0]
             if S > eng.length or (len(take) + 1) * max(smax, S) > eng.max_prefill_rows:
                 break
+            if take and (len(take) + 1) * max(smax, S) > self._budget_left:      # (the first join of a chunk is always admitted)
+                self.joins_deferred_by_budget += 1
+                break
             take.append(item)
             smax = max(smax, S)
         if len(take) < 2:
@@ -168,6 +234,7 @@ class ContinuousBatcher:
         use = idle[:len(take)]
         if not eng.prefill_slots(use, [t[1] for t in take], [t[2] for t in take]):
             return eng
+        self._budget_left -= len(take) * smax
         for b, (rid, _, _, budget) in zip(use, take):
             self._queue.popleft()
             rows[b] = [rid, budget, []]
@@ -177,18 +244,33 @@ class ContinuousBatcher:
                 dec.streams_reset(b)
         return eng
 
-    def _join(self, eng, row, k):
+    def _join(self, eng, row, k, others_live=True):
         """The first queued utterance takes over `row`.  Its context is placed right-aligned against the batch's current
         length; a longer one first moves the resident rows up (Engine.prefill_slot -> shift_context), after the engine has
-        been re-homed into a larger one if the cache lacks the room.  Returns (row state, engine)."""
+        been re-homed into a larger one if the cache lacks the room.  Returns (row state, engine) -- or (None, engine) when
+        the utterance has to WAIT: the chunk's prefill budget is spent (it joins after the next chunk), or admitting it would
+        move the resident rows too far / too often or grow the batch beyond `max_total_len` (it stays at the head of the
+        queue and opens the next batch; with no live row left the batch simply ends)."""
         m = self.model
-        rid, ri, rm, budget = self._queue.popleft()
+        rid, ri, rm, budget = self._queue[0]
         S = ri.shape[0]
+        if S > eng.length and (S - eng.length > self.max_shift or S + k + 1 > self.max_total_len or
+                               self._shifts_this_batch >= self.max_shifts_per_batch):
+            if getattr(self, "_deferred_rid", None) != rid:
+                self.deferred_to_next_batch += 1
+                self._deferred_rid = rid
+            return None, eng
+        if S > self._budget_left and self._budget_left < self.join_budget_rows and others_live:
+            self.joins_deferred_by_budget += 1      # not the first join of this chunk and it does not fit what is left
+            return None, eng
+        self._queue.popleft()
+        self._budget_left -= S
         need = max(eng.length, S) + k + 1
         if need > eng.max_len:
             eng = m._ensure_engine(self.B, need, max(4 * k, 32), 1, cont=True)
         if S > eng.length:
             self.shifted_for_long_context += 1
+            self._shifts_this_batch += 1
         eng.prefill_slot(row, ri, rm)
         self.joined_mid_batch += 1
         return [rid, budget, []], eng

@@ -144,3 +144,52 @@ def test_bf16_prefill_gemm_tiles_vs_fp64_product():
     with pytest.raises(RuntimeError):
         eng.k_gemm_bf16(torch.zeros(256, 512), torch.zeros(100, 512), 2)
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the 8-rank launch of bench.py, dry on one device
+# ---------------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    return r.returncode, line, r.stderr[-3000:]
+
+
+def test_bench_eight_ranks_on_one_device_slices_like_one_process():
+    """BASELINE configs[3] is launched as 8 ranks (`bench.py --gpus 8`, one rank per GPU).  No 8-GPU node is available to
+    the builder, so the launch is exercised DRY: eight gloo ranks that all use cuda:0 (CSM_BENCH_ONE_DEVICE=1) run the real
+    engine on their own row slices -- rank slicing at world 8 (bench.py: ids_all[rank * B: ...], sharded.shard_rows), the
+    barrier / MAX all-reduce / all-gather code, config 4 with weak == strong == 128 rows (16 per rank).  Every rank's tokens
+    equal a solo run of its row, and the 128-row result equals the single-process result of the same rows."""
+    args = ["--steps", "3", "--warmup", "1", "--ctx", "32", "--no-cpu-baseline", "--config4", "1", "--config4-frames", "2"]
+    rc, line, err = _run_bench(["--gpus", "8"] + args, {"CSM_BENCH_ONE_DEVICE": "1", "CSM_BENCH_NO_DECODE_BF16": "1"})
+    assert rc == 0 and line is not None, err
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "batch-split x8" and line["dist_backend"] == "gloo"
+    assert len(line["tokens_checksum_per_rank"]) == 8
+    c4 = line["config4"]
+    assert c4["weak"]["rows_total"] == 128 and c4["strong"]["rows_total"] == 128
+    assert c4["weak"]["rows_per_gpu"] == 16 and c4["strong"]["rows_per_gpu"] == 16 and c4["strong"]["engine_passes_per_gpu"] == 1
+    assert c4["weak"]["tokens_checksum"] == c4["strong"]["tokens_checksum"]            # the same 128 rows, the same split
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    ids, mask = synth_context(cfg, 8, 8, 24, seed=2)
+    for r in (0, 3, 7):
+        out = m.generate(ids[r:r + 1].to(DEV), mask[r:r + 1].to(DEV), max_new_frames=4, topk=1, stop_on_all_zeros=False)
+        w = torch.arange(1, out.numel() + 1, device=out.device, dtype=torch.int64).reshape(out.shape)
+        assert int((out * w).sum()) == line["tokens_checksum_per_rank"][r], f"rank {r} tokens differ from its solo run"
+    ids4, mask4 = synth_context(cfg, 128, 8, 24, seed=4)
+    from csm_hf_amd.sharded import generate_sharded
+    one = generate_sharded(m, ids4.to(DEV), mask4.to(DEV), max_new_frames=2, temperature=1.0, topk=1, stop_on_all_zeros=False)
+    assert int(one.to(torch.int64).sum()) == c4["strong"]["tokens_checksum"]
+    m._drop_engine()

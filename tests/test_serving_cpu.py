@@ -208,3 +208,73 @@ def test_joins_of_one_chunk_go_through_one_slot_prefill():
         else:
             assert not joint_calls and cb.joined_together == 0
         assert cb.joined_mid_batch == 5
+
+
+def test_growth_is_capped_a_too_long_context_opens_the_next_batch():
+    """a join that would move the resident rows further than `max_shift` (or beyond `max_total_len`, or
+    once too often) no longer re-homes the cache without bound: it stays at the head of the queue -- nothing overtakes it --
+    and opens the NEXT batch when the running one has drained."""
+    m = StubModel(max_frames=64)
+    cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=4, max_shift=100)
+    a = cb.submit(*utterance(1, 3), max_new_frames=2)
+    b = cb.submit(*utterance(2, 3), max_new_frames=14)
+    c = cb.submit(*utterance(3, 900), max_new_frames=2)          # 900 - 7 > max_shift: may not join the running batch
+    d = cb.submit(*utterance(4, 3), max_new_frames=2)            # queued behind it: waits too (FIFO)
+    out = cb.run()
+    assert [out[x].shape[0] for x in (a, b, c, d)] == [2, 14, 2, 2]
+    assert len(m.engines) == 2 and cb.deferred_to_next_batch == 1 and cb.shifted_for_long_context == 0
+    assert not any(x[0] == "shift" for x in m.engines[0].log) and not any(x[0] == "join" for x in m.engines[0].log)
+    assert m.engines[1].log[0] == ("prefill", 2, 900)            # c and d opened the next batch together
+    # within the cap the join happens as before; the number of moves per batch is bounded too
+    m2 = StubModel(max_frames=64)
+    cb2 = ContinuousBatcher(m2, batch_size=2, topk=1, check_every=2, max_shift=100, max_shifts_per_batch=1)
+    cb2.submit(*utterance(1, 3), max_new_frames=2)
+    cb2.submit(*utterance(2, 3), max_new_frames=30)
+    cb2.submit(*utterance(3, 50), max_new_frames=2)              # first move: allowed
+    cb2.submit(*utterance(4, 120), max_new_frames=2)             # second move of this batch: deferred
+    out2 = cb2.run()
+    assert len(out2) == 4 and cb2.shifted_for_long_context == 1 and cb2.deferred_to_next_batch == 1 and len(m2.engines) == 2
+
+
+def test_join_budget_per_chunk_and_latency_record():
+    """at most `join_budget_rows` context frames are prefilled between two chunks (the first join of a chunk
+    is always admitted), and every request gets a time-to-first-frame, its inter-chunk gaps and its late chunks (a chunk of k
+    frames is late when it follows its predecessor by more than k x 80 ms) on the batcher's clock."""
+    t = [0.0]
+
+    def clock():
+        return t[0]
+    m = StubModel(max_frames=64)
+    cb = ContinuousBatcher(m, batch_size=3, topk=1, check_every=2, join_budget_rows=10, clock=clock)
+    cb.joint_joins = False
+    specs = [(1, 6, 2), (2, 6, 2), (3, 6, 12), (4, 6, 2), (6, 6, 2), (7, 6, 2)]
+    rid = [cb.submit(*utterance(k, T), max_new_frames=bud) for k, T, bud in specs]
+    orig = m._ensure_engine
+
+    def timed(*a_, **k_):
+        eng = orig(*a_, **k_)
+        gen, pf = eng.generate, eng.prefill_slot
+
+        def generate(s, n, use_graph=True):
+            gen(s, n, use_graph)
+            t[0] += 0.05 * n                      # 50 ms per frame: inside the 80 ms deadline
+
+        def prefill_slot(row, ids, mask):
+            pf(row, ids, mask)
+            t[0] += 0.30                          # a slow join: the NEXT chunk of the resident rows arrives late
+        eng.generate, eng.prefill_slot = generate, prefill_slot
+        return eng
+    m._ensure_engine = timed
+    out = cb.run()
+    assert sorted(out) == rid
+    # rows 0 and 1 finish in the first chunk; two 6-frame contexts are queued but only 10 rows may be prefilled per chunk
+    assert cb.joins_deferred_by_budget >= 1
+    joins = [x for x in m.engines[0].log if x[0] == "join"]
+    assert len(joins) == 3
+    L = cb.latency
+    assert abs(L[rid[0]]["ttff_s"] - 0.10) < 1e-9 and L[rid[0]]["late_chunks"] == 0
+    long_one = L[rid[2]]                           # the 12-frame utterance lives through the joins
+    assert long_one["chunks"] == 6 and len(long_one["chunk_gaps_s"]) == 5
+    assert long_one["late_chunks"] >= 1 and max(long_one["chunk_gaps_s"]) >= 0.40 - 1e-9     # 0.10 generate + 0.30 join > 2 x 80 ms
+    s = cb.latency_summary()
+    assert s["requests"] == 6 and s["late_chunks"] >= 1 and s["chunk_deadline_s"] == 0.16 and s["ttff_s"]["max"] >= s["ttff_s"]["p50"]

@@ -53,6 +53,16 @@ for label in (("warm-up", "continuous", "continuous+audio") if AUDIO else ("warm
             extra = f"; {secs:.0f} s of 24 kHz audio decoded on the way = {secs / dt:.0f} x real time in total"
         print(f"{label:20s}: {N} utterances, {total} frames, batch {B}: {dt:.2f} s = {total / dt:.0f} useful frames/s "
               f"({cb.joined_mid_batch} utterances joined a running batch){extra}", flush=True)
+        # latency against the real-time deadline of 80 ms per frame and stream (all utterances are submitted at t = 0: the
+        # time to first frame of a queued utterance includes its wait for a free row)
+        ls = cb.latency_summary()
+        first = [cb.latency[r]["ttff_s"] for r in sorted(cb.latency)[:B]]
+        ms = lambda v: "-" if v is None else f"{v * 1e3:.1f}"
+        print(f"{'':20s}  time to first frame: first batch {ms(min(first))}-{ms(max(first))} ms; all: p50 {ms(ls['ttff_s']['p50'])} p99 {ms(ls['ttff_s']['p99'])} "
+              f"max {ms(ls['ttff_s']['max'])} ms | inter-chunk gap (chunk = {cb.check_every} frames, deadline {ls['chunk_deadline_s'] * 1e3:.0f} ms): p50 "
+              f"{ms(ls['inter_chunk_gap_s']['p50'])} p99 {ms(ls['inter_chunk_gap_s']['p99'])} max {ms(ls['inter_chunk_gap_s']['max'])} ms; late chunks "
+              f"{ls['late_chunks']} of {ls['chunks']}; joins deferred by the per-chunk prefill budget {cb.joins_deferred_by_budget}, contexts deferred to the "
+              f"next batch {cb.deferred_to_next_batch}", flush=True)
 # static batches (the reference's rule: a batch runs until its longest row is done), same rows per batch, FIFO order
 torch.cuda.synchronize()
 t0 = time.perf_counter()
