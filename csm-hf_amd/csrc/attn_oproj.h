@@ -30,15 +30,10 @@ struct AttnOprojArgs {
   float* out;            // residual stream [N], updated in place (batched form: [rows][ldo])
   int beside_streamer;   // host-side: refuse (-2) when a workgroup of this launch does not fit beside a resident streamer wave
   int dbg_onekey;        // TIMING ONLY (wrong results): every lane loads key 0 -- the launch without its K/V traffic
-  // batched form (attn_oproj_rows_kernel, 2 <= rows <= 64): sequence = row; the updated residual row also leaves as
-  // MFMA B-operand planes for the gate/up launch (x * oln in fragment order, 16 rows per group) + per-16-column sums of x^2
-  int ldo;
-  bf16_t* oplanes;       // nullable
-  const float* oln;      // [N] the consumer's norm weight
-  float* oss;            // [rows][oss_ld]
-  int oss_ld;
-  int pl1;               // decode_precision = bf16: one nearest-even plane
 };
+// (A batched form of this fusion -- one workgroup per (64-output slice, batch row) -- was measured SLOWER than the stand-alone
+//  attention + matrix-core o_proj pair at B = 16 (5.58 vs 5.09 ms per step: every workgroup pulls its row's K/V tiles once per
+//  head) and removed in round 4; numbers in profiles/r03_b16_step_timeline.md and DESIGN.md's appendix.)
 
 #ifdef CSM_ATTN_OPROJ_KERNEL
 // blockDim = 64 n_q (n_q in {2, 4, 8}: the K/V tile alone is 128 registers).  A thread multiplies KPT = max(8, K / 64)
@@ -113,96 +108,6 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
   if (part == 0) a.out[n] = resid + s * ws;
 }
 
-// Batched decode (2 <= rows <= 64, decoder cache of <= 32 positions): the same idea per batch row.  grid = (N / 64, rows),
-// blockDim = 64 n_q: workgroup (slice j, row r) computes row r's n_q attention heads in parallel on its waves, then the 64
-// outputs of its slice: thread (output n, head h) multiplies the HD-wide k range of head h (HD / 8 eight-weight loads,
-// requested at kernel start), the n_q lanes of an output meet by DPP.  The o_proj matrix is read from HBM once and 15 more
-// times from L2 (128 KB per workgroup); K/V of a row are re-read by its N / 64 workgroups (64 KB each, L2).  Epilogue =
-// the batched o_proj's: residual add, the row as planes times the consumer's norm weight, per-tile sums of squares.
-// Would replace attn_decode_kernel (one wave per (row, head)) + the matrix-core o_proj launch.  MEASURED SLOWER and off by
-// default (engine option fuse_attn_oproj bit 1): B = 16 frame-step 5.58 vs 5.09 ms, i.e. ~14 us against 4.7 + 5.5 for the
-// pair: without an exchange between workgroups every one of the 256 workgroups pulls its row's K/V tiles once per head
-// (256 KB) plus 128 KB of weights through its texture unit, 16x the K/V traffic of the stand-alone attention launch.  At
-// one row (attn_oproj_kernel above) the same redundancy is 128 workgroups and it wins; at 16 rows it does not.
-template <typename KT, typename WT, int HD>
-__global__ __launch_bounds__(512) void attn_oproj_rows_kernel(AttnOprojArgs a) {
-  using Tile = AttnTile32<KT, HD>;
-  constexpr int NL = HD / 8, RW = 64;   // eight-weight loads per thread; outputs per workgroup
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // q[n_q][HD] | att[n_q][HD] | p[n_q][32] | sq[64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nq = a.n_q, K = nq * HD;
-  const int r = blockIdx.y;
-  float* qs = lds + wave * HD;
-  float* att = lds + nq * HD;
-  float* pb = lds + 2 * nq * HD + wave * 32;
-  float* sq = lds + 2 * nq * HD + nq * 32;
-  const int oloc = tid / nq, head = tid - oloc * nq;
-  const int n = blockIdx.x * RW + oloc;
-  const WT* wp = reinterpret_cast<const WT*>(a.W) + (size_t)n * K + head * HD;
-  W8<WT> w[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) w[i].load(wp + 8 * i);
-  const float ws = a.wscale ? a.wscale[n] : 1.f;
-  float resid = 0.f, ln = 1.f;
-  if (head == 0) {
-    resid = a.out[(size_t)r * a.ldo + n];
-    if (a.oplanes) ln = a.oln[n];
-  }
-  {
-    const int h = wave;
-    const int pos = row_position(nullptr, 0, a.pos_ptr, a.pos_const);
-    const int cnt = min(pos + 1, 32);
-    const int j = h / (nq / a.n_kv);
-    const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)r * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
-    const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)r * a.n_kv + j) * (size_t)a.lmax * HD;
-    Tile tile;
-    tile.load(kc, vc, a.lmax, 0, cnt, lane);
-    const float* qsrc = a.q + (size_t)r * K + (size_t)h * HD;
-#pragma unroll
-    for (int i = 0; i < HD / 64; ++i) qs[lane + 64 * i] = qsrc[lane + 64 * i];
-    __builtin_amdgcn_wave_barrier();
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 acc = (f32x4)(0.f);
-    tile.accumulate(qs, pb, cnt, lane, m_run, l_run, acc);
-    acc = Tile::reduce(acc);
-    if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(att + h * HD + 4 * lane) = acc * (1.f / l_run);
-  }
-  __syncthreads();
-  const float* xp = att + head * HD;
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp + 8 * i), x1 = *reinterpret_cast<const f32x4*>(xp + 8 * i + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s0 = fmaf(w[i].get(e), x0[e], s0);
-      s1 = fmaf(w[i].get(4 + e), x1[e], s1);
-    }
-  }
-  float s = s0 + s1;
-  s += dpp_all<0xB1>(s);                  // quad_perm [1,0,3,2]
-  if (nq >= 4) s += dpp_all<0x4E>(s);     // quad_perm [2,3,0,1]
-  if (nq >= 8) s += dpp_all<0x141>(s);    // row_half_mirror
-  if (head == 0) {
-    const float xn = resid + s * ws;
-    a.out[(size_t)r * a.ldo + n] = xn;
-    if (a.oplanes) {
-      store_planes(a.oplanes + (size_t)(r >> 4) * 3 * 16 * a.N, (size_t)a.N * 16, n, r & 15, xn * ln, a.pl1 != 0);
-      sq[oloc] = xn * xn;
-    }
-  }
-  if (a.oplanes) {   // per-tile (16 columns) sums of squares of the updated row, fixed order
-    __syncthreads();
-    if (tid < RW / 16) {
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) q += sq[tid * 16 + i];
-      a.oss[(size_t)r * a.oss_ld + blockIdx.x * (RW / 16) + tid] = q;
-    }
-  }
-}
 #endif  // CSM_ATTN_OPROJ_KERNEL
 // returns -2 (caller runs the two-launch form) when the shape is not covered (head_dim not 64 / 128, n_q not 2 / 4 / 8, N % 32, cache longer than 32 positions)
 int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojArgs& a);
-// batched form: rows sequences (row = sequence); -2 when not covered (rows outside 2..64, N % 64, n_q not 2 / 4 / 8)
-int launch_attn_oproj_rows(hipStream_t st, int wdtype, int kvdtype, int rows, const AttnOprojArgs& a);

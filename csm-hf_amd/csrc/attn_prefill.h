@@ -23,7 +23,6 @@ struct PrefillAttnArgs {
                         // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
   uint8_t* oq;          // nullable (attn_prefill_bf16_kernel only): output as MX-fp8 rows [B*S][n_q*64] e4m3 + os [B*S][n_q*2] E8M0 scales
   uint8_t* os;          // (the OCP recipe of mx_quant_rows_kernel, gemm_mx.h; a 32-block = half a head = the lane pair of a query row) instead of `out`
-  int ksplit_groups;    // host-side A/B: 2 = two key groups per workgroup from 256 visible positions on, 3 = the same at <= 128 VGPRs; else one
 };
 
 #ifdef CSM_ATTN_PREFILL_KERNELS   // defined by attn_prefill.hip only

@@ -14,17 +14,8 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
     return (int)hipGetLastError();
   }
   if (bf16_math) {
-    // A/B (engine option attn_key_groups = 2 | 3): two key groups per workgroup -- half the sequential key tiles of the longest
-    // workgroup.  MEASURED SLOWER (csm-1b prefill of 2048 frames, bf16 / mxfp8: 5.91 / 4.72 -> 6.07 / 4.95 ms; register-capped
-    // form 6.60 / 5.38): the kernel is bound by its softmax VALU throughput, not by its longest chain.  Off by default.
-    if (a.past + a.S >= 256 && a.ksplit_groups >= 2) {
-      if (a.ksplit_groups == 3) {   // A/B: register-capped form, two workgroups per CU
-        if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t, 2, 4>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float, 2, 4>), grid, dim3(512), 0, st, a);
-      } else if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t, 2>), grid, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float, 2>), grid, dim3(512), 0, st, a);
-      return (int)hipGetLastError();
-    }
+    // (two key groups per workgroup -- half the sequential key tiles of the longest workgroup -- measured SLOWER, 2048 frames
+    //  bf16 / mxfp8 5.91 / 4.72 -> 6.07 / 4.95 ms: the kernel is bound by its softmax VALU throughput; removed in round 4)
     if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();

@@ -155,26 +155,25 @@ struct csm_engine {
   size_t loss_lab_n = 0, loss_rows_n = 0;
   float* p_part = nullptr;   // split-K partial products of the residual prefill GEMMs: [4][max_prefill_rows][Hb]
   int prefill_splitk = 1;
-  int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
+  static constexpr int prefill_splitk_qkv = 4;   // most K splits of the QKV GEMM (swept 0 / 2 / 4 / 8: 4 best or tied at 32-512 frames) of a short prefill split over K too (partials summed by the RoPE launch)
   float* p_part_gu = nullptr;   // [4][min(128, max_prefill_rows)][2 F] partial products of a short prefill's split-K gate/up GEMM (allocated at first use)
   int prefill_splitk_gu = 2;    // most K splits of the gate/up GEMM of a prefill of <= 64 rows (<= 128 with one activation plane); partials summed + SwiGLU by swiglu_reduce_kernel; 0 / 1 = off.  Measured 2 / 4 ways at 32 / 64 / 128 rows: bf16 1.49 -> 1.37 / 1.38, 1.54 -> 1.42 / 1.47, 1.83 -> 1.76 / 1.86 ms; exact 1.87 -> 1.72 / 1.74, 1.98 -> 1.84 / 1.89, 2.39 -> 2.50 / 2.59
-  int prefill_plane_pad = 2176; // elements between the bf16 planes of an exact-mode operand beyond R K (multiple of 8, <= 8192).  Measured over 4 processes each at 2 048 rows: pad 0 16.1 / 18.2 / 16.1 / 18.3 ms (bimodal by process), 2176: 16.2 / 16.2 / 16.7 / 16.9; 1088: 17.5; 4224: 16.3 / 17.4; no effect at 512 / 1 024 / 16 x 512 rows
-  int prefill_part_resid = 0;   // A/B (GemmArgs::part_resid): split 0 of a split-K o_proj / down_proj adds straight into the residual stream, the next RMSNorm folds the other ksplit - 1.  Bitwise the all-partials form and MEASURED SLOWER (the split-0 workgroups' read-modify-write makes them the launch's tail: 512 / 2 048 frames bf16 2.34 / 5.79 -> 2.42 / 5.85 ms, mxfp8 1.93 / 4.50 -> 2.00 / 4.63): off
+  static constexpr int prefill_plane_pad = 2176; // elements between the bf16 planes of an exact-mode operand beyond R K (multiple of 8, <= 8192).  Measured over 4 processes each at 2 048 rows: pad 0 16.1 / 18.2 / 16.1 / 18.3 ms (bimodal by process), 2176: 16.2 / 16.2 / 16.7 / 16.9; 1088: 17.5; 4224: 16.3 / 17.4; no effect at 512 / 1 024 / 16 x 512 rows
   int gemm_mx_skinny = 256;     // GemmMxArgs::skinny: the same for the MX-fp8 GEMM, as a row bound (0 = off)
   int gemm_dma_skinny = 1;      // GemmArgs::dma_skinny: 64 / 32-row workgroups of the LDS-DMA GEMM for the split-K / SwiGLU launches of a prefill of up to 256 rows (bf16 mode) / 768 rows (exact mode)
   int prefill_fuse_rope = 1;    // QKV GEMM with the RoPE / q-scale / cache-append epilogue (GEPI_ROPE, gemm.h) where an LDS-DMA tile takes the launch and head_dim is 64
   int prefill_fuse_quant = 1;   // mxfp8 mode: the context attention writes its output already MX-quantised (no mx_quant_rows launch)
   size_t p_part_h = 0;          // p_part holds 4 x max_prefill_rows x p_part_h floats
-  int prefill_splitk_max = 8;   // most K splits of a residual prefill GEMM (the partials buffer holds 4 at max_prefill_rows: more only for fewer rows)
-  int prefill_planes = 1;
+  static constexpr int prefill_splitk_max = 8;   // most K splits of a residual prefill GEMM (the partials buffer holds 4 at max_prefill_rows: more only for fewer rows)
+  static constexpr int prefill_planes = 1;
   int prefill_bf16 = 0;   // prefill_precision: 0 = exact (fp32 activations as three bf16 planes), 1 = activations rounded to bf16 (one plane)
-  int gemm_wide = 1, gemm_wide_depth = 1, gemm_wide_exact = 0, gemm_wide_krot = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
+  int gemm_wide = 1; static constexpr int gemm_wide_depth = 1, gemm_wide_exact = 0;   // gemm_wide_kernel switches (GemmArgs::wide ...)
   int gemm_256 = 256;   // gemm256_kernel (256 x 256 tile): minimum workgroup count (tiles x K splits) of a launch it takes (one per CU); 0 = off;
                         // bits 24-25 select a schedule variant (A/B).  csm-1b prefill, bf16 / mxfp8: 2048 frames 6.50 / 5.07 -> 5.86 / 4.71 ms,
                         // 16 x 512 frames 19.7 / 16.0 -> 18.8 / 13.6 ms (profiles/r03_gemm256.txt)
-  int gemm_dma_min_wgs = 200;   // exact (three-plane) LDS-DMA GEMM only for launches of at least this many 128 x 128 workgroups: below, the 64 x 64
+  static constexpr int gemm_dma_min_wgs = 200;   // exact (three-plane) LDS-DMA GEMM only for launches of at least this many 128 x 128 workgroups: below, the 64 x 64
                                 // square tile fills the chip better (256-frame exact prefill 3.26 -> 2.92 ms; 512 / 1024 frames unchanged: profiles/r03_prefill.txt)
-  int gemm_dma = 5, gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): bit 0 one plane, bit 2 three planes (exact), launches of up to 4096 rows
+  int gemm_dma = 5; static constexpr int gemm_dma_max_rows = 4096;   // gemm_dma_bf16_kernel (GemmArgs::dma): bit 0 one plane, bit 2 three planes (exact), launches of up to 4096 rows
   // prefill_precision = mxfp8 (BASELINE configs[4]): MX-fp8 copies of the backbone linears (csm_bind_mx_weights, borrowed) and
   // the quantised-activation scratch [max_prefill_rows][widest K] + scales
   std::unordered_map<const void*, void*> train_wT;   // transposed weight copies of the training backward (train_impl.inc)
@@ -182,7 +181,7 @@ struct csm_engine {
   int prefill_mx = 0;
   uint8_t *p_mx_q = nullptr, *p_mx_s = nullptr, *p_mx_q2 = nullptr, *p_mx_s2 = nullptr;   // q2 / s2: the SwiGLU output (down_proj's operand)
   int mx_fuse_swiglu = 1;   // gate/up writes its SwiGLU output as MX-fp8 itself (0: fp32 + quantiser launch, A/B)
-  int prefill_x3_attn = 1;     // exact mode: context attention as three-piece products on the bf16 matrix pipe (0 = fp32 MFMA)
+  static constexpr int prefill_x3_attn = 1;     // exact mode: context attention as three-piece products on the bf16 matrix pipe (0 = fp32 MFMA)
   int prefill_bf16_attn = 1;   // with prefill_bf16: the context attention on the bf16 matrix pipe too (0 = keep the fp32-MFMA flash kernel)
   // host mirrors
   int B = 0;
@@ -191,15 +190,14 @@ struct csm_engine {
   int nsplit_bb = 0;  // 0 = auto: ~256 workgroups per attention launch
   int fuse_attn_oproj = 1;   // decoder attention + o_proj as one launch (attn_oproj.h): bit 0 single sequence (B = 1: 3.28 -> 3.16 ms),
                              // bit 1 batched rows (measured SLOWER at B = 16, 5.58 vs 5.09 ms: off)
-  int fuse_dec_attn = 0;  // measured (round 1): separate 2-workgroup attention + register-path o_proj is 4 % faster per frame
-  int use_mfma = 1;
-  int flash_prefill = 1;
+  static constexpr int use_mfma = 1;
+  static constexpr int flash_prefill = 1;
   int fuse_sample = 1;   // B == 1 greedy: argmax folded into the head launch + next QKV prologue
   float2* am_part = nullptr;
   float* g16_slabs = nullptr;
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
-  int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
+  static constexpr int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
                                            // consumed lines are then the first victims in L2 (3.32 -> 3.30 ms per step)
   // KV splits of the backbone decode attention: the kernel is latency-bound per 32-key tile, so aim for
   // <= 2 tiles per workgroup at the current length (+ headroom for the frames of this generate call) while
@@ -226,13 +224,13 @@ struct csm_engine {
   unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
   unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
-  int pf_enable = 1, pf_window_mb = 24, pf_sub_kb = 4096, pf_grid = 256;
-  int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
-  int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
-  int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
-  int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
-  int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
-  int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB
+  int pf_enable = 1, pf_window_mb = 24; static constexpr int pf_sub_kb = 4096, pf_grid = 256;
+  static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
+  static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
+  static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
+  static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
+  static constexpr int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
+  static constexpr int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB
   std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
   std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
   uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
@@ -250,20 +248,21 @@ struct csm_engine {
   bf16_t *pl_h = nullptr, *pl_act = nullptr;
   float* pl_ss = nullptr;
   int use_planes = 31;  // bit 0: residual stream, bit 1: SwiGLU output, bit 2: attention output, bit 3: sampler feedback row, bit 4: backbone input row (embedding sum)
-  int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
-  int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
-  int gemv_norm_ks = 1;   // B = 1, K = 2048 normed launches on the register GEMV with two waves per task: bit 0 the backbone QKV (3.134 -> 3.103 ms
+  static constexpr int g16_gu = 0;     // A/B: panel tiles of the batched gate/up launch (0 = auto, 1 | 2 | 4)
+  static constexpr int attn_prefetch = 0;   // backbone decode attention requests tile i+1 before consuming tile i: bit 0 at B = 1, bit 1 at B >= 2
+  static constexpr int gemv_norm_ks = 1;   // B = 1, K = 2048 normed launches on the register GEMV with two waves per task: bit 0 the backbone QKV (3.134 -> 3.103 ms
                           // per step, tokens unchanged), bit 1 gate/up (measured slower: off); profiles/r03_b1_ab.txt
   int* p_seq_slot = nullptr;   // set around stack_rows by csm_prefill_slots: sequence b of the prefill lives in cache slot p_seq_slot[b]
   int* d_slots = nullptr;      // [max_batch] device copy of the slots of one csm_prefill_slots call
-  int attn_key_groups = 0;   // context attention on the bf16 pipe, A/B: 2 | 3 = two key groups per workgroup (measured slower: 2048 frames 5.91 -> 6.07 ms)
   int rows64 = 1;   // batches of 33..64 rows: one matrix-core launch per linear (gemm32_kernel with four batch tiles) instead of two 32-row launches
+  char *shift_kt = nullptr, *shift_vt = nullptr;   // scratch of csm_shift_context (one layer of the resident batch), kept between calls
+  size_t shift_bytes = 0;
   int decode_bf16 = 0;   // decode_precision = bf16 (the reference's own arithmetic class for batched decode, README.md:73): activations handed
                          // between the matrix-core launches as ONE nearest-even bf16 plane, one MFMA per weight fragment instead of three
   int dbg_skip = 0;   // TIMING ONLY (results are wrong): knock launches out of a decode layer -- bits 0-4 decoder QKV / attention / o_proj / gate-up / down_proj, bit 5 the fused B = 1 attention + o_proj launch, bit 6 the B = 1 fused-argmax heads, bits 8-12 the same five for the backbone
-  int g16_slab = 0;   // A/B: split-K slab exchange form (gemv.h g16_slab)
-  int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
-  int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
+  int g16_slab = 0;   // bits 4-7: TIMING-ONLY knock-outs of the -DCSM_G16_KO variant build (dbg_skip bits 16-19)
+  static constexpr int g16_down = 0;   // A/B: panel shape override of the batched down_proj (nw | kb << 8 | pt << 16), 0 = auto
+  static constexpr int attn_one_wave = 1;  // bit 0: decoder attention, bit 1: backbone attention as one-wave workgroups (measured: B=1
                           // 3.54 / 3.49 / 3.56 / 3.51 ms per step for 0 / 1 / 2 / 3)
 };
 
@@ -452,6 +451,8 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->stream2) hipStreamDestroy(e->stream2);
   for (void* p : e->allocs) hipFree(p);
+  if (e->shift_kt) hipFree(e->shift_kt);
+  if (e->shift_vt) hipFree(e->shift_vt);
   drop_tiled(e);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -566,29 +567,16 @@ extern "C" int csm_set_kv_start(csm_engine_t* e, const int32_t* kv_start_host, i
 
 extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   if (!e || !name) return fail(CSM_ERR_ARG, "null argument");
-  if (!strcmp(name, "nt_backbone")) e->nt_backbone = value;
-  else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value;
-  else if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
-  else if (!strcmp(name, "fuse_decoder_attention")) e->fuse_dec_attn = value;
+  if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
-  else if (!strcmp(name, "use_mfma")) e->use_mfma = value;
-  else if (!strcmp(name, "flash_prefill")) e->flash_prefill = value;
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
-  else if (!strcmp(name, "attn_one_wave")) e->attn_one_wave = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "decode_bf16")) e->decode_bf16 = value ? 1 : 0;
-  else if (!strcmp(name, "prefill_planes")) e->prefill_planes = value;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
-  else if (!strcmp(name, "prefill_x3_attn")) e->prefill_x3_attn = value;
   else if (!strcmp(name, "gemm_wide")) e->gemm_wide = value;
-  else if (!strcmp(name, "gemm_wide_depth")) e->gemm_wide_depth = value;
-  else if (!strcmp(name, "gemm_wide_krot")) e->gemm_wide_krot = value;
-  else if (!strcmp(name, "gemm_wide_exact")) e->gemm_wide_exact = value;
   else if (!strcmp(name, "gemm_dma")) e->gemm_dma = value;
-  else if (!strcmp(name, "gemm_dma_min_wgs")) e->gemm_dma_min_wgs = value;
   else if (!strcmp(name, "gemm_256")) e->gemm_256 = value < 0 ? 0 : value;
-  else if (!strcmp(name, "gemm_dma_max_rows")) e->gemm_dma_max_rows = value;
   else if (!strcmp(name, "prefill_bf16")) e->prefill_bf16 = value ? 1 : 0;
   else if (!strcmp(name, "mx_fuse_swiglu")) e->mx_fuse_swiglu = value;
   else if (!strcmp(name, "prefill_mx")) {
@@ -596,38 +584,15 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
     e->prefill_mx = value ? 1 : 0;
   }
   else if (!strcmp(name, "prefill_splitk")) e->prefill_splitk = value ? 1 : 0;
-  else if (!strcmp(name, "prefill_splitk_qkv")) e->prefill_splitk_qkv = value < 0 ? 0 : value;   // 0 / 1: off; n: at most n splits
   else if (!strcmp(name, "prefill_splitk_gu")) e->prefill_splitk_gu = value < 0 ? 0 : value;
-  else if (!strcmp(name, "prefill_plane_pad")) e->prefill_plane_pad = value < 0 ? 0 : (value > 8192 ? 8192 : (value & ~7));
-  else if (!strcmp(name, "prefill_part_resid")) e->prefill_part_resid = value ? 1 : 0;
   else if (!strcmp(name, "gemm_mx_skinny")) e->gemm_mx_skinny = value < 0 ? 0 : value;
   else if (!strcmp(name, "gemm_dma_skinny")) e->gemm_dma_skinny = value < 0 ? 0 : value;   // 2 = A/B: exact mode up to 4096 rows
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
-  else if (!strcmp(name, "prefill_splitk_max")) e->prefill_splitk_max = value < 1 ? 1 : (value > 32 ? 32 : value);
-  else if (!strcmp(name, "g16_down")) e->g16_down = value;
-  else if (!strcmp(name, "g16_slab")) e->g16_slab = value;
-  else if (!strcmp(name, "dbg_skip")) e->dbg_skip = value;
+  else if (!strcmp(name, "dbg_skip")) { e->dbg_skip = value & 0xffff; e->g16_slab = (value >> 16) << 4; }   // bits 16-19: in-kernel knock-outs of the CSM_G16_KO build
   else if (!strcmp(name, "rows64")) e->rows64 = value ? 1 : 0;
-  else if (!strcmp(name, "attn_key_groups")) e->attn_key_groups = value;
-  else if (!strcmp(name, "gemv_norm_ks")) e->gemv_norm_ks = value;
-  else if (!strcmp(name, "attn_prefetch")) e->attn_prefetch = value;
-  else if (!strcmp(name, "g16_gu")) e->g16_gu = value;
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
-  else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
-  else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
-  else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
-  else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
-  else if (!strcmp(name, "g16_k16")) e->g16_k16 = value;
-  else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;
-  else if (!strcmp(name, "prefetch_skip_late")) e->pf_skip_late = value ? 1 : 0;
-  else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 1 ? 1 : value;
-  else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
-  else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
-  else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value;
-  else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value;
-  else if (!strcmp(name, "prefetch_stride")) e->pf_stride = (value == 32 || value == 64 || value == 128 || value == 256) ? value : 0;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -733,7 +698,7 @@ static bool planes_on(const csm_engine* e, const Stack& s, int M) {
 
 // one Llama layer on M single-token rows (decode)
 static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh, const int* pos_ptr, int pos_const,
-                        float* qb, float* att, float* part, int nsplit, float* act, int nt, bool fuse_attn,
+                        float* qb, float* att, float* part, int nsplit, float* act, int nt,
                         const GemvArgs* tok = nullptr, bool kv_only = false, bool in_planes = false,
                         const float* next_ln = nullptr) {
   const csm_layer_weights_t& w = s.layers[l];
@@ -767,9 +732,9 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   o.nt = nt_small;
   o.W = w.wo; o.wscale = w.so; o.N = H; o.K = nq * hd; o.ldx = nq * hd; o.out = h; o.ldo = ldh;
   int ao = -2;
-  if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn && (sk & 32)) {
+  if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && (sk & 32)) {
     ao = 0;   // dbg_skip bit 5: the fused attention + o_proj launch knocked out (timing only)
-  } else if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
+  } else if (M == 1 && (e->fuse_attn_oproj & 1) && &s == &e->dec && s.lmax <= 32) {
     // single sequence, short cache: one launch for SDPA + o_proj (heads in parallel on the waves of each o_proj workgroup)
     AttnOprojArgs f{};
     f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
@@ -779,21 +744,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
   }
-  if (ao == -2 && M >= 2 && (e->fuse_attn_oproj & 2) && &s == &e->dec && s.lmax <= 32 && !fuse_attn) {
-    // batched decode, short cache: per batch row the same fusion (attn_oproj_rows_kernel); planes epilogue like o_proj's
-    AttnOprojArgs f{};
-    f.q = qb; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
-    f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h; f.ldo = ldh;
-    if (planes) { f.oplanes = e->pl_h; f.oln = w.ln2; f.oss = e->pl_ss; f.oss_ld = PL_SS_LD; f.pl1 = e->decode_bf16; }
-    ao = launch_attn_oproj_rows(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, M, f);
-    if (ao != -2) LCK(ao);
-  }
   if (ao != -2) {
-  } else if (fuse_attn) {
-    // short cache (decoder, <= 32 positions): SDPA runs as the prologue of the o_proj launch
-    o.x = qb; o.n_q = nq; o.n_kv = nkv; o.hd = hd; o.pos_ptr = pos_ptr; o.pos_const = pos_const;
-    o.kcache = s.kc[l]; o.vcache = s.vc[l]; o.lmax = s.lmax;
-    LCK(gemv_rows(e, M, PRO_ATTN, EPI_RESID, o));
   } else {
     AttnArgs t{};
     t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
@@ -828,7 +779,6 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
   d.nt = nt_big;
   d.W = w.wd; d.wscale = w.sd; d.N = H; d.K = F; d.x = act; d.ldx = F; d.out = h; d.ldo = ldh;
   if (e->g16_down) { d.g16_nw = e->g16_down & 0xff; d.g16_kb = (e->g16_down >> 8) & 0xff; d.g16_pt = (e->g16_down >> 16) & 0xff; }
-  d.g16_slab = e->g16_slab;
   if (planes) { d.xplanes = act_planes ? e->pl_act : nullptr; d.oplanes = e->pl_h; d.oln = next_ln; d.oss = e->pl_ss; d.oss_ld = PL_SS_LD; }
   if (!(sk & 16)) LCK(gemv_rows(e, M, PRO_PLAIN, EPI_RESID, d));
   return 0;
@@ -872,7 +822,7 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   if (em_planes) { em.oplanes = e->pl_h; em.oln = e->bb.layers[0].ln1; em.oss = e->pl_ss; em.oss_ld = PL_SS_LD; em.pl1 = e->decode_bf16; }
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
-    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone, false,
+    LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone,
                      nullptr, false, l > 0 || em_planes, l + 1 < e->bb.c.layers ? e->bb.layers[l + 1].ln1 : e->bb.final_norm));
   if (want_last_h) {
     LCK(launch_rmsnorm(e->stream, e->h_bb, Hb, e->bb.final_norm, B, Hb, e->bb.c.rms_eps, e->last_h, Hb, nullptr, 0, 0));
@@ -1003,7 +953,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     }
     for (int l = 0; l < e->dec.c.layers && !(two_tok && p == 1); ++l)
       LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder,
-                       e->fuse_dec_attn && e->dec.lmax <= 32 && B == 1, (use_tok && l == 0) ? &tok : nullptr,
+                       (use_tok && l == 0) ? &tok : nullptr,
                        // pass 0 (the backbone state at position 0) produces no logits: its last layer only has to
                        // append K/V -- the attention, o_proj and MLP of that layer are dead work
                        p == 0 && l == e->dec.c.layers - 1, l > 0 || (p >= 2 && (e->use_planes & 8) && !use_tok),   // p == 1: codebook 0 was sampled before pass 0 overwrote the planes
@@ -1223,7 +1173,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     }
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     // the bf16 flash kernel leaves its output already MX-quantised (a 32-block is half a head: the lane pair of a query row)
     bool att_q = e->flash_prefill && e->prefill_bf16_attn && e->prefill_fuse_quant && hd == 64;
     if (att_q) { fa.oq = e->p_mx_q; fa.os = e->p_mx_s; }
@@ -1238,16 +1188,8 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
     LCK(fr);
     if (!att_q) LCK(quant(e->p_att, A));
     if (ks_o > 1) {
-      if (e->prefill_part_resid) {
-        GemmMxArgs g{};
-        g.Aq = e->p_mx_q; g.As = e->p_mx_s; g.Wq = m.o; g.Ws = m.o_s; g.R = (int)R; g.N = H; g.K = A; g.C = e->p_h; g.ldc = H;
-        g.ksplit = ks_o; g.Cpart = e->p_part; g.part_stride = part_stride; g.part_resid = 1; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
-        LCK(launch_gemm_mx(e->stream, GEPI_PARTIAL, g));
-        pending = ks_o - 1;
-      } else {
-        LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
-        pending = ks_o;
-      }
+      LCK(gemm(GEPI_PARTIAL, m.o, m.o_s, H, A, nullptr, 0, ks_o, part_stride));
+      pending = ks_o;
     } else {
       LCK(gemm(GEPI_RESID, m.o, m.o_s, H, A, e->p_h, H, 1, 0));
     }
@@ -1273,9 +1215,8 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
       GemmMxArgs g{};
       g.Aq = fq ? e->p_mx_q2 : e->p_mx_q; g.As = fq ? e->p_mx_s2 : e->p_mx_s; g.Wq = m.d; g.Ws = m.d_s; g.R = (int)R; g.N = H; g.K = F;
       g.C = e->p_h; g.ldc = H; g.ksplit = ks_d; g.Cpart = e->p_part; g.part_stride = part_stride; g.big = e->gemm_256; g.skinny = e->gemm_mx_skinny;
-      g.part_resid = (ks_d > 1 && e->prefill_part_resid) ? 1 : 0;
       LCK(launch_gemm_mx(e->stream, ks_d > 1 ? GEPI_PARTIAL : GEPI_RESID, g));
-      if (ks_d > 1) pending = ks_d - g.part_resid;
+      if (ks_d > 1) pending = ks_d;
     }
   }
   *pending_out = pending;
@@ -1353,7 +1294,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     GemmArgs g{};
     if (pl) { g.Aplanes = e->p_pl_h; g.a_plane_stride = ps_h; }
     g.A = e->p_xn; g.lda = H; g.W = w.wqkv; g.wscale = w.sqkv; g.R = (int)R; g.N = s.nqkv(); g.K = H; g.C = e->p_qkv; g.ldc = s.nqkv();
-    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.krot = e->gemm_wide_krot; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs; g.dma_skinny = e->gemm_dma_skinny;
+    g.Wt = tiled_of(e, w.wqkv); g.wide = e->gemm_wide; g.wide_depth = e->gemm_wide_depth; g.wide_exact = e->gemm_wide_exact; g.dma = e->gemm_dma; g.dma_max_rows = e->gemm_dma_max_rows; g.big256 = e->gemm_256; g.dma_min_wgs = e->gemm_dma_min_wgs; g.dma_skinny = e->gemm_dma_skinny;
     RopeArgs ra{};
     bool roped = false;
     if (ks_q > 1) {
@@ -1377,7 +1318,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     }
     PrefillAttnArgs fa{};
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
-    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.ksplit_groups = e->attn_key_groups; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
+    fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }
     int fr = e->flash_prefill ? launch_attn_prefill(e->stream, e->cfg.kv_dtype, B, hd, fa, (one && e->prefill_bf16_attn) ? 1 : (e->prefill_x3_attn ? 2 : 0)) : -2;
     bool att_pl = pl && fr != -2;
@@ -1390,12 +1331,12 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     LCK(fr);
     GemmArgs o{};
     if (att_pl) { o.Aplanes = e->p_pl_h; o.a_plane_stride = ps_att; }
-    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.krot = e->gemm_wide_krot; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs; o.dma_skinny = e->gemm_dma_skinny;
+    o.Wt = tiled_of(e, w.wo); o.wide = e->gemm_wide; o.wide_depth = e->gemm_wide_depth; o.wide_exact = e->gemm_wide_exact; o.dma = e->gemm_dma; o.dma_max_rows = e->gemm_dma_max_rows; o.big256 = e->gemm_256; o.dma_min_wgs = e->gemm_dma_min_wgs; o.dma_skinny = e->gemm_dma_skinny;
     o.A = e->p_att; o.lda = nq * hd; o.W = w.wo; o.wscale = w.so; o.R = (int)R; o.N = H; o.K = nq * hd; o.C = e->p_h; o.ldc = H;
     if (att_pl && ks_o > 1) {
-      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride; o.part_resid = e->prefill_part_resid;
+      o.ksplit = ks_o; o.Cpart = e->p_part; o.part_stride = part_stride;
       LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, o));
-      pending = ks_o - o.part_resid;
+      pending = ks_o;
     } else {
       LCK(launch_gemm(e->stream, wd, GEPI_RESID, o));
     }
@@ -1404,7 +1345,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     pending = 0;
     GemmArgs gu{};
     if (pl) { gu.Aplanes = e->p_pl_h; gu.a_plane_stride = ps_h; gu.Cplanes = e->p_pl_act; gu.c_plane_stride = ps_act; }
-    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.krot = e->gemm_wide_krot; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs; gu.dma_skinny = e->gemm_dma_skinny;
+    gu.Wt = tiled_of(e, w.wgu); gu.wide = e->gemm_wide; gu.wide_depth = e->gemm_wide_depth; gu.wide_exact = e->gemm_wide_exact; gu.dma = e->gemm_dma; gu.dma_max_rows = e->gemm_dma_max_rows; gu.big256 = e->gemm_256; gu.dma_min_wgs = e->gemm_dma_min_wgs; gu.dma_skinny = e->gemm_dma_skinny;
     gu.A = e->p_xn; gu.lda = H; gu.W = w.wgu; gu.wscale = w.sgu; gu.R = (int)R; gu.N = 2 * F; gu.K = H; gu.C = e->p_act; gu.ldc = F;
     if (ks_gu > 1) {   // short prefill: split over K, partials summed + SwiGLU by swiglu_reduce_kernel (misc.h)
       gu.ksplit = ks_gu; gu.Cpart = e->p_part_gu; gu.part_stride = R * (size_t)(2 * F);
@@ -1415,12 +1356,12 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
     }
     GemmArgs d{};
     if (pl) { d.Aplanes = e->p_pl_act; d.a_plane_stride = ps_act; }
-    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.krot = e->gemm_wide_krot; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs; d.dma_skinny = e->gemm_dma_skinny;
+    d.Wt = tiled_of(e, w.wd); d.wide = e->gemm_wide; d.wide_depth = e->gemm_wide_depth; d.wide_exact = e->gemm_wide_exact; d.dma = e->gemm_dma; d.dma_max_rows = e->gemm_dma_max_rows; d.big256 = e->gemm_256; d.dma_min_wgs = e->gemm_dma_min_wgs; d.dma_skinny = e->gemm_dma_skinny;
     d.A = e->p_act; d.lda = F; d.W = w.wd; d.wscale = w.sd; d.R = (int)R; d.N = H; d.K = F; d.C = e->p_h; d.ldc = H;
     if (pl && ks_d > 1) {
-      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride; d.part_resid = e->prefill_part_resid;
+      d.ksplit = ks_d; d.Cpart = e->p_part; d.part_stride = part_stride;
       LCK(launch_gemm(e->stream, wd, GEPI_PARTIAL, d));
-      pending = ks_d - d.part_resid;
+      pending = ks_d;
     } else {
       LCK(launch_gemm(e->stream, wd, GEPI_RESID, d));
     }
@@ -1594,12 +1535,22 @@ extern "C" int csm_shift_context(csm_engine_t* e, int delta) {
   if (len + delta > e->cfg.max_len) return fail(CSM_ERR_CAPACITY, "length %d + shift %d exceeds max_len %d", len, delta, e->cfg.max_len);
   if (delta >= s.rope_positions) return fail(CSM_ERR_CAPACITY, "shift %d beyond the RoPE table (%d positions)", delta, s.rope_positions);
   const size_t es = e->esz_kv, cnt = (size_t)B * nkv * len * hd;
-  char *kt = nullptr, *vt = nullptr;
   if (len > 0) {
-    if (hipMalloc((void**)&kt, cnt * es + 256) != hipSuccess || hipMalloc((void**)&vt, cnt * es + 256) != hipSuccess) {
-      if (kt) hipFree(kt);
-      return fail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) for the context shift failed", 2 * cnt * es);
+    // scratch for ONE layer of the resident batch, kept by the engine (a hipMalloc / hipFree pair per join otherwise)
+    if (e->shift_bytes < cnt * es) {
+      if (e->shift_kt) hipFree(e->shift_kt);
+      if (e->shift_vt) hipFree(e->shift_vt);
+      e->shift_kt = e->shift_vt = nullptr;
+      e->shift_bytes = 0;
+      const size_t want = cnt * es + cnt * es / 2 + 256;   // headroom: the batch keeps growing while it runs
+      if (hipMalloc((void**)&e->shift_kt, want) != hipSuccess || hipMalloc((void**)&e->shift_vt, want) != hipSuccess) {
+        if (e->shift_kt) hipFree(e->shift_kt);
+        e->shift_kt = e->shift_vt = nullptr;
+        return fail(CSM_ERR_NOMEM, "hipMalloc(%zu bytes) for the context shift failed", 2 * want);
+      }
+      e->shift_bytes = want - 256;
     }
+    char *kt = e->shift_kt, *vt = e->shift_vt;
     for (int l = 0; l < s.c.layers; ++l) {
       KvShiftArgs a{};
       a.kcache = s.kc[l]; a.vcache = s.vc[l]; a.ktmp = kt; a.vtmp = vt; a.B = B; a.n_kv = nkv; a.hd = hd; a.lmax = s.lmax; a.len = len;
@@ -1613,16 +1564,17 @@ extern "C" int csm_shift_context(csm_engine_t* e, int delta) {
                               (size_t)B * nkv, hipMemcpyDeviceToDevice, e->stream);
       }
       if (r || h1 != hipSuccess || h2 != hipSuccess) {
-        hipStreamSynchronize(e->stream); hipFree(kt); hipFree(vt);
-        return fail(r ? r : (int)(h1 != hipSuccess ? h1 : h2), "context shift failed at layer %d", l);
+        // NOT atomic: layers 0 .. l-1 are already moved and re-rotated while the counters are not.  The resident batch is
+        // unusable: drop it, so that every later call fails loudly until the caller resets and prefills again
+        hipStreamSynchronize(e->stream);
+        e->B = 0; e->h_len = 0; e->h_frame = 0; e->ready = false;
+        return fail(r ? r : (int)(h1 != hipSuccess ? h1 : h2), "context shift failed at layer %d: the resident batch was dropped (csm_reset + csm_prefill)", l);
       }
     }
   }
   LCK(launch_add_ints(e->stream, e->d_kv_start, B, delta));
   LCK(launch_set_int(e->stream, e->d_len, len + delta));
   HIPCK(hipStreamSynchronize(e->stream));
-  if (kt) hipFree(kt);
-  if (vt) hipFree(vt);
   e->h_len = len + delta;
   return 0;
 }

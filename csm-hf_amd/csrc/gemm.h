@@ -57,17 +57,14 @@ struct GemmArgs {
   int ksplit;
   float* Cpart;
   size_t part_stride;
-  // part_resid = 1 (residual GEMMs: o_proj, down_proj): split 0 adds its partial product straight into the residual stream C (the
-  // RESID epilogue) and only splits 1.. go to Cpart (+ (s - 1) * part_stride): the consumer folds ksplit - 1 partials.  x + p0 is
-  // the first addition of the fold either way, so the result is bitwise the all-partials form at one partial array less written
-  // and re-read (16.8 MB each way per launch at 2 048 rows)
-  int part_resid;
+  // (split 0 adding straight into the residual stream -- one partial array less written and re-read -- was bitwise the
+  //  all-partials form and SLOWER at every length: its read-modify-write made those workgroups the launch's tail; removed in round 4)
   // fragment-order copy of W (launchers.hip tile16_kernel; nullable): enables gemm_wide_kernel for one-plane activations
   const void* Wt;
   // gemm_wide_kernel switches (per engine, csm_set_option): wide = 0 keeps the square tile; wide_depth = weight-fragment
   // sets in registers (1: two workgroups per CU, 4: one); wide_exact = 1 also routes three-plane (exact) launches to it
-  // (measured slower: off); krot = start the k walk at a per-workgroup step (changes the fp32 summation order: off)
-  int wide, wide_depth, wide_exact, krot;
+  // (measured slower: off)
+  int wide, wide_depth, wide_exact;
   // gemm_dma_bf16_kernel (gemm_mx.h: both operands staged by LDS-DMA from row-major memory, 128 x 128 x 64 tile) for one-plane
   // bf16 launches.  Bits: 1 = one-plane launches of at most dma_max_rows rows, 2 = one-plane always (A/B), 4 = three-plane
   // (exact) launches of 256 ... dma_max_rows rows, 8 = three-plane always (A/B), 32 = three-plane launches on 32-wide k-steps
@@ -233,8 +230,7 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(GemmArgs a) {
           }
         } else if (r < a.R) {
           if (EPI == GEPI_PARTIAL) {
-            if (a.part_resid && blockIdx.y == 0) a.C[(size_t)r * a.ldc + n] += v;
-            else a.Cpart[(size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n] = v;
+            a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
           }
           else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
@@ -423,8 +419,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
           }
         } else if (r < a.R) {
           if (EPI == GEPI_PARTIAL) {
-            if (a.part_resid && blockIdx.y == 0) a.C[(size_t)r * a.ldc + n] += v;
-            else a.Cpart[(size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n] = v;
+            a.Cpart[(size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n] = v;
           }
           else if (EPI == GEPI_RESID) a.C[(size_t)r * a.ldc + n] += v;
           else a.C[(size_t)r * a.ldc + n] = v;
@@ -520,7 +515,7 @@ __global__ __launch_bounds__(256, (DEPTH == 1 && NPL == 1) ? 2 : 1) void gemm_wi
   // at the same k at the same time, and with tiles 16 K elements (a power of two) apart every fragment request of that
   // moment lands on the same few L2 / HBM channels (measured: ~1/4 of the L2 bandwidth, 24 % matrix-pipe busy)
   const int nstep = kspan / BK;
-  const int s0 = a.krot ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nstep) : 0;
+  const int s0 = 0;   // (a per-workgroup rotated start of the k walk changed the summation order and did not pay: removed in round 4)
   auto kof = [&](int i) {   // k of logical step i (0 <= i < nstep + DEPTH)
     int t = s0 + i;
     t = t >= nstep ? t - nstep : t;
@@ -607,14 +602,7 @@ __global__ __launch_bounds__(256, (DEPTH == 1 && NPL == 1) ? 2 : 1) void gemm_wi
           c[0] = h0; c[1] = h1;
         }
       } else if (EPI == GEPI_PARTIAL) {
-        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
-          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-          const f32x4 o = *c;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          *c = v;
-        } else {
-          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
-        }
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;

@@ -346,8 +346,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     for (int e = 0; e < NQ; ++e) {
       const int q = tid + e * 64 * NW;
       if (q < PT * 64) {
-        if (a.g16_slab & 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, /*sc1*/ 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mine[e]), rs, slab_off + q * 16, 0, /*sc1*/ 16);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -365,8 +364,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       f32x4 v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb)
-        v[kb] = kb < KB ? ((a.g16_slab & 3) == 2 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, 0))
-                                           : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, /*sc1*/ 16)))
+        v[kb] = kb < KB ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(kb * PT * 1024 + q * 16), 0, /*sc1*/ 16))
                         : (f32x4)(0.f);
       f32x4 s = (f32x4)(0.f);
 #pragma unroll

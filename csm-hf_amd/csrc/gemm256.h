@@ -405,14 +405,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(ARGS a) {
         }
         if (!done) *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
       } else if (EPI == GEPI_PARTIAL) {
-        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
-          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-          const f32x4 o = *c;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          *c = v;
-        } else {
-          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
-        }
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;

@@ -43,7 +43,6 @@ struct GemmMxArgs {
   uint8_t* Cq;
   uint8_t* Cs;
   int big;             // host-side: workgroup count from which the 256 x 256 tile (gemm256.h) takes the launch (0 = never)
-  int part_resid;      // GEPI_PARTIAL: split 0 adds into C (RESID), splits 1.. go to Cpart (GemmArgs::part_resid, gemm.h)
   int skinny;          // host-side: > 0 = PARTIAL / SWIGLU launches of at most this many rows run 64 (<= 32 rows: 32) activation rows per workgroup
   RopeEpi rope;        // GEPI_ROPE only (gemm.h)
 };
@@ -276,14 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx_kernel(GemmMxArgs a) {
         const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
         *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
       } else if (EPI == GEPI_PARTIAL) {
-        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
-          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-          const f32x4 o = *c;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          *c = v;
-        } else {
-          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
-        }
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;
@@ -447,14 +439,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
           *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
         }
       } else if (EPI == GEPI_PARTIAL) {
-        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
-          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-          const f32x4 o = *c;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          *c = v;
-        } else {
-          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
-        }
+        *reinterpret_cast<f32x4*>(a.Cpart + (size_t)blockIdx.y * a.part_stride + (size_t)r * a.N + n) = v;
       } else if (EPI == GEPI_RESID) {
         f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
         const f32x4 o = *c;
@@ -467,139 +452,8 @@ __global__ __launch_bounds__(256, NPL == 1 ? 2 : 1) void gemm_dma_bf16_kernel(Ge
   }
 }
 
-// ---- exact mode (three planes), k-steps of 32: a stage is 32 KiB, TWO workgroups per CU --------------------------------------
-// gemm_dma_bf16_kernel<EPI, 3> keeps one 4-wave workgroup per CU (2 x 64 KiB of LDS): one wave per SIMD, so every LDS-read
-// latency, barrier and DMA wait of a k-step is exposed although the step is matrix-pipe bound (96 MFMAs per wave against 32
-// fragment reads): 0.33 of the bf16 peak on gate/up at 512 rows.  Here a k-step is 32 elements -- 64-byte LDS rows, one
-// 16-byte chunk per lane and fragment, 48 MFMAs per wave and step -- so a stage is (3 + 1) x 128 rows x 64 B = 32 KiB and two
-// workgroups share a CU: a second wave on every SIMD multiplies while the first waits.  A fragment (16 rows x 64 B) is one
-// contiguous KiB of LDS, read conflict-free without a swizzle; a DMA piece (1 KiB) covers 16 rows.  Per accumulator the
-// products are added in the same order as in the 64-wide kernel (k ascending; lo, mid, hi inside a 32-wide step): bitwise
-// the same result.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_dma3_k32_kernel(GemmArgs a) {
-  constexpr int BM = 128, BKB = 64, BKE = 32;            // k-step: 64 bytes = 32 elements
-  constexpr int TILE = BM * BKB, STAGE = 4 * TILE;       // 8 KiB per plane tile; [A hi | A mid | A lo | W]
-  extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int j16 = lane & 15, g = lane >> 4;
-  const int nbm = (a.R + BM - 1) / BM, nbn = a.N / BM;
-  int bm, bn;
-  if (nbn % 8 == 0) {
-    const int q = (int)blockIdx.x >> 3;
-    bm = q % nbm;
-    bn = (q / nbm) * 8 + ((int)blockIdx.x & 7);
-  } else {
-    bm = (int)blockIdx.x % nbm;
-    bn = (int)blockIdx.x / nbm;
-  }
-  const int r0 = bm * BM, n0 = bn * BM;
-  const int kspan = EPI == GEPI_PARTIAL ? a.K / a.ksplit : a.K;
-  const int kbeg = EPI == GEPI_PARTIAL ? (int)blockIdx.y * kspan : 0;
-  const int nk = kspan / BKE;
-  const uint8_t* Ab = reinterpret_cast<const uint8_t*>(a.Aplanes);
-  const uint8_t* Wb = reinterpret_cast<const uint8_t*>(a.W);
-  const size_t rowb = (size_t)a.K * 2, psb = a.a_plane_stride * 2;
-  // DMA pieces of this wave: tile rows 32 wave + 16 i .. + 16 (i = 0, 1); lane l lands at row + (l >> 2), chunk position l & 3.
-  // Bank swizzle (exhaustive search over the lane groups in which ds_read_b128 is serviced, MI355X guide: {0-3, 12-15, 20-27},
-  // ...): chunk c of row r is stored at position c ^ (bit3(r) << 1) -- applied to the per-lane SOURCE address here, to the read
-  // offset below; without it every fragment read is a 2-way conflict.
-  const uint8_t* asrc[2];
-  const uint8_t* wsrc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 32 + i * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
-    const int ra = min(r0 + row, a.R - 1);
-    asrc[i] = Ab + (size_t)ra * rowb + (size_t)kbeg * 2 + c * 16;
-    wsrc[i] = Wb + (size_t)(n0 + row) * rowb + (size_t)kbeg * 2 + c * 16;
-  }
-  auto issue = [&](int ks, int st) {
-    uint8_t* base = mx_lds + st * STAGE;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + p * psb + (size_t)ks * BKB),
-                                         (__attribute__((address_space(3))) void*)(base + p * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (size_t)ks * BKB),
-                                       (__attribute__((address_space(3))) void*)(base + 3 * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-  };
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4)(0.f);
-  const int cg = (g ^ (((j16 >> 3) & 1) << 1)) * 16;
-  const int aoff = (wr * 64 + j16) * BKB + cg, woff = 3 * TILE + (wc * 64 + j16) * BKB + cg;
-
-  issue(0, 0);
-  for (int ks = 0; ks < nk; ++ks) {
-    const int st = ks & 1;
-    if (ks + 1 < nk) {
-      issue(ks + 1, st ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // the 8 pieces of step ks have landed; step ks+1 stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    const uint8_t* sb = mx_lds + st * STAGE;
-    dma_bf16x8 wf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<u32x4*>(&wf[t]) = *reinterpret_cast<const u32x4*>(sb + woff + t * 16 * BKB);
-#pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
-      dma_bf16x8 af[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(&af[p]) = *reinterpret_cast<const u32x4*>(sb + p * TILE + aoff + ri * 16 * BKB);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int p = 2; p >= 0; --p)   // lo, mid, hi: small terms first
-          acc[ri][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[p], acc[ri][ni], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#pragma unroll
-  for (int ri = 0; ri < 4; ++ri) {
-    const int r = r0 + wr * 64 + ri * 16 + j16;
-    if (r >= a.R) continue;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
-      f32x4 v = acc[ri][ni];
-      if (EPI == GEPI_SWIGLU) {
-        const float h0 = (v[0] / (1.f + __expf(-v[0]))) * v[1], h1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
-        if (a.Cplanes) {        // three exact planes for the down_proj GEMM
-          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1), a.c_plane_stride, h0);
-          store_rowplane1(a.Cplanes + (size_t)r * (a.N >> 1) + (n >> 1) + 1, a.c_plane_stride, h1);
-        } else {
-          *reinterpret_cast<f32x2*>(a.C + (size_t)r * a.ldc + (n >> 1)) = f32x2{h0, h1};
-        }
-      } else if (EPI == GEPI_PARTIAL) {
-        if (a.part_resid && blockIdx.y == 0) {   // split 0: straight into the residual stream
-          f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-          const f32x4 o = *c;
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          *c = v;
-        } else {
-          *reinterpret_cast<f32x4*>(a.Cpart + (size_t)((int)blockIdx.y - a.part_resid) * a.part_stride + (size_t)r * a.N + n) = v;
-        }
-      } else if (EPI == GEPI_RESID) {
-        f32x4* c = reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n);
-        const f32x4 o = *c;
-        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        *c = v;
-      } else {
-        *reinterpret_cast<f32x4*>(a.C + (size_t)r * a.ldc + n) = v;
-      }
-    }
-  }
-}
+// (A three-plane form on 32-wide k-steps with two workgroups per CU -- gemm_dma3_k32_kernel, round 3 -- was bitwise this
+// kernel and not faster on whole prefills (profiles/r03_prefill.txt); removed in round 4.)
 #endif  // CSM_ARGS_ONLY
 
 // -2 = shape / operands not covered (the caller falls back to the other prefill GEMM kernels)

@@ -67,28 +67,9 @@ static int launch_dma_epi(hipStream_t st, const dim3& grid, const GemmArgs& a) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a);
   return (int)hipGetLastError();
 }
-template <int EPI>
-static int launch_dma3_k32(hipStream_t st, const dim3& grid, const GemmArgs& a) {
-  hipLaunchKernelGGL((gemm_dma3_k32_kernel<EPI>), grid, dim3(256), 2 * 4 * 128 * 64, st, a);   // 64 KiB: no attribute needed
-  return (int)hipGetLastError();
-}
 int launch_gemm_dma_bf16(hipStream_t st, int epi, const GemmArgs& a) {
   if (!a.Aplanes || !a.W || a.wscale || a.R < 1 || a.N % 128 || a.K % 64 || a.ldc % 4) return -2;
   const bool exact = a.a_plane_stride != 0;
-  if (exact && (a.dma & 32)) {   // three planes on 32-wide k-steps: two workgroups per CU
-    if (epi == GEPI_ROPE) return -2;
-    if (epi == GEPI_SWIGLU && a.Cplanes && a.c_plane_stride == 0) return -2;
-    const int ks3 = epi == GEPI_PARTIAL ? a.ksplit : 1;
-    if (ks3 < 1 || a.K % (32 * ks3) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;
-    const dim3 grid3(((a.R + 127) / 128) * (a.N / 128), ks3);
-    switch (epi) {
-      case GEPI_STORE: return launch_dma3_k32<GEPI_STORE>(st, grid3, a);
-      case GEPI_RESID: return launch_dma3_k32<GEPI_RESID>(st, grid3, a);
-      case GEPI_SWIGLU: return launch_dma3_k32<GEPI_SWIGLU>(st, grid3, a);
-      case GEPI_PARTIAL: return launch_dma3_k32<GEPI_PARTIAL>(st, grid3, a);
-      default: return -1;
-    }
-  }
   if (epi == GEPI_SWIGLU && a.Cplanes && (a.c_plane_stride != 0) != exact) return -2;
   const int ks = epi == GEPI_PARTIAL ? a.ksplit : 1;
   if (ks < 1 || a.K % (64 * ks) || (epi == GEPI_PARTIAL && !a.Cpart)) return -2;

@@ -12,9 +12,9 @@
 // Replaces (reference call sites): q/k/v/o_proj, gate/up/down_proj inside transformers.LlamaModel as
 // called from modeling_csm.py:345-354,545-552,568-576; codebook0_head (:361), projection (:542),
 // audio_head matmul (:557); RMSNorm (transformers modeling_llama.py:62-67) as prologue; RoPE
-// (modeling_llama.py:130-160) + DynamicCache append (cache_utils.py:144-145) as the QKV epilogue; and,
-// for short caches (the 32-position decoder), SDPA itself (sdpa_attention.py:97-163) as the prologue of
-// the o_proj launch (PRO_ATTN).
+// (modeling_llama.py:130-160) + DynamicCache append (cache_utils.py:144-145) as the QKV epilogue.
+// (SDPA as the prologue of the o_proj launch -- PRO_ATTN, round 1 -- measured 4 % slower per frame than the separate
+// launch and was removed in round 4; the B = 1 decoder runs attention + o_proj as attn_oproj_kernel.)
 #pragma once
 #include "common.h"
 #include "prefetch.h"
@@ -22,20 +22,20 @@
 #include "attn_tile.h"
 #endif
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_ATTN = 2, PRO_TOKNORM = 3 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_TOKNORM = 3 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
 
 struct GemvArgs {
   const void* W;
   const float* wscale;  // per-output-row scale (fp8 weights), nullable
   int N, K;
-  const float* x;  // [M][ldx]   (PRO_ATTN: q [M][n_q*hd], pre-scaled, rotated)
+  const float* x;  // [M][ldx]
   int ldx;
   const float* ln;  // PRO_NORM weight [K]
   float eps;
   float* out;  // EPI_STORE/RESID: [M][ldo] indexed by output row; EPI_SWIGLU: [M][ldo] indexed by pair
   int ldo;
-  // EPI_QKV / PRO_ATTN
+  // EPI_QKV
   int n_q, n_kv, hd;
   float qscale;
   const float* cos_tab;  // [pos][hd/2]
@@ -88,7 +88,7 @@ struct GemvArgs {
   int norm_ks;         // host-side: 2 = single-row normed launches with K = 2048 take the register path with two waves per task (K split in the workgroup)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
-  int g16_slab;  // split-K slab exchange of the MFMA kernel: 0 = write-through (sc1) stores + sc1 loads, 1 = plain stores + sc1 loads, 2 = plain both (A/B)
+  int g16_slab;  // bits 4-7: TIMING-ONLY knock-outs of the -DCSM_G16_KO variant build (gemm16.h); the split-K slab exchange is write-through (sc1) stores + sc1 loads
   // weight streamer (prefetch.h): launches-started counter bumped by workgroup 0 (nullable), and a host-side slot
   // the launcher fills with this launch's workgroup -> rows geometry
   unsigned* prog;
@@ -106,43 +106,6 @@ __device__ __forceinline__ size_t k_index(int b, int j, int d, int t, int n_kv, 
 }
 __device__ __forceinline__ size_t v_index(int b, int j, int t, int d, int n_kv, int hd, int lmax) {
   return (((size_t)b * n_kv + j) * lmax + t) * hd + d;
-}
-
-// Short-cache attention (<= 32 keys: the decoder) for one row into LDS: xs[h*hd + d] = softmax(q_h K^T) V.
-// Waves split the query heads; consecutive heads of a wave that share a kv-head reuse the register tile.
-template <typename KT, int HD>
-__device__ __forceinline__ void attn_short_to_lds(const GemvArgs& a, int m, float* xs, float* qs, float* pbuf) {
-  using Tile = AttnTile32<KT, HD>;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = a.n_q / a.n_kv;
-  const int b = a.row_seq ? a.row_seq[m] : a.seq_base + m;
-  const int pos = row_position(a.row_pos, m, a.pos_ptr, a.pos_const);
-  const int cnt = pos + 1;  // <= 32
-  const int hpw = (a.n_q + 3) >> 2;
-  const int h0 = wave * hpw, h1 = min(a.n_q, h0 + hpw);
-  Tile tile;
-  int cur_j = -1;
-  if (h0 < h1) {
-    cur_j = h0 / G;
-    tile.load(reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + cur_j) * (size_t)(HD >> 2) * a.lmax * 4,
-              reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + cur_j) * (size_t)a.lmax * HD, a.lmax, 0, cnt, lane);
-  }
-  const float* q = a.x + (size_t)m * a.ldx;
-  for (int i = tid * 4; i < a.n_q * HD; i += 1024) *reinterpret_cast<f32x4*>(qs + i) = *reinterpret_cast<const f32x4*>(q + i);
-  __syncthreads();
-  for (int h = h0; h < h1; ++h) {
-    const int j = h / G;
-    if (j != cur_j) {
-      cur_j = j;
-      tile.load(reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD >> 2) * a.lmax * 4,
-                reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD, a.lmax, 0, cnt, lane);
-    }
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 acc = (f32x4)(0.f);
-    tile.accumulate(qs + h * HD, pbuf + wave * 32, cnt, lane, m_run, l_run, acc);
-    acc = Tile::reduce(acc);
-    if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(xs + h * HD + 4 * lane) = acc * (1.f / l_run);
-  }
 }
 
 struct GemvTask {
@@ -490,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 
 template <typename WT, typename KT, int M, int PRO, int EPI, int KS>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] | red[M][4] | part[4][2M] | (PRO_ATTN) p[4][32] q[K]
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] | red[M][4] | part[4][2M]
   constexpr int U = 4;
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,7 +505,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   }
   constexpr int XR = 2;  // x column blocks of 1024 held in registers (K <= 2048: every normed input of the model)
   f32x4 xv[M][XR], lnw[XR];
-  if (PRO != PRO_ATTN) {
+  {
 #pragma unroll
     for (int r = 0; r < XR; ++r) {
       const int kk = tid * 4 + r * 1024;
@@ -563,14 +526,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   }
 
   // ---- prologue: stage x into LDS (plain | RMS-normalised | short-cache attention output) -----------
-  if (PRO == PRO_ATTN) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (a.hd == 128) attn_short_to_lds<KT, 128>(a, m, xs + (size_t)m * K, part + 4 * 2 * M + 128, part + 4 * 2 * M);
-      else attn_short_to_lds<KT, 64>(a, m, xs + (size_t)m * K, part + 4 * 2 * M + 128, part + 4 * 2 * M);
-      __syncthreads();
-    }
-  } else if (PRO == PRO_NORM && K <= XR * 1024) {
+  if (PRO == PRO_NORM && K <= XR * 1024) {
     // normed inputs: statistic and scaling entirely from registers, one LDS-only barrier for the wave exchange
     float ss[M];
 #pragma unroll

@@ -46,14 +46,14 @@ int launch_gemv(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi
 int gemv_configure_all() {
   GemvArgs a{};
   a.configure_only = 1;
-  static const int combos[6][2] = {{PRO_PLAIN, EPI_STORE}, {PRO_NORM, EPI_STORE}, {PRO_PLAIN, EPI_RESID},
-                                   {PRO_ATTN, EPI_RESID}, {PRO_NORM, EPI_SWIGLU}, {PRO_NORM, EPI_QKV}};
+  static const int combos[5][2] = {{PRO_PLAIN, EPI_STORE}, {PRO_NORM, EPI_STORE}, {PRO_PLAIN, EPI_RESID},
+                                   {PRO_NORM, EPI_SWIGLU}, {PRO_NORM, EPI_QKV}};
   for (int wd = 0; wd < 3; ++wd)
     for (int kd = 0; kd < 2; ++kd)
       for (int M = 1; M <= 4; ++M)
         for (int ks = 1; ks <= 4; ks *= 2)
           for (auto& c : combos) {
-            if (c[1] != EPI_QKV && c[0] != PRO_ATTN && kd == 1) continue;
+            if (c[1] != EPI_QKV && kd == 1) continue;
             int r = launch_dispatch(nullptr, wd, kd, M, c[0], c[1], ks, a);
             if (r) return r;
           }

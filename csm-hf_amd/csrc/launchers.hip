@@ -223,27 +223,6 @@ int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojAr
   return launch_attn_oproj_t<float, float>(st, a);
 }
 
-template <typename KT, typename WT>
-static int launch_attn_oproj_rows_t(hipStream_t st, int rows, const AttnOprojArgs& a) {
-  const dim3 grid(a.N / 64, rows), block(64 * a.n_q);
-  const size_t lds = ((size_t)2 * a.n_q * a.hd + (size_t)a.n_q * 32 + 64) * sizeof(float);
-  if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_rows_kernel<KT, WT, 64>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((attn_oproj_rows_kernel<KT, WT, 128>), grid, block, lds, st, a);
-  return (int)hipGetLastError();
-}
-int launch_attn_oproj_rows(hipStream_t st, int wdtype, int kvdtype, int rows, const AttnOprojArgs& a) {
-  if ((a.hd != 64 && a.hd != 128) || a.lmax > 32 || a.n_q % a.n_kv || rows < 2 || rows > 64 || a.N % 64) return -2;
-  if (a.n_q != 2 && a.n_q != 4 && a.n_q != 8) return -2;
-  if (kvdtype == 1) {
-    if (wdtype == 2) return launch_attn_oproj_rows_t<bf16_t, fp8_t>(st, rows, a);
-    if (wdtype == 1) return launch_attn_oproj_rows_t<bf16_t, bf16_t>(st, rows, a);
-    return launch_attn_oproj_rows_t<bf16_t, float>(st, rows, a);
-  }
-  if (wdtype == 2) return launch_attn_oproj_rows_t<float, fp8_t>(st, rows, a);
-  if (wdtype == 1) return launch_attn_oproj_rows_t<float, bf16_t>(st, rows, a);
-  return launch_attn_oproj_rows_t<float, float>(st, rows, a);
-}
-
 int launch_ce_rows(hipStream_t st, const CeArgs& a) {
   if (a.rows < 1) return 0;
   hipLaunchKernelGGL(ce_rows_kernel, dim3(a.rows), dim3(256), 0, st, a);

@@ -17,7 +17,7 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
@@ -498,9 +498,11 @@ class Engine:
             ids = ids.unsqueeze(0)
             mask = None if mask is None else mask.unsqueeze(0)
         S = ids.shape[1]
+        if not 0 <= int(row) < max(self.batch, 1):
+            raise ValueError(f"row {row} outside the running batch of {self.batch}")
+        ids, m = self._prep_ids(ids, mask)          # validates the joining ids BEFORE the resident rows are touched
         if S > self.length:
             self.shift_context(S - self.length)
-        ids, m = self._prep_ids(ids, mask)
         torch.cuda.current_stream().synchronize()
         _ck(self.lib, self.lib.csm_prefill_slot(self._h, int(row), _ptr(ids), _ptr(m), S))
         self.sync()

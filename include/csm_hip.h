@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 5
+#define CSM_ABI_VERSION 6
 
 enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
@@ -128,18 +128,22 @@ int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w);
 int csm_build_proj_table(csm_engine_t* e, float* proj_table_out);
 int csm_set_proj_table(csm_engine_t* e, const float* proj_table);
 int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; graphs stay */
-/* engine knobs (A/B measurements; defaults are the measured best): "nt_backbone", "nt_decoder" (non-temporal weight
- * loads: 0 none, 1 all, 2 large streams only), "nsplit_backbone" (KV splits of the backbone decode attention, 0 = by
- * length), "use_mfma" (batched rows on the matrix-core kernel), "tile_weights" (fragment-order weight copies for that
- * kernel; 0 frees them), "attn_one_wave" (bit 0 decoder / bit 1 backbone attention as one-wave workgroups),
- * "use_planes" (bit mask: batched activations handed over as MFMA B-operand planes -- 1 residual stream, 2 SwiGLU
- * output, 4 attention output, 8 sampler feedback row), "fuse_sample" (greedy arg-max folded into the head launch),
- * "fuse_decoder_attention", "flash_prefill", "prefill_planes" (prefill activations handed to the GEMMs as bf16 planes),
- * "g16_gu" / "g16_down" (panel-shape overrides of the batched gate/up and down_proj launches), "weight_prefetch" (weight
- * streamer on/off), "prefetch_window_mb" (bytes it may run ahead of the consumers, default 24), "prefetch_sub_kb"
- * (pacing granularity), "prefetch_grid" (its workgroups, default 256); "prefill_fuse_rope" (1: apply_rotary_pos_emb +
- * DynamicCache.update, modeling_llama.py:130-176 / 267-281, run as the EPILOGUE of the prefill's QKV GEMM instead of a launch
- * of their own) and "prefill_fuse_quant" (1: MX-fp8 prefill, the attention output leaves its kernel already quantised) */
+/* Engine options -- the COMPLETE list (ABI 6 removed 36 A/B knobs whose losing variants left the library; an unknown name is
+ * CSM_ERR_ARG).  Defaults are the measured best; every call drops the captured graphs.
+ *   precision:   "prefill_bf16" (context activations rounded to bf16), "prefill_mx" (context linears on the MX-fp8 matrix
+ *                instruction; needs csm_bind_mx_weights), "prefill_bf16_attn" (context attention on the bf16 pipe in those
+ *                modes), "decode_bf16" (batched decode on ONE nearest-even activation plane: the reference's own bf16 class)
+ *   decode:      "nsplit_backbone" (KV splits of the backbone attention, 0 = by length), "fuse_attn_oproj" (B = 1 decoder
+ *                attention + o_proj as one launch), "fuse_sample" (greedy arg-max folded into the head launch),
+ *                "two_token_pass" (positions 0 and 1 of the decoder as one 2-row pass, modeling_csm.py:534-552), "use_planes"
+ *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (33-64 rows in one launch per linear),
+ *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
+ *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 24)
+ *   prefill:     "gemm_wide", "gemm_dma", "gemm_256", "gemm_dma_skinny", "gemm_mx_skinny" (tile selection of the context GEMMs:
+ *                used by the bitwise tile-vs-tile tests), "prefill_splitk", "prefill_splitk_gu" (K splits of short prefills),
+ *                "prefill_fuse_rope" (RoPE + cache append as the QKV GEMM's epilogue, modeling_llama.py:130-176 / 267-281),
+ *                "prefill_fuse_quant" / "mx_fuse_swiglu" (MX quantisation fused into the producing kernels)
+ *   measurement: "dbg_skip" (TIMING ONLY, wrong results: knock launch kinds out of the decode chain) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).

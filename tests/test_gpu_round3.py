@@ -865,36 +865,3 @@ def test_skinny_tiles_of_the_mx_gemm_are_bitwise():
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (n_ctx, gu, float((a[0] - b[0]).abs().max()))
     m._engine.set_option("gemm_mx_skinny", 256)
     m._drop_engine()
-
-
-def test_split_zero_of_a_residual_gemm_adds_straight_into_the_residual_stream():
-    """Split-K o_proj / down_proj of a prefill (GEPI_PARTIAL): with `prefill_part_resid` (an A/B option, measured slower and off by
-    default) split 0 runs the RESID epilogue on the residual stream and only splits 1.. are written as partial products for the next RMSNorm to fold.  x + p0 is the first addition
-    of the fold either way: hidden state and logits are BITWISE those of the all-partials form (three precisions, 128- and 64-row
-    LDS-DMA tiles, the 256 x 256 tile at 1 024 rows, the square tile)."""
-    cfg = CSMConfig()
-    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
-    m = CSMModel(cfg)
-    m.load_state_dict(sd)
-    del sd
-
-    def run(precision, n_ctx, opts):
-        ids, mask = synth_context(cfg, 1, n_ctx // 4, n_ctx - n_ctx // 4, seed=2)
-        m.prefill_precision = precision
-        eng = m._ensure_engine(1, 1100, 4, 1024)
-        for k, v in opts.items():
-            eng.set_option(k, v)
-        eng.reset()
-        eng.set_kv_start([0])
-        lh, lg = eng.prefill(ids, mask)
-        return lh.cpu(), lg.cpu()
-    for precision in ("exact", "bf16", "mxfp8"):
-        for n_ctx, extra in ((48, {}), (300, {}), (300, dict(gemm_dma=0)), (1024, {})):
-            if precision == "exact" and n_ctx == 1024:
-                continue
-            a = run(precision, n_ctx, dict(prefill_part_resid=0, **extra))
-            b = run(precision, n_ctx, dict(prefill_part_resid=1, **extra))
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (precision, n_ctx, extra, float((a[0] - b[0]).abs().max()))
-        m._engine.set_option("gemm_dma", 5)
-    m._engine.set_option("prefill_part_resid", 0)
-    m._drop_engine()
