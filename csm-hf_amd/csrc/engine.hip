@@ -267,7 +267,7 @@ struct csm_engine {
 };
 
 static void drop_tiled(csm_engine* e);
-constexpr int PL_GROUPS = 4;     // plane groups of 16 rows: batches up to 64 rows run on activation planes
+constexpr int PL_GROUPS = 8;     // plane groups of 16 rows: batches up to 128 rows run on activation planes
 constexpr int PL_SS_LD = 512;   // partial-sum columns per row: hidden / 16 tiles, hidden <= 8192
 static inline int emb_dtype(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? CSM_DTYPE_BF16 : e->cfg.weight_dtype; }
 static inline size_t w_esz(const csm_engine* e) { return e->cfg.weight_dtype == CSM_DTYPE_FP8 ? 1 : (e->cfg.weight_dtype == CSM_DTYPE_BF16 ? 2 : 4); }
@@ -396,7 +396,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     HIPCK(hipMemsetAsync(e->pl_act, 0, G * 3 * 16 * Fm * sizeof(bf16_t), e->stream));
     HIPCK(hipMemsetAsync(e->pl_ss, 0, G * 16 * PL_SS_LD * sizeof(float), e->stream));
   }
-  e->g16_slab_floats = (size_t)1 << 20;
+  e->g16_slab_floats = (size_t)1 << 23;   // split-K slabs: panels x K splits x batch tiles x 256 floats (backbone gate/up at 128 rows: 4 M floats)
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
   HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
 
@@ -640,7 +640,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     const auto tl = e->tiled.find(a.W);
     a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
     if (left > 16 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes (33..64 with rows64): one launch, weights streamed once
-      const int cap = (e->rows64 && m0 % 64 == 0 && left > 32) ? 64 : 32;
+      const int cap = (e->rows64 && m0 % 128 == 0 && left > 64) ? 128 : ((e->rows64 && m0 % 64 == 0 && left > 32) ? 64 : 32);
       const int m = left < cap ? left : cap;
       slice(m);
       const int r = launch_gemm32(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,

@@ -12,7 +12,7 @@
 // MT = 16-row batch tiles per weight fragment: 2 (17..32 rows) or, round 3, 4 (33..64 rows: one launch and ONE pass over the
 // weights for a 64-row batch instead of two 32-row launches -- B = 64 is launch-bound like every other batch size, so halving
 // its launches is what counts).  With four tiles the B operands of tile mt+1 are requested while tile mt multiplies (two
-// register sets) instead of all up front.
+// register sets) instead of all up front.  Round 4: MT = 8 (65..128 rows: BASELINE configs[3]'s 128-row strong leg in ONE engine pass).
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   constexpr int U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   const int m = lane & 15, g = lane >> 4;
   const int chunk = (int)blockIdx.y * NW + wave;
   constexpr bool QUAD = (EPI == EPI_RESID || EPI == EPI_SWIGLU);
-  static_assert(!QUAD || U * 64 <= 64 * NW, "one quad per thread");
+  constexpr int NQE = (U * 64 + 64 * NW - 1) / (64 * NW);   // epilogue quads per thread (2 with eight batch tiles x two weight tiles)
   constexpr int NE = (U * 256 + 64 * NW - 1) / (64 * NW);
 
   // ---- EPI_QKV epilogue inputs first (dependent chain: position -> cos/sin) -------------------------------
@@ -82,13 +82,18 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
   }
   // residual values (and the consumer's norm weight for the output planes): requested last, consumed last
-  f32x4 rq = (f32x4)(0.f), lq = (f32x4)(1.f);
-  if (EPI == EPI_RESID && tid < U * 64) {
-    const int u = tid >> 6, t = u / MT, mt = u - t * MT, l = tid & 63, mm = mt * 16 + (l & 15);
-    const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
-    if (mm < M && n0 < a.N) {
-      rq = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
-      if (a.oplanes && a.oln) lq = *reinterpret_cast<const f32x4*>(a.oln + n0);
+  f32x4 rq[NQE], lq[NQE];
+#pragma unroll
+  for (int e = 0; e < NQE; ++e) {
+    rq[e] = (f32x4)(0.f); lq[e] = (f32x4)(1.f);
+    const int q = tid + e * 64 * NW;
+    if (EPI == EPI_RESID && q < U * 64) {
+      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = mt * 16 + (l & 15);
+      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      if (mm < M && n0 < a.N) {
+        rq[e] = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
+        if (a.oplanes && a.oln) lq[e] = *reinterpret_cast<const f32x4*>(a.oln + n0);
+      }
     }
   }
   // RMS scale of the rows of batch tile mt = wave (waves 0 and 1) from the producer's per-tile sums of squares
@@ -204,8 +209,11 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
 
   // ---- epilogues ------------------------------------------------------------------------------------------
   if (QUAD) {
-    if (tid < U * 64) {
-      const int u = tid >> 6, t = u / MT, mt = u - t * MT, l = tid & 63, mm = mt * 16 + (l & 15);
+#pragma unroll
+    for (int e = 0; e < NQE; ++e) {
+      const int q = tid + e * 64 * NW;
+      if (q >= U * 64) continue;
+      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = mt * 16 + (l & 15);
       const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         f32x4 pv = *reinterpret_cast<const f32x4*>(panel + u * 256 + l * 4);
@@ -216,11 +224,11 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
         }
         pv[0] *= rs; pv[1] *= rs; pv[2] *= rs; pv[3] *= rs;
         if (EPI == EPI_RESID) {
-          const f32x4 xn = rq + pv;
+          const f32x4 xn = rq[e] + pv;
           *reinterpret_cast<f32x4*>(a.out + (size_t)mm * a.ldo + n0) = xn;
           if (a.oplanes) {
             f32x4 xt;
-            xt[0] = xn[0] * lq[0]; xt[1] = xn[1] * lq[1]; xt[2] = xn[2] * lq[2]; xt[3] = xn[3] * lq[3];
+            xt[0] = xn[0] * lq[e][0]; xt[1] = xn[1] * lq[e][1]; xt[2] = xn[2] * lq[e][2]; xt[3] = xn[3] * lq[e][3];
             const size_t ps = (size_t)a.N * 16;
             store_planes4(a.oplanes + (size_t)mt * 3 * ps, ps, n0, l & 15, xt, one);
             if (a.oss) red[u * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);

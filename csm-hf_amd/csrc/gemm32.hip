@@ -31,6 +31,12 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
 template <typename WT, typename KT, int PRO, int EPI, int PT>
 static int launch_nw32(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
   if (nw != 8) return -2;
+  if (M > 64) {   // 65..128 rows (round 4): eight batch tiles per weight fragment -- a 128-row batch streams the weights ONCE.  One quad per
+    // thread: one weight tile per panel, except the QKV panels that pair the two RoPE halves of a head (element epilogue)
+    // Two weight tiles per panel wherever the launch asked for at least two (the activation planes of a batch tile are loaded once
+    // per PANEL: one-tile panels moved twice the plane bytes of two 64-row passes, 17.1 ms per 128-row step); 144 KiB of LDS
+    return launch_g32<WT, KT, PRO, EPI, 8, (PT >= 2 ? 2 : 1), 8>(st, M, KB, a, slabs, sf, tk, nt);
+  }
   if (M > 32) {   // 33..64 rows: four batch tiles per weight fragment (panels of at most two weight tiles: LDS, one quad per thread)
     if (PT > 2) return -2;
     return launch_g32<WT, KT, PRO, EPI, 8, (PT > 2 ? 2 : PT), 4>(st, M, KB, a, slabs, sf, tk, nt);
@@ -70,7 +76,7 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
 
 int launch_gemm32(hipStream_t st, int wdtype, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                   size_t slab_floats, int* tickets, int n_tickets) {
-  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 64 || !a.xplanes || !a.Wt) return -2;
+  if ((wdtype != 1 && wdtype != 2) || M < 17 || M > 128 || !a.xplanes || !a.Wt) return -2;
   if (wdtype == 2) return launch_gemm32_t<fp8_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
   return launch_gemm32_t<bf16_t>(st, kvdtype, M, pro, epi, a, slabs, slab_floats, tickets, n_tickets);
 }
@@ -90,11 +96,12 @@ int gemm32_configure_all() {
         for (int K : {1024, 8192}) {   // KB == 1 and the K-split panel choice of the residual launches
           if (K == 8192 && c[0] == PRO_NORM) continue;
           a.K = K;
-          for (int one = 0; one < 2; ++one) {
-            a.pl1 = one;
-            const int r = launch_gemm32(nullptr, wd, kd, 64, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
-            if (r != 0 && r != -2) return r;
-          }
+          for (int one = 0; one < 2; ++one)
+            for (int rows : {64, 128}) {
+              a.pl1 = one;
+              const int r = launch_gemm32(nullptr, wd, kd, rows, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
+              if (r != 0 && r != -2) return r;
+            }
         }
   return 0;
 }

@@ -11,7 +11,7 @@
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
   if (a.nsplit < 1) return -1;
-  if (a.oplanes && rows > 64) return -1;
+  if (a.oplanes && rows > 128) return -1;
   const int G = a.n_q / a.n_kv;
   const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
   const int bd = a.one_wave ? 64 : 256;

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     for (int k = tid * 4; k < a.Hd; k += 1024) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + k);
       *reinterpret_cast<f32x4*>(dst + k) = v;
-      if (a.oplanes && row < 64) {
+      if (a.oplanes && row < 128) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(a.oln + k);
         f32x4 t;
         t[0] = v[0] * w[0]; t[1] = v[1] * w[1]; t[2] = v[2] * w[2]; t[3] = v[3] * w[3];
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
       }
     }
-    if (a.oplanes && row < 64) {   // block-uniform
+    if (a.oplanes && row < 128) {   // block-uniform
       sq = wave_sum(sq);
       __syncthreads();
       if ((tid & 63) == 0) s_val[tid >> 6] = sq;

@@ -37,7 +37,7 @@ def gather_frames(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
     return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], dim=0)
 
 
-MAX_ROWS_PER_PASS = 64   # rows one engine pass keeps on the matrix-core activation-plane path (csrc/engine.hip: PL_GROUPS)
+MAX_ROWS_PER_PASS = 128   # rows one engine pass keeps on the matrix-core activation-plane path (csrc/engine.hip: PL_GROUPS)
 
 
 def _generate_rows(model, ids, mask, row0: int, kw) -> torch.Tensor:

@@ -501,12 +501,13 @@ def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
 
 
 def test_csm1b_64_row_launch_is_bitwise_two_32_row_launches(csm1b_bf16):
-    """33..64 rows on gemm32_kernel<..., MT = 4> (one launch, one pass over the weights) against two 32-row launches
-    (`rows64 = 0`): every accumulator sums its products in the same order in both forms, so the generated frames are equal
-    bit for bit -- 48 rows (a partial fourth tile) and 64."""
+    """33..64 rows on gemm32_kernel<..., MT = 4> and, round 4, 65..128 rows on MT = 8 (one launch, ONE pass over the weights:
+    VERDICT r3 item 5) against 32-row launches (`rows64 = 0`): every accumulator sums its products in the same order in both
+    forms, so the generated frames are equal bit for bit -- 48 rows (a partial fourth tile), 64, 100 (a partial seventh tile),
+    128.  Both arithmetic classes (exact planes / decode_precision bf16)."""
     m = csm1b_bf16
     cfg = m.config
-    for B in (48, 64):
+    for B in (48, 64, 100, 128):
         ids, mask = synth_context(cfg, B, 12, 20, seed=47)
         outs = []
         for r64 in (1, 0):
@@ -516,6 +517,19 @@ def test_csm1b_64_row_launch_is_bitwise_two_32_row_launches(csm1b_bf16):
             outs.append(m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu())
         m._engine.set_option("rows64", 1)
         assert torch.equal(outs[0], outs[1]), B
+        if B in (64, 128):
+            try:
+                m.decode_precision = "bf16"
+                b16 = []
+                for r64 in (1, 0):
+                    eng = m._ensure_engine(B, 64, 8, B * 32)
+                    eng.set_option("rows64", r64)
+                    b16.append(m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu())
+                assert torch.equal(b16[0], b16[1]), (B, "bf16")
+            finally:
+                m._engine.set_option("rows64", 1)
+                m.decode_precision = "exact"
+    m._drop_engine()
 
 
 def test_csm1b_config3_batch16_voiceclone_rows_vs_reference(gold, csm1b_bf16):
