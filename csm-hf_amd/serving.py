@@ -35,7 +35,7 @@ class ContinuousBatcher:
     def __init__(self, model, batch_size: int, temperature: float = 1.0, topk: int = 50, max_new_frames: int = 100,
                  check_every: int = 8, seed: Optional[int] = None, initial_frames: Optional[int] = None, audio_decoder=None,
                  max_shift: int = 1024, max_total_len: int = 16384, max_shifts_per_batch: int = 8, join_budget_rows: int = 4096,
-                 frame_seconds: float = 0.08, clock=None):
+                 frame_seconds: float = 0.08, clock=None, clamp_audio_ids: bool = False):
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
         self.model = model
@@ -51,6 +51,9 @@ class ContinuousBatcher:
         # (csm_mimi_streams_*), a row's stream is restarted when a new utterance takes the row over; `self.audio` then holds
         # {request id: waveform [n * samples_per_frame]} (CPU) next to the frames `run()` returns
         self.audio_decoder = audio_decoder
+        # a trained model never emits ids >= the codec's codebook size (2048 of the 2051 vocabulary entries); random-weight
+        # benchmarks do: clamp_audio_ids=True folds them instead of raising (timing runs only)
+        self.clamp_audio_ids = bool(clamp_audio_ids)
         self.audio: Dict[int, torch.Tensor] = {}
         self.joint_joins = True        # several joins of one chunk through one slot prefill (csm_prefill_slots); False: one by one
         self.joined_together = 0       # ... how many utterances joined that way (statistics)
@@ -164,7 +167,7 @@ class ContinuousBatcher:
                 # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of
                 # idle / finished rows are decoded too and dropped; ids beyond the codec's codebook cannot come from a real model)
                 live = [b for b, r in enumerate(rows) if r is not None]
-                if live and int(toks_dev[live].max()) >= dec.cfg.codebook_size:
+                if live and not self.clamp_audio_ids and int(toks_dev[live].max()) >= dec.cfg.codebook_size:
                     raise ValueError(f"generated token id {int(toks_dev[live].max())} is outside the codec's codebook ({dec.cfg.codebook_size})")
                 codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k] (the clamp only touches idle rows)
                 step = max(1, dec.max_frames // B)

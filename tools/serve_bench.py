@@ -37,7 +37,8 @@ if AUDIO:
     mc = MimiDecodeConfig()
     dec = MimiDecoder(mc, synth_mimi_state_dict(mc, seed=0, device=dev), dev, max_frames=max(64, 8 * B))   # one group call per chunk of 8 frames
 for label in (("warm-up", "continuous", "continuous+audio") if AUDIO else ("warm-up", "continuous")):
-    cb = ContinuousBatcher(m, batch_size=B, topk=1, check_every=8, audio_decoder=dec if label == "continuous+audio" else None)
+    cb = ContinuousBatcher(m, batch_size=B, topk=1, check_every=8, audio_decoder=dec if label == "continuous+audio" else None,
+                           clamp_audio_ids=True)     # synthetic weights emit ids 2048-2050 too
     for ids, mask, budget in (reqs[:B] if label == "warm-up" else reqs):
         cb.submit(ids, mask, max_new_frames=budget if label != "warm-up" else 16)
     torch.cuda.synchronize()

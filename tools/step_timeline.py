@@ -13,7 +13,9 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 gy = "grid_y" if "grid_y" in cols else "0"
 wg = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else "0")
 ks = list(cur.execute(f"select start, end, name, grid_x, {gy}, {wg} from kernels order by start"))
-idx = [i for i, k in enumerate(ks) if "embed_sum" in k[2] and k[3] <= 4096]
+# the decode step's embedding launch = the smallest embed_sum grid of the trace (prefill launches cover whole contexts)
+es = [k[3] * max(1, k[4]) for k in ks if "embed_sum" in k[2]]
+idx = [i for i, k in enumerate(ks) if "embed_sum" in k[2] and k[3] * max(1, k[4]) == min(es)]
 if len(idx) < 3:
     sys.exit("no frame-steps found")
 a, b = idx[-3], idx[-2]
