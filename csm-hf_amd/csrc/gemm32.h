@@ -12,7 +12,8 @@
 // MT = 16-row batch tiles per weight fragment: 2 (17..32 rows) or, round 3, 4 (33..64 rows: one launch and ONE pass over the
 // weights for a 64-row batch instead of two 32-row launches -- B = 64 is launch-bound like every other batch size, so halving
 // its launches is what counts).  With four tiles the B operands of tile mt+1 are requested while tile mt multiplies (two
-// register sets) instead of all up front.  Round 4: MT = 8 (65..128 rows: BASELINE configs[3]'s 128-row strong leg in ONE engine pass).
+// register sets) instead of all up front.  Round 4: up to 128 rows per launch (BASELINE configs[3]'s 128-row strong leg in ONE
+// engine pass): the batch tiles beyond MT go to further workgroups of the panel (blockIdx.z), shapes in gemm32.hip.
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
   constexpr int U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
@@ -25,6 +26,10 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   const int K = a.K;
   const int m = lane & 15, g = lane >> 4;
   const int chunk = (int)blockIdx.y * NW + wave;
+  // batch rows split across workgroups (blockIdx.z): this workgroup owns the batch tiles mt0 .. mt0 + MT - 1 of the launch.  The
+  // small launches of a 128-row step (QKV: 48 panels) otherwise leave most of the chip idle while every wave walks 786 KB of planes
+  const int mt0 = (int)blockIdx.z * MT;
+  const int bx = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;   // slab / ticket slot of this (panel, row group)
   constexpr bool QUAD = (EPI == EPI_RESID || EPI == EPI_SWIGLU);
   constexpr int NQE = (U * 64 + 64 * NW - 1) / (64 * NW);   // epilogue quads per thread (2 with eight batch tiles x two weight tiles)
   constexpr int NE = (U * 256 + 64 * NW - 1) / (64 * NW);
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       const int i = tid + e * 64 * NW;
       if (i < U * 256) {
         const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
-        const int mm = mt * 16 + (l & 15), r = (l >> 4) * 4 + reg;
+        const int mm = (mt0 + mt) * 16 + (l & 15), r = (l >> 4) * 4 + reg;
         const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
         if (mm < M && n < a.N) {
           ppos[e] = row_position(a.row_pos, mm, a.pos_ptr, a.pos_const);
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   const size_t ps = (size_t)K * 16;
   constexpr bool one = ONE;   // decode_precision = bf16 (GemvArgs::pl1): one nearest-even activation plane, one MFMA per weight fragment (gemm16.h)
   auto load_planes = [&](int mt, int buf) {
-    const bf16_t* pp = a.xplanes + (size_t)mt * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
+    const bf16_t* pp = a.xplanes + (size_t)(mt0 + mt) * 3 * ps + ((size_t)chunk * 256 + lane) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       xh[buf][j] = *reinterpret_cast<const bf16x8*>(pp + j * 512);
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     rq[e] = (f32x4)(0.f); lq[e] = (f32x4)(1.f);
     const int q = tid + e * 64 * NW;
     if (EPI == EPI_RESID && q < U * 64) {
-      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = mt * 16 + (l & 15);
+      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = (mt0 + mt) * 16 + (l & 15);
       const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         rq[e] = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   }
   // RMS scale of the rows of batch tile mt = wave (waves 0 and 1) from the producer's per-tile sums of squares
   if (PRO == PRO_NORM && wave < MT) {
-    const float* sp = a.xss + (size_t)(wave * 16 + m) * a.xss_ld;
+    const float* sp = a.xss + (size_t)((mt0 + wave) * 16 + m) * a.xss_ld;
     f32x4 pv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   }
   if (KB > 1) {   // split-K across workgroups: 16-byte sc1 slab stores + ticket, the last arriver combines with sc1 loads (gemm16.h)
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
-    const unsigned slab_off = (unsigned)(((size_t)blockIdx.x * KB + blockIdx.y) * (U * 256) * sizeof(float));
+    const unsigned slab_off = (unsigned)(((size_t)bx * KB + blockIdx.y) * (U * 256) * sizeof(float));
 #pragma unroll
     for (int e = 0; e < NQ; ++e) {
       const int q = tid + e * 64 * NW;
@@ -185,14 +190,14 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int tk = __hip_atomic_fetch_add(tickets + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = tk == KB - 1;
-      if (last) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last) __hip_atomic_store(tickets + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *flag = last;
     }
     __syncthreads();
     if (!*flag) return;
-    const unsigned base_off = (unsigned)((size_t)blockIdx.x * KB * (U * 256) * sizeof(float));
+    const unsigned base_off = (unsigned)((size_t)bx * KB * (U * 256) * sizeof(float));
     for (int q = tid; q < U * 64; q += 64 * NW) {
       f32x4 v[16];
 #pragma unroll
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     for (int e = 0; e < NQE; ++e) {
       const int q = tid + e * 64 * NW;
       if (q >= U * 64) continue;
-      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = mt * 16 + (l & 15);
+      const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = (mt0 + mt) * 16 + (l & 15);
       const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         f32x4 pv = *reinterpret_cast<const f32x4*>(panel + u * 256 + l * 4);
-        const float rs = (PRO == PRO_NORM) ? stat[mm] : 1.f;
+        const float rs = (PRO == PRO_NORM) ? stat[mt * 16 + (l & 15)] : 1.f;
         if (a.wscale) {
           const f32x4 ws = *reinterpret_cast<const f32x4*>(a.wscale + n0);
           pv[0] *= ws[0]; pv[1] *= ws[1]; pv[2] *= ws[2]; pv[3] *= ws[3];
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
             f32x4 xt;
             xt[0] = xn[0] * lq[e][0]; xt[1] = xn[1] * lq[e][1]; xt[2] = xn[2] * lq[e][2]; xt[3] = xn[3] * lq[e][3];
             const size_t ps = (size_t)a.N * 16;
-            store_planes4(a.oplanes + (size_t)mt * 3 * ps, ps, n0, l & 15, xt, one);
+            store_planes4(a.oplanes + (size_t)(mt0 + mt) * 3 * ps, ps, n0, l & 15, xt, one);
             if (a.oss) red[u * 64 + l] = (xn[0] * xn[0] + xn[1] * xn[1]) + (xn[2] * xn[2] + xn[3] * xn[3]);
           }
         } else {   // SwiGLU: (gate, up) pairs
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
           const float h1 = (pv[2] / (1.f + __expf(-pv[2]))) * pv[3];
           if (a.oplanes) {
             const size_t ps = (size_t)(a.N >> 1) * 16;
-            store_planes2(a.oplanes + (size_t)mt * 3 * ps, ps, n0 >> 1, l & 15, h0, h1, one);
+            store_planes2(a.oplanes + (size_t)(mt0 + mt) * 3 * ps, ps, n0 >> 1, l & 15, h0, h1, one);
           } else {
             *reinterpret_cast<f32x2*>(a.out + (size_t)mm * a.ldo + (n0 >> 1)) = f32x2{h0, h1};
           }
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     if (EPI == EPI_RESID && a.oplanes && a.oss) {   // per-tile sums of x_new^2 for the consumer's RMS scale
       __syncthreads();
       if (tid < U * 16) {
-        const int u = tid >> 4, t = u / MT, mt = u - t * MT, mm = mt * 16 + (tid & 15);
+        const int u = tid >> 4, t = u / MT, mt = u - t * MT, mm = (mt0 + mt) * 16 + (tid & 15);
         const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
         if (mm < M && n0 < a.N) {
           const int c = tid & 15;
@@ -262,11 +267,11 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       const int i = tid + e * 64 * NW;
       if (i >= U * 256) continue;
       const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
-      const int mm = mt * 16 + (l & 15), r = (l >> 4) * 4 + reg;
+      const int mm = (mt0 + mt) * 16 + (l & 15), r = (l >> 4) * 4 + reg;
       if (mm >= M) continue;
       const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
       if (n >= a.N) continue;
-      const float rs = (PRO == PRO_NORM) ? stat[mm] : 1.f;
+      const float rs = (PRO == PRO_NORM) ? stat[mt * 16 + (l & 15)] : 1.f;
       const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f) * rs;
       if (EPI == EPI_STORE) {
         a.out[(size_t)mm * a.ldo + n] = v;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       }
     }
   }
-  if (a.bump_a && blockIdx.x == 0 && tid == 0) {
+  if (a.bump_a && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }

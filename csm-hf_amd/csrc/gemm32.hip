@@ -5,11 +5,12 @@ template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT, bo
 static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* slabs, size_t slab_floats, int* tickets,
                       int n_tickets) {
   if (!ONE && a.pl1) return launch_g32<WT, KT, PRO, EPI, NW, PT, MT, true>(st, M, KB, a, slabs, slab_floats, tickets, n_tickets);
+  const int Z = ((M + 15) / 16 + MT - 1) / MT;   // row groups of MT batch tiles, one workgroup each per panel (blockIdx.z)
   constexpr int U = PT * MT;
   int gx;
   if (EPI == EPI_QKV) gx = (a.n_q + 2 * a.n_kv) * ((a.hd >> 1) / 16);
   else gx = ((a.N + 15) / 16 + PT - 1) / PT;
-  if (KB > 1 && ((size_t)gx * KB * U * 256 > slab_floats || gx > n_tickets)) return -2;
+  if (KB > 1 && ((size_t)gx * Z * KB * U * 256 > slab_floats || gx * Z > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * U * 256 + U * 256 + 16 + 16 * MT) * sizeof(float);
   auto fn = gemm32_kernel<WT, KT, PRO, EPI, NW, PT, MT, ONE>;
   if (lds > 64 * 1024) {   // four batch tiles x two weight tiles: 72 KiB -- raise the dynamic-LDS limit once per DEVICE
@@ -24,53 +25,61 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
     }
   }
   if (a.configure_only) return 0;
-  hipLaunchKernelGGL(fn, dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  hipLaunchKernelGGL(fn, dim3(gx, KB, Z), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 
-template <typename WT, typename KT, int PRO, int EPI, int PT>
-static int launch_nw32(hipStream_t st, int M, int nw, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
-  if (nw != 8) return -2;
-  if (M > 64) {   // 65..128 rows (round 4): eight batch tiles per weight fragment -- a 128-row batch streams the weights ONCE.  One quad per
-    // thread: one weight tile per panel, except the QKV panels that pair the two RoPE halves of a head (element epilogue)
-    // Two weight tiles per panel wherever the launch asked for at least two (the activation planes of a batch tile are loaded once
-    // per PANEL: one-tile panels moved twice the plane bytes of two 64-row passes, 17.1 ms per 128-row step); 144 KiB of LDS
-    return launch_g32<WT, KT, PRO, EPI, 8, (PT >= 2 ? 2 : 1), 8>(st, M, KB, a, slabs, sf, tk, nt);
-  }
-  if (M > 32) {   // 33..64 rows: four batch tiles per weight fragment (panels of at most two weight tiles: LDS, one quad per thread)
-    if (PT > 2) return -2;
-    return launch_g32<WT, KT, PRO, EPI, 8, (PT > 2 ? 2 : PT), 4>(st, M, KB, a, slabs, sf, tk, nt);
-  }
-  return launch_g32<WT, KT, PRO, EPI, 8, PT, 2>(st, M, KB, a, slabs, sf, tk, nt);
+// (weight tiles per panel PT, batch tiles per workgroup MT) -> instantiation.  U = PT * MT accumulator tiles <= 16 (LDS: 9 KiB each).
+// Rows beyond MT tiles go to further workgroups of the same panel (blockIdx.z): they re-read the panel's weights from the caches.
+// With many rows the activation planes, not the weights, are the larger operand (6 bytes per row and k against 2 per weight
+// row and k), so tall panels (PT = 4) with few batch tiles move the fewest bytes.
+template <typename WT, typename KT, int PRO, int EPI>
+static int launch_sel(hipStream_t st, int M, int pt, int mt, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
+#define G32_CASE(P, T) if (pt == P && mt == T) return launch_g32<WT, KT, PRO, EPI, 8, P, T>(st, M, KB, a, slabs, sf, tk, nt)
+  G32_CASE(2, 2);
+  if constexpr (EPI == EPI_SWIGLU) { G32_CASE(4, 4); }
+  if constexpr (EPI == EPI_RESID) { G32_CASE(1, 2); G32_CASE(4, 2); G32_CASE(2, 4); G32_CASE(4, 4); }
+  if constexpr (EPI == EPI_STORE) { G32_CASE(1, 2); }
+#undef G32_CASE
+  return -2;
 }
 
 template <typename WT>
 static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi, const GemvArgs& a, float* slabs,
                            size_t slab_floats, int* tickets, int n_tickets) {
   if (pro != PRO_PLAIN && pro != PRO_NORM) return -2;
-  if (a.K % 1024 != 0) return -2;                          // 8 or 16 waves, one 128-wide chunk each
+  if (a.K % 1024 != 0) return -2;                          // 8 waves, one 128-wide chunk each
   if ((epi == EPI_RESID || epi == EPI_SWIGLU) && (a.N % 16 != 0 || a.ldo % 4 != 0)) return -2;
   // 8 waves per workgroup always (two batch tiles need ~170 VGPRs: a 16-wave workgroup would spill), one 128-wide
   // chunk per wave, the rest of K split across workgroups -- allowed for the normed launches too, because on planes the
   // RMS scale is applied by the (last-arriver) epilogue
   const int nchunks = a.K / 128;
-  const int nw = 8, KB = nchunks / 8;
+  const int KB = nchunks / 8;
   if (nchunks % 8 || KB > 16) return -2;
+  // shapes (measured at 64 and 128 rows, profiles/r04_g32_shapes.txt; frames bitwise the same for every shape):
+  //   <= 32 rows: one workgroup per panel walks both batch tiles; gate/up and QKV panels of 32 weight rows, the residual launches 16
+  //               (64 when that leaves >= 128 workgroups per K split), the heads 16
+  //   > 32 rows:  QKV, o_proj and the heads keep two batch tiles per workgroup and spread the rows over blockIdx.z (a 128-row QKV
+  //               launch has 48 panels: one workgroup per panel left 200 CUs idle while each wave walked 786 KB of planes);
+  //               gate/up and the K-split down_proj take four batch tiles on 64-row panels (32-row panels for down_proj at <= 64 rows)
+  const int ntiles = (a.N + 15) / 16;
+  int pt = 2, mt = 2;
+  if (M <= 32) {
+    if (epi == EPI_RESID) pt = (KB > 1 && ntiles >= 128) ? 4 : 1;
+    if (epi == EPI_STORE) pt = 1;
+  } else if (epi == EPI_SWIGLU) {
+    pt = 4; mt = 4;
+  } else if (epi == EPI_RESID && a.K > 2048) {
+    pt = M > 64 ? 4 : 2; mt = 4;
+  }
   if (epi == EPI_QKV) {
     if (pro != PRO_NORM || (a.hd != 64 && a.hd != 128)) return -2;
-    if (kvdtype == 1) return launch_nw32<WT, bf16_t, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-    return launch_nw32<WT, float, PRO_NORM, EPI_QKV, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+    if (kvdtype == 1) return launch_sel<WT, bf16_t, PRO_NORM, EPI_QKV>(st, M, 2, 2, KB, a, slabs, slab_floats, tickets, n_tickets);
+    return launch_sel<WT, float, PRO_NORM, EPI_QKV>(st, M, 2, 2, KB, a, slabs, slab_floats, tickets, n_tickets);
   }
-  // panels: gate/up 32 rows (as on planes at M <= 16), the residual launches 16 rows (64 when that leaves >= 128
-  // workgroups per K split), the heads 16 rows
-  const int ntiles = (a.N + 15) / 16;
-  if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_nw32<WT, float, PRO_NORM, EPI_SWIGLU, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-  if (pro == PRO_PLAIN && epi == EPI_RESID) {
-    if (KB > 1 && ntiles >= 128 && M <= 32) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 4>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-    if (KB > 1 && ntiles >= 128) return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 2>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-    return launch_nw32<WT, float, PRO_PLAIN, EPI_RESID, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
-  }
-  if (pro == PRO_NORM && epi == EPI_STORE) return launch_nw32<WT, float, PRO_NORM, EPI_STORE, 1>(st, M, nw, KB, a, slabs, slab_floats, tickets, n_tickets);
+  if (pro == PRO_NORM && epi == EPI_SWIGLU) return launch_sel<WT, float, PRO_NORM, EPI_SWIGLU>(st, M, pt, mt, KB, a, slabs, slab_floats, tickets, n_tickets);
+  if (pro == PRO_PLAIN && epi == EPI_RESID) return launch_sel<WT, float, PRO_PLAIN, EPI_RESID>(st, M, pt, mt, KB, a, slabs, slab_floats, tickets, n_tickets);
+  if (pro == PRO_NORM && epi == EPI_STORE) return launch_sel<WT, float, PRO_NORM, EPI_STORE>(st, M, pt, mt, KB, a, slabs, slab_floats, tickets, n_tickets);
   return -2;
 }
 
