@@ -21,6 +21,7 @@ struct PrefillAttnArgs {
   size_t plane_stride;
   const int* seq_slot;  // nullable: sequence b of this launch lives in cache slot seq_slot[b] (continuous batching: several rows of a
                         // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
+  int map;              // attn_prefill_bf16_kernel: query-tile order (see the kernel)
   uint8_t* oq;          // nullable (attn_prefill_bf16_kernel only): output as MX-fp8 rows [B*S][n_q*64] e4m3 + os [B*S][n_q*2] E8M0 scales
   uint8_t* os;          // (the OCP recipe of mx_quant_rows_kernel, gemm_mx.h; a 32-block = half a head = the lane pair of a query row) instead of `out`
 };
@@ -217,25 +218,33 @@ __device__ __forceinline__ float ap_max3(float a, float b, float c) {   // no Na
   return r;
 }
 
-// NG = key groups per workgroup (round 3, A/B only: measured SLOWER, see attn_prefill.hip).  The idea: the last query tile walks
-// S / 64 key tiles one after the other while the workgroups of the early tiles have long finished (all of them are resident at
-// once), so with NG = 2 a workgroup is two 4-wave groups that take alternate key tiles (group g: tiles g, g + 2, ...) with their own
-// LDS stage and their own running statistics, and group 1 hands (o, m, l) to group 0 through LDS at the end: the chain is
-// half as long, nothing crosses workgroups, no second launch.  The merge is the usual two-part softmax combination.
-// OCC = waves per SIMD the register allocation aims at (A/B: 4 = two 8-wave workgroups per CU at <= 128 VGPRs, which spills the
-// fp32 K/V stage; 1 = unconstrained)
-template <typename KT, int NG = 1, int OCC = 1>
-__global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
+// PD = K / V tiles in flight in registers behind the tile being computed (round 4).  With one (rounds 2-3) an iteration of the
+// key loop could not be shorter than a global load's round trip: the last query tile of a 2 048-frame context walks 32 key
+// tiles one after the other.
+// -- measured in round 4 (profiles/r04_attn_prefill_knockout.txt): PD = 2 / 3 change nothing, the default stays 1.
+// VAR: TIMING-ONLY knock-outs (wrong results; not instantiated in the library): 1 = no exp2, 2 = no K / V loads after the
+// first tile, 4 = no barriers, 8 = no MFMAs, 16 = no LDS staging writes
+// (two key groups per workgroup -- the longest workgroup's chain halved, merged through LDS -- measured slower in round 3 and is gone)
+template <typename KT, int PD = 1, int VAR = 0>
+__global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
   constexpr int HD = 64, LDK = 72;   // 144-byte LDS rows: 16-byte reads of 32 consecutive rows cover all banks evenly
-  __shared__ __attribute__((aligned(16))) bf16_t kv_all[2 * NG * 64 * LDK];
-  bf16_t* const Ks_all = kv_all;                      // [group][key][d]
-  bf16_t* const Vt_all = kv_all + NG * 64 * LDK;      // [group][d][ap_vperm(key)]
-  const int grp = NG > 1 ? (int)threadIdx.x >> 8 : 0;
-  bf16_t* const Ks = Ks_all + grp * 64 * LDK;
-  bf16_t* const Vt = Vt_all + grp * 64 * LDK;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) bf16_t kv_all[2 * 64 * LDK];
+  bf16_t* const Ks = kv_all;                  // [key][d]
+  bf16_t* const Vt = kv_all + 64 * LDK;       // [d][ap_vperm(key)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = a.n_q / a.n_kv;
-  const int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
+  // query tile of this workgroup.  Every workgroup of a 2 048-frame context is resident at once (two per CU), so nothing balances
+  // itself: a CU that holds two of the latest tiles (32 key tiles each) runs twice as long as the average one (MAP 0, rounds 2-3).
+  // MAP 1: every other wave of 256 workgroups walks the tiles in ascending order, so that the two workgroups of a CU (dispatch
+  // slots n and n + 256) hold a long and a short tile: 2 048 frames 5.69 -> 5.51 ms (bf16), 4.36 -> 4.17 ms (mxfp8).  MAP 2:
+  // neighbours in dispatch order paired instead: no change (the dispatcher is round-robin over the CUs).
+  int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
+  if (a.map == 1) {
+    const int n = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((n >> 8) & 1) qt = blockIdx.x;
+  } else if (a.map == 2) {
+    qt = (blockIdx.x & 1) ? (int)(blockIdx.x >> 1) : (int)(gridDim.x - 1 - (blockIdx.x >> 1));
+  }
   const int j = blockIdx.y, b = blockIdx.z;
   const int s0 = qt * 32;
   const int li = lane & 31, lh = lane >> 5;
@@ -271,40 +280,42 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
   float m_run = -INFINITY, l_run = 0.f;
   constexpr float L2E = 1.4426950408889634f, SLACK = 8.f;
 
-  ApStage<KT> st;
-  int kt0 = (kv_lo & ~63) + 64 * grp;
-  if (kt0 <= kmax) st.load(kc, vc, a.lmax, kt0, tid);
+  ApStage<KT> st[PD];
+  int kt0 = kv_lo & ~63;
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (kt0 + 64 * p <= kmax) st[p].load(kc, vc, a.lmax, kt0 + 64 * p, tid);
   // where this thread's V share lands: rows d = 16*wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
   const int vkey = tid & 63;
   uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
   // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
   const uint32_t vsel = (vkey & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selector over {theirs, mine}
-  // (the loop bound is the same for both groups -- every thread meets every barrier; a group whose tile lies past kmax idles)
-  for (int base = kv_lo & ~63; base <= kmax; base += 64 * NG, kt0 += 64 * NG) {
-    const bool live = NG == 1 || kt0 <= kmax;
+  auto sync = [&]() { if (!(VAR & 4)) __syncthreads(); };
+  auto tile = [&](ApStage<KT>& sg) __attribute__((always_inline)) {
     // ---- registers -> LDS ------------------------------------------------------------------------------------
-    if (live) {
+    if (!(VAR & 16)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * 256;
-        *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = st.kword(i);
+        *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = sg.kword(i);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const uint32_t mine = st.vpair(q);
+        const uint32_t mine = sg.vpair(q);
         const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
         vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
       }
     }
-    __syncthreads();
-    if (!live) { __syncthreads(); continue; }
-    if (kt0 + 64 * NG <= kmax) st.load(kc, vc, a.lmax, kt0 + 64 * NG, tid);   // next tile in flight behind this tile's math
+    sync();
+    // this stage's registers are free again: tile kt0 + 64 PD goes in flight behind the math of PD tiles
+    if (!(VAR & 2) && kt0 + 64 * PD <= kmax) sg.load(kc, vc, a.lmax, kt0 + 64 * PD, tid);
     // ---- S^T[key][row] = sum_d K[key][d] Q[row][d], two 32-key halves ----------------------------------------------
     f32x16 sc0 = (f32x16)(0.f), sc1 = (f32x16)(0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const ap_bf16x8 k0 = *reinterpret_cast<const ap_bf16x8*>(&Ks[li * LDK + 16 * t + 8 * lh]);
       const ap_bf16x8 k1 = *reinterpret_cast<const ap_bf16x8*>(&Ks[(32 + li) * LDK + 16 * t + 8 * lh]);
+      if (VAR & 8) { sc0[t] += (float)k0[0]; sc1[t] += (float)k1[0]; continue; }
       sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], sc0, 0, 0, 0);
       sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], sc1, 0, 0, 0);
     }
@@ -340,8 +351,10 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
       ap_f32x2 x0 = {sc0[r], sc0[r + 1]}, x1 = {sc1[r], sc1[r + 1]};
       x0 = x0 * l2e2 + nm2;
       x1 = x1 * l2e2 + nm2;
-      x0[0] = __builtin_amdgcn_exp2f(x0[0]); x0[1] = __builtin_amdgcn_exp2f(x0[1]);
-      x1[0] = __builtin_amdgcn_exp2f(x1[0]); x1[1] = __builtin_amdgcn_exp2f(x1[1]);
+      if (!(VAR & 1)) {
+        x0[0] = __builtin_amdgcn_exp2f(x0[0]); x0[1] = __builtin_amdgcn_exp2f(x0[1]);
+        x1[0] = __builtin_amdgcn_exp2f(x1[0]); x1[1] = __builtin_amdgcn_exp2f(x1[1]);
+      }
       sum2 += x0 + x1;
       sc0[r] = x0[0]; sc0[r + 1] = x0[1];
       sc1[r] = x1[0]; sc1[r + 1] = x1[1];
@@ -355,33 +368,18 @@ __global__ __launch_bounds__(256 * NG, OCC) void attn_prefill_bf16_kernel(Prefil
       const ap_bf16x8 pb = ap_pack8(sc[r0], sc[r0 + 1], sc[r0 + 2], sc[r0 + 3], sc[r0 + 4], sc[r0 + 5], sc[r0 + 6], sc[r0 + 7]);
       const ap_bf16x8 v0 = *reinterpret_cast<const ap_bf16x8*>(&Vt[li * LDK + (2 * u + lh) * 8]);
       const ap_bf16x8 v1 = *reinterpret_cast<const ap_bf16x8*>(&Vt[(32 + li) * LDK + (2 * u + lh) * 8]);
+      if (VAR & 8) { o0[u] += (float)v0[0] * (float)pb[0]; o1[u] += (float)v1[0] * (float)pb[1]; continue; }
       o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
     }
-    __syncthreads();   // the tile is rewritten at the top of the next iteration
-  }
-  if (NG > 1) {
-    // group 1 -> group 0: (o0, o1, m, l) of every lane through the (now free) K stage memory, lane-major (conflict-free)
-    float* xch = reinterpret_cast<float*>(kv_all);   // 4 waves x 34 rows x 64 lanes x 4 B = 34 816 B of the 36 864 B of both stages
-    static_assert(NG == 1 || (size_t)4 * 34 * 64 * sizeof(float) <= (size_t)2 * NG * 64 * LDK * sizeof(bf16_t), "exchange area");
-    float* mine_x = xch + (size_t)wave * 34 * 64 + lane;
-    if (grp == 1) {
+    sync();   // the tile is rewritten by the next one
+  };
+  while (kt0 <= kmax) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { mine_x[r * 64] = o0[r]; mine_x[(16 + r) * 64] = o1[r]; }
-      mine_x[32 * 64] = m_run;
-      mine_x[33 * 64] = l_run;
-    }
-    __syncthreads();
-    if (grp == 1) return;
-    const float m1 = mine_x[32 * 64], l1 = mine_x[33 * 64];
-    const float m = fmaxf(m_run, m1);
-    const float w0 = m_run > -INFINITY ? __builtin_amdgcn_exp2f(m_run - m) : 0.f;
-    const float w1 = m1 > -INFINITY ? __builtin_amdgcn_exp2f(m1 - m) : 0.f;
-    l_run = l_run * w0 + l1 * w1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] = o0[r] * w0 + mine_x[r * 64] * w1;
-      o1[r] = o1[r] * w0 + mine_x[(16 + r) * 64] * w1;
+    for (int p = 0; p < PD; ++p) {
+      if (kt0 > kmax) break;   // (uniform)
+      tile(st[p]);
+      kt0 += 64;
     }
   }
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;

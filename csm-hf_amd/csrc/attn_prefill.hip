@@ -4,7 +4,8 @@
 #define CSM_ATTN_PREFILL_KERNELS 1
 #include "attn_prefill.h"
 
-int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a, int bf16_math) {
+int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const PrefillAttnArgs& a0, int bf16_math) {
+  PrefillAttnArgs a = a0;
   if (hd != 64 || a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 4 || a.S < 1) return -2;
   const dim3 grid((a.S + 31) / 32, a.n_kv, B);
   if (bf16_math == 2) {   // exact on the bf16 pipe: K / V as three pieces in LDS (fp32 cache) or one (bf16 cache)
@@ -14,8 +15,9 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
     return (int)hipGetLastError();
   }
   if (bf16_math) {
-    // (two key groups per workgroup -- half the sequential key tiles of the longest workgroup -- measured SLOWER, 2048 frames
-    //  bf16 / mxfp8 5.91 / 4.72 -> 6.07 / 4.95 ms: the kernel is bound by its softmax VALU throughput; removed in round 4)
+    // (round 4, profiles/r04_attn_prefill_knockout.txt: two or three K / V tiles in flight instead of one change nothing; the
+    //  longest workgroup's chain of 32 key tiles sets the launch time at 2 048 frames)
+    a.map = 1;
     if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
