@@ -92,7 +92,7 @@ def test_generate_sharded_gloo(world, B):
 
 
 def test_explicit_noise_is_sliced_per_engine_pass():
-    """generate_sharded(noise=[n, B_total, 32, V]): every 64-row engine pass receives the draws of ITS rows (global row
+    """generate_sharded(noise=[n, B_total, 32, V]): every engine pass (MAX_ROWS_PER_PASS rows) receives the draws of ITS rows (global row
     index), not the full-batch tensor (which CSMModel._check_noise rejects on shape)."""
     seen = []
 
@@ -102,10 +102,11 @@ def test_explicit_noise_is_sliced_per_engine_pass():
             seen.append((self.row_offset, ids.shape[0], float(noise[0, 0, 0, 0]), float(noise[0, -1, 0, 0])))
             return super().generate(ids, mask, max_new_frames=max_new_frames, **kw)
 
-    B, n, V = 70, 2, 5
+    from csm_hf_amd.sharded import MAX_ROWS_PER_PASS as P
+    B, n, V = P + 6, 2, 5
     ids = torch.ones(B, 2, 33, dtype=torch.long)
     mask = torch.ones(B, 2, 33, dtype=torch.int32)
     noise = torch.arange(B, dtype=torch.float32)[None, :, None, None].expand(n, B, 32, V).contiguous()   # value = global row
     out = generate_sharded(NoiseModel(), ids, mask, max_new_frames=n, stop_on_all_zeros=False, noise=noise)
     assert out.shape[0] == B
-    assert seen == [(0, 64, 0.0, 63.0), (64, 6, 64.0, 69.0)]
+    assert seen == [(0, P, 0.0, float(P - 1)), (P, 6, float(P), float(P + 5))]
