@@ -34,6 +34,8 @@ struct AttnArgs {
   bf16_t* oplanes;  // nullable: the output also as MFMA B-operand planes for a batched o_proj (rows <= 16)
   int pl1;          // decode_precision = bf16: one nearest-even plane (common.h store_planes)
   int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
+  int* tickets;       // nullable, [rows * n_q] zeroed once (self-resetting): with nsplit > 1 the LAST split of a (row, head) to arrive
+                      // merges the partials itself -- no attn_combine launch (round 4: one launch less per backbone layer)
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -115,10 +117,69 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
       }
     } else {
       float* pp = a.part + (((size_t)row * a.n_q + h) * a.nsplit + sp) * (HD + 4);
-      if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(pp + 4 * lane) = acc;
+      if (!a.tickets) {
+        if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(pp + 4 * lane) = acc;
+        if (lane == 0) {
+          pp[HD] = m_run;
+          pp[HD + 1] = l_run;
+        }
+        continue;
+      }
+      // ---- fused merge: write-through (sc1) partial + ticket; the last arriver of (row, head) reads all partials back (sc1: the
+      // other splits ran on other XCDs, each with its own L2) and does attn_combine_kernel's arithmetic, term for term
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 0x7ffffff0, 0x00020000);
+      const unsigned off0 = (unsigned)(((size_t)row * a.n_q + h) * a.nsplit * (HD + 4) * sizeof(float));
+      const unsigned off = off0 + (unsigned)(sp * (HD + 4) * sizeof(float));
+      if (lane < Tile::LPR) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs, off + 16 * lane, 0, /*sc1*/ 16);
       if (lane == 0) {
-        pp[HD] = m_run;
-        pp[HD + 1] = l_run;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_run), rs, off + HD * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_run), rs, off + HD * 4 + 4, 0, 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int last = 0;
+      if (lane == 0) {
+        int* tk = a.tickets + (size_t)row * a.n_q + h;
+        last = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.nsplit - 1;
+        if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (!last) continue;
+      constexpr int NS = 32;   // splits merged per register batch (B = 1 at a 512-frame context: 32)
+      const float ms = lane < a.nsplit ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off0 + (unsigned)(lane * (HD + 4) + HD) * 4, 0, 16)) : -INFINITY;
+      const float ls = lane < a.nsplit ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off0 + (unsigned)(lane * (HD + 4) + HD + 1) * 4, 0, 16)) : 0.f;
+      float num[HD / 64];
+#pragma unroll
+      for (int i = 0; i < HD / 64; ++i) num[i] = 0.f;
+      float w = 0.f, inv = 0.f;
+      for (int sb = 0; sb < a.nsplit; sb += NS) {
+        float pv[HD / 64][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int i = 0; i < HD / 64; ++i)
+            pv[i][s] = sb + s < a.nsplit ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off0 + (unsigned)((sb + s) * (HD + 4) + lane + 64 * i) * 4, 0, 16)) : 0.f;
+        if (sb == 0) {
+          const float M = wave_max(ms);
+          w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+          inv = 1.f / wave_sum(ls * w);
+        }
+#pragma unroll
+        for (int i = 0; i < HD / 64; ++i)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            // (lanes >= nsplit hold w = 0 and pv = 0: fmaf(0, 0, num) = num, exactly attn_combine_kernel's 64-term chain)
+            const float ws = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), sb + s));
+            num[i] = fmaf(ws, pv[i][s], num[i]);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < HD / 64; ++i) {
+        const float o = num[i] * inv;
+        a.out[((size_t)row * a.n_q + h) * HD + lane + 64 * i] = o;
+        if (a.oplanes) {
+          const size_t ps = (size_t)a.n_q * HD * 16;
+          store_planes(a.oplanes + (size_t)(row >> 4) * 3 * ps, ps, h * HD + lane + 64 * i, row & 15, o, a.pl1 != 0);
+        }
       }
     }
   }

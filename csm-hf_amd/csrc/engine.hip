@@ -131,6 +131,10 @@ struct csm_engine {
   uint64_t* d_rng = nullptr;   // {seed, global index of row 0}: read by the sampler, written before every launch
   int64_t* ring = nullptr;
   // decode scratch
+  int* attn_tickets = nullptr;   // [B * n_q]: split-merge tickets of the backbone attention (attn.h), zeroed once, self-resetting
+  int fuse_attn_combine = 1;     // 2-32 rows: the last split of a (row, head) merges the partials inside the attention launch (0 = always the
+                                 // attn_combine launch).  Measured (round 4): B = 16 5.09 -> 5.05 ms; B = 1 3.12 -> 3.16 and 128 rows 11.52 -> 11.59 the other way
+                                 // (the ticket round trip on the tail of 32 splits costs what the launch costs), so those keep the launch
   float *q_bb = nullptr, *att_bb = nullptr, *part_bb = nullptr, *act_bb = nullptr, *h_bb = nullptr;
   float* head_out = nullptr;  // [B][ld_head]: [0,Hd) decoder pos-0 input, [Hd, Hd+V) codebook-0 logits
   int ld_head = 0;
@@ -355,6 +359,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   if ((r = dalloc(e, &e->h_bb, (size_t)B * Hb)) || (r = dalloc(e, &e->q_bb, (size_t)B * nqb)) ||
       (r = dalloc(e, &e->att_bb, (size_t)B * nqb)) ||
       (r = dalloc(e, &e->part_bb, (size_t)B * cfg->backbone.n_q * 64 * (cfg->backbone.head_dim + 4))) ||
+      (r = dalloc(e, &e->attn_tickets, (size_t)B * cfg->backbone.n_q)) ||
       (r = dalloc(e, &e->act_bb, (size_t)B * cfg->backbone.ffn)) || (r = dalloc(e, &e->head_out, (size_t)B * e->ld_head)) ||
       (r = dalloc(e, &e->dec_x, (size_t)B * Hd)) || (r = dalloc(e, &e->q_dec, (size_t)B * nqd)) ||
       (r = dalloc(e, &e->att_dec, (size_t)B * nqd)) || (r = dalloc(e, &e->act_dec, (size_t)B * cfg->decoder.ffn)) ||
@@ -399,6 +404,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   e->g16_slab_floats = (size_t)1 << 23;   // split-K slabs: panels x K splits x batch tiles x 256 floats (backbone gate/up at 128 rows: 4 M floats)
   if ((r = dalloc(e, &e->g16_slabs, e->g16_slab_floats)) || (r = dalloc(e, &e->g16_tickets, (size_t)4096))) return r;
   HIPCK(hipMemsetAsync(e->g16_tickets, 0, 4096 * sizeof(int), e->stream));
+  HIPCK(hipMemsetAsync(e->attn_tickets, 0, (size_t)B * cfg->backbone.n_q * sizeof(int), e->stream));
 
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
@@ -573,6 +579,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "decode_bf16")) e->decode_bf16 = value ? 1 : 0;
+  else if (!strcmp(name, "fuse_attn_combine")) e->fuse_attn_combine = value ? 1 : 0;
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
   else if (!strcmp(name, "gemm_wide")) e->gemm_wide = value;
   else if (!strcmp(name, "gemm_dma")) e->gemm_dma = value;
@@ -750,6 +757,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
     t.nsplit = nsplit; t.out = att; t.part = part;
+    t.tickets = (&s == &e->bb && nsplit > 1 && e->fuse_attn_combine && M >= 2 && M <= 32) ? e->attn_tickets : nullptr;
     t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
     t.tile_prefetch = (M == 1 ? e->attn_prefetch & 1 : (e->attn_prefetch >> 1) & 1);
     // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)

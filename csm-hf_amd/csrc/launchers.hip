@@ -10,7 +10,7 @@
 
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
-  if (a.nsplit < 1) return -1;
+  if (a.nsplit < 1 || a.nsplit > 64) return -1;
   if (a.oplanes && rows > 128) return -1;
   const int G = a.n_q / a.n_kv;
   const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
@@ -29,7 +29,7 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   }
   int e = (int)hipGetLastError();
   if (e) return e;
-  if (a.nsplit > 1) {
+  if (a.nsplit > 1 && !a.tickets) {
     if (a.nsplit > 64) return -1;
     if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1);
     else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1);

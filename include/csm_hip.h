@@ -134,7 +134,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                instruction; needs csm_bind_mx_weights), "prefill_bf16_attn" (context attention on the bf16 pipe in those
  *                modes), "decode_bf16" (batched decode on ONE nearest-even activation plane: the reference's own bf16 class)
  *   decode:      "nsplit_backbone" (KV splits of the backbone attention, 0 = by length), "fuse_attn_oproj" (B = 1 decoder
- *                attention + o_proj as one launch), "fuse_sample" (greedy arg-max folded into the head launch),
+ *                attention + o_proj as one launch), "fuse_attn_combine" (backbone attention: the last KV split of a (row, head)
+ *                merges the partials inside the launch), "fuse_sample" (greedy arg-max folded into the head launch),
  *                "two_token_pass" (positions 0 and 1 of the decoder as one 2-row pass, modeling_csm.py:534-552), "use_planes"
  *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (33-64 rows in one launch per linear),
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
