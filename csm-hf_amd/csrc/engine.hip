@@ -597,7 +597,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_fuse_rope")) e->prefill_fuse_rope = value ? 1 : 0;
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "dbg_skip")) { e->dbg_skip = value & 0xffff; e->g16_slab = (value >> 16) << 4; }   // bits 16-19: in-kernel knock-outs of the CSM_G16_KO build
-  else if (!strcmp(name, "rows64")) e->rows64 = value ? 1 : 0;
+  else if (!strcmp(name, "rows64")) e->rows64 = value < 0 ? -1 : (value ? 1 : 0);   // -1: 16-row launches only (tests: every wider form against gemm16_kernel)
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
@@ -646,8 +646,8 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     };
     const auto tl = e->tiled.find(a.W);
     a.Wt = tl == e->tiled.end() ? nullptr : tl->second;
-    if (left > 16 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes (33..64 with rows64): one launch, weights streamed once
-      const int cap = (e->rows64 && m0 % 128 == 0 && left > 64) ? 128 : ((e->rows64 && m0 % 64 == 0 && left > 32) ? 64 : 32);
+    if (left > 16 && e->rows64 >= 0 && e->use_mfma && !a.no_mfma && xpl && a.Wt && m0 % 32 == 0) {   // 17..32 rows on planes (33..64 with rows64): one launch, weights streamed once
+      const int cap = (e->rows64 > 0 && m0 % 128 == 0 && left > 64) ? 128 : ((e->rows64 > 0 && m0 % 64 == 0 && left > 32) ? 64 : 32);
       const int m = left < cap ? left : cap;
       slice(m);
       const int r = launch_gemm32(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,

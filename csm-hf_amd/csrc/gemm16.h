@@ -222,7 +222,9 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   for (int t = 0; t < PT; ++t) {
     if (TL) {
       // tile index of this panel tile (its first row is a multiple of 16); rows >= N are zero in the copy
-      const size_t tile = (size_t)(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4);
+      // (the last panel of a matrix whose tile count is not a multiple of PT -- the 2 051-row heads -- must not read past the copy: its
+    //  extra tiles re-read the last real one and are dropped by the epilogue's n < N)
+    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
       const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -325,9 +327,17 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     const int q = tid + e * 64 * NW;
     mine[e] = (f32x4)(0.f);
     if (q < PT * 64) {
+      // association: eight waves at a time, the groups of eight then in order -- what the 8-wave kernels with a K split across
+      // workgroups compute (gemm32.h at K = 2048: two slabs of eight waves), so that a 16-wave launch of this kernel and a wider
+      // launch of that one round a row alike, bit for bit
       f32x4 s = (f32x4)(0.f);
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(red + w * PT * 256 + q * 4);
+      for (int w0 = 0; w0 < NW; w0 += 8) {
+        f32x4 sg = (f32x4)(0.f);
+#pragma unroll
+        for (int w = w0; w < w0 + 8 && w < NW; ++w) sg += *reinterpret_cast<const f32x4*>(red + w * PT * 256 + q * 4);
+        s += sg;
+      }
       mine[e] = s;
       *reinterpret_cast<f32x4*>(panel + q * 4) = s;
     }
@@ -447,11 +457,13 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         if (t == 0) {
           const float v0 = v, v1 = panel[256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f) * rs;
           const float c = pre0[e], sn = pre1[e];
-          const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
+          // explicit contraction, the form of rope_scatter_kernel / rope_epilogue_row (misc.h, gemm.h): left to the compiler, two
+            // instantiations of this epilogue rounded differently (1e-6 in the logits between 16-row and wider launches, round 4)
+            const float o0 = __fmaf_rn(v0, c, -__fmul_rn(v1, sn)), o1 = __fmaf_rn(v1, c, __fmul_rn(v0, sn));
           if (head < a.n_q) {
             float* q = a.qbuf + (size_t)mm * a.n_q * a.hd + head * a.hd;
-            q[hi] = o0 * a.qscale;
-            q[hi + half] = o1 * a.qscale;
+            q[hi] = __fmul_rn(o0, a.qscale);
+            q[hi + half] = __fmul_rn(o1, a.qscale);
           } else {
             const int j = head - a.n_q;
             store_kv(kc + k_index<KT>(b, j, hi, pos, a.n_kv, a.hd, a.lmax), o0);

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   AFrag<WT> wf[PT][4];
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    const size_t tile = (size_t)(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4);
+    // (the last panel of a matrix whose tile count is not a multiple of PT -- the 2 051-row heads -- must not read past the copy: its
+    //  extra tiles re-read the last real one and are dropped by the epilogue's n < N)
+    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
     const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
@@ -287,11 +289,13 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
           if (t == 0) {
             const float v0 = v, v1 = panel[(MT + mt) * 256 + (i & 255)] * (a.wscale ? a.wscale[n + half] : 1.f) * rs;
             const float c = pre0[e], sn = pre1[e];
-            const float o0 = v0 * c - v1 * sn, o1 = v1 * c + v0 * sn;
+            // explicit contraction, the form of rope_scatter_kernel / rope_epilogue_row (misc.h, gemm.h): left to the compiler, two
+            // instantiations of this epilogue rounded differently (1e-6 in the logits between 16-row and wider launches, round 4)
+            const float o0 = __fmaf_rn(v0, c, -__fmul_rn(v1, sn)), o1 = __fmaf_rn(v1, c, __fmul_rn(v0, sn));
             if (head < a.n_q) {
               float* q = a.qbuf + (size_t)mm * a.n_q * a.hd + head * a.hd;
-              q[hi] = o0 * a.qscale;
-              q[hi + half] = o1 * a.qscale;
+              q[hi] = __fmul_rn(o0, a.qscale);
+              q[hi + half] = __fmul_rn(o1, a.qscale);
             } else {
               const int j = head - a.n_q;
               store_kv(kc + k_index<KT>(b, j, hi, pos, a.n_kv, a.hd, a.lmax), o0);

@@ -37,8 +37,8 @@ template <typename WT, typename KT, int PRO, int EPI>
 static int launch_sel(hipStream_t st, int M, int pt, int mt, int KB, const GemvArgs& a, float* slabs, size_t sf, int* tk, int nt) {
 #define G32_CASE(P, T) if (pt == P && mt == T) return launch_g32<WT, KT, PRO, EPI, 8, P, T>(st, M, KB, a, slabs, sf, tk, nt)
   G32_CASE(2, 2);
-  if constexpr (EPI == EPI_SWIGLU) { G32_CASE(4, 4); }
-  if constexpr (EPI == EPI_RESID) { G32_CASE(1, 2); G32_CASE(4, 2); G32_CASE(2, 4); G32_CASE(4, 4); }
+  if constexpr (EPI == EPI_SWIGLU) { G32_CASE(4, 4); G32_CASE(4, 2); }
+  if constexpr (EPI == EPI_RESID) { G32_CASE(1, 1); G32_CASE(4, 1); G32_CASE(2, 4); G32_CASE(4, 4); }
   if constexpr (EPI == EPI_STORE) { G32_CASE(1, 2); }
 #undef G32_CASE
   return -2;
@@ -56,17 +56,17 @@ static int launch_gemm32_t(hipStream_t st, int kvdtype, int M, int pro, int epi,
   const int nchunks = a.K / 128;
   const int KB = nchunks / 8;
   if (nchunks % 8 || KB > 16) return -2;
-  // shapes (measured at 64 and 128 rows, profiles/r04_g32_shapes.txt; frames bitwise the same for every shape):
-  //   <= 32 rows: one workgroup per panel walks both batch tiles; gate/up and QKV panels of 32 weight rows, the residual launches 16
-  //               (64 when that leaves >= 128 workgroups per K split), the heads 16
-  //   > 32 rows:  QKV, o_proj and the heads keep two batch tiles per workgroup and spread the rows over blockIdx.z (a 128-row QKV
-  //               launch has 48 panels: one workgroup per panel left 200 CUs idle while each wave walked 786 KB of planes);
-  //               gate/up and the K-split down_proj take four batch tiles on 64-row panels (32-row panels for down_proj at <= 64 rows)
-  const int ntiles = (a.N + 15) / 16;
+  // shapes (weight tiles per panel, batch tiles per workgroup; rows beyond go to blockIdx.z), measured at 24 / 32 / 64 / 128 rows
+  // (profiles/r04_g32_shapes.txt); a row's arithmetic does not depend on the shape (tests: logits bitwise against 16-row launches):
+  //   QKV (2, 2) always -- a 128-row QKV launch has 48 panels: one workgroup per panel left 200 CUs idle while each wave walked
+  //       786 KB of planes.  ((2, 1) is NOT used: its RoPE epilogue compiles to a different multiply-add contraction, 1e-6 off)
+  //   o_proj: (1, 1) up to 32 rows, (2, 2) beyond;  heads: (1, 2) up to 32 rows, (2, 2) beyond
+  //   gate/up: (4, 2) up to 32 rows, (4, 4) beyond;  K-split down_proj: (4, 1) up to 32 rows, (2, 4) up to 64, (4, 4) beyond
   int pt = 2, mt = 2;
   if (M <= 32) {
-    if (epi == EPI_RESID) pt = (KB > 1 && ntiles >= 128) ? 4 : 1;
+    if (epi == EPI_RESID) { pt = a.K > 2048 ? 4 : 1; mt = 1; }
     if (epi == EPI_STORE) pt = 1;
+    if (epi == EPI_SWIGLU) pt = 4;
   } else if (epi == EPI_SWIGLU) {
     pt = 4; mt = 4;
   } else if (epi == EPI_RESID && a.K > 2048) {
@@ -106,7 +106,7 @@ int gemm32_configure_all() {
           if (K == 8192 && c[0] == PRO_NORM) continue;
           a.K = K;
           for (int one = 0; one < 2; ++one)
-            for (int rows : {64, 128}) {
+            for (int rows : {32, 64, 128}) {
               a.pl1 = one;
               const int r = launch_gemm32(nullptr, wd, kd, rows, c[0], c[1], a, nullptr, (size_t)1 << 30, nullptr, 1 << 20);
               if (r != 0 && r != -2) return r;

@@ -203,12 +203,12 @@ struct GemvEpi {
       KT* vc = reinterpret_cast<KT*>(a.vcache);
       if (k.head < a.n_q + a.n_kv) {
         const float c = a0[m], s = a1[m];
-        const float o0 = v0 * c - v1 * s;
-        const float o1 = v1 * c + v0 * s;
+        const float o0 = __fmaf_rn(v0, c, -__fmul_rn(v1, s));   // explicit contraction: the form of every RoPE site (misc.h rope_scatter_kernel)
+        const float o1 = __fmaf_rn(v1, c, __fmul_rn(v0, s));
         if (k.head < a.n_q) {
           float* q = a.qbuf + (size_t)m * a.n_q * a.hd + k.head * a.hd;
-          q[k.hi] = o0 * a.qscale;
-          q[k.hi + half] = o1 * a.qscale;
+          q[k.hi] = __fmul_rn(o0, a.qscale);
+          q[k.hi + half] = __fmul_rn(o1, a.qscale);
         } else {
           const int j = k.head - a.n_q;
           store_kv(kc + k_index<KT>(b, j, k.hi, pos[m], a.n_kv, a.hd, a.lmax), o0);

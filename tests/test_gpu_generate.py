@@ -501,35 +501,36 @@ def test_csm1b_batched_rows_other_shapes_and_paths(csm1b_bf16, B, opts):
 
 
 def test_csm1b_64_row_launch_is_bitwise_two_32_row_launches(csm1b_bf16):
-    """33..64 rows on gemm32_kernel<..., MT = 4> and, round 4, 65..128 rows on MT = 8 (one launch, ONE pass over the weights:
-    VERDICT r3 item 5) against 32-row launches (`rows64 = 0`): every accumulator sums its products in the same order in both
-    forms, so the generated frames are equal bit for bit -- 48 rows (a partial fourth tile), 64, 100 (a partial seventh tile),
-    128.  Both arithmetic classes (exact planes / decode_precision bf16)."""
+    """17..128 batched rows in ONE matrix-core launch per linear (gemm32_kernel: several batch tiles per workgroup, further rows on
+    blockIdx.z, shapes by launch kind -- gemm32.hip) against narrower launches: 32-row launches (`rows64 = 0`) and 16-row launches
+    on gemm16_kernel (`rows64 = -1`).  Every accumulator sums its products in the same order in every form, so not only the
+    generated frames but the LOGITS of every codebook and the backbone's last hidden state are equal bit for bit (round 4: the
+    token comparison alone let a 1e-6 multiply-add contraction difference of one instantiation through) -- 24 rows (a partial second
+    tile), 32, 48, 64, 100 (a partial seventh tile), 128.  Both arithmetic classes (exact planes / decode_precision bf16)."""
     m = csm1b_bf16
     cfg = m.config
-    for B in (48, 64, 100, 128):
-        ids, mask = synth_context(cfg, B, 12, 20, seed=47)
-        outs = []
-        for r64 in (1, 0):
-            m.setup_caches(B)
-            eng = m._ensure_engine(B, 64, 8, B * 32)
-            eng.set_option("rows64", r64)
-            outs.append(m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu())
-        m._engine.set_option("rows64", 1)
-        assert torch.equal(outs[0], outs[1]), B
-        if B in (64, 128):
-            try:
-                m.decode_precision = "bf16"
-                b16 = []
-                for r64 in (1, 0):
-                    eng = m._ensure_engine(B, 64, 8, B * 32)
+    try:
+        for B in (24, 32, 48, 64, 100, 128):
+            ids, mask = synth_context(cfg, B, 12, 20, seed=47)
+            for prec in (("exact", "bf16") if B in (24, 32, 64, 128) else ("exact",)):
+                m.decode_precision = prec
+                outs = []
+                for r64 in ((1, -1) if B <= 32 else (1, 0, -1)):
+                    T = ids.shape[1]
+                    eng = m._ensure_engine(B, T + 3 + 1, 3, B * T)      # (traced_generate asks for the same engine)
                     eng.set_option("rows64", r64)
-                    b16.append(m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=3, topk=1, stop_on_all_zeros=False).cpu())
-                assert torch.equal(b16[0], b16[1]), (B, "bf16")
-            finally:
+                    outs.append(traced_generate(m, ids, mask, 3))
+                    assert m._engine is eng
                 m._engine.set_option("rows64", 1)
-                m.decode_precision = "exact"
-    m._drop_engine()
+                for o in outs[1:]:
+                    assert torch.equal(outs[0][0], o[0]), (B, prec, "tokens")
+                    assert torch.equal(outs[0][1], o[1]), (B, prec, "logits", float((outs[0][1] - o[1]).abs().max()))
+                    assert torch.equal(outs[0][2], o[2]), (B, prec, "last_h")
+    finally:
+        m.decode_precision = "exact"
+        if m._engine is not None:
+            m._engine.set_option("rows64", 1)
+        m._drop_engine()
 
 
 def test_csm1b_config3_batch16_voiceclone_rows_vs_reference(gold, csm1b_bf16):
