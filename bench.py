@@ -148,10 +148,11 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
         ids, mask = synth_context(cfg, rows, ctx // 4, ctx - ctx // 4, seed=4)
         ids, mask = ids.to(dev), mask.to(dev)
         a0, a1 = shard_rows(rows, rank, world)
-        # exact = the engine's default (three exact bf16 planes per activation); bf16 = decode_precision "bf16", the reference's own
-        # arithmetic class (one nearest-even plane): reported beside it, never instead of it
+        # exact = the engine's default (three exact bf16 planes per activation); bf16 = decode_precision AND prefill_precision "bf16",
+        # the reference's own arithmetic class for the whole call (one nearest-even plane): reported beside it, never instead of it
         for mode in (("exact",) if os.environ.get("CSM_BENCH_NO_DECODE_BF16") == "1" else ("exact", "bf16")):
             model.decode_precision = mode
+            model.prefill_precision = mode
             walls = []
             for it in range(2):          # first pass sizes the engine and captures the graph (untimed)
                 if dist is not None:
@@ -186,8 +187,10 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
                 out[leg] = rec
             else:
                 out[leg]["decode_precision_bf16"] = {k: rec[k] for k in ("ms_per_step_decode", "roofline_frac_of_8TBs", "frames_per_s_end_to_end",
-                                                                        "frames_per_s_decode_only", "tokens_checksum")}
+                                                                        "frames_per_s_decode_only", "wall_s", "tokens_checksum")}
+                out[leg]["decode_precision_bf16"]["prefill_precision"] = "bf16"
         model.decode_precision = "exact"
+        model.prefill_precision = "exact"
     return out
 
 
