@@ -193,3 +193,38 @@ def test_bench_eight_ranks_on_one_device_slices_like_one_process():
     one = generate_sharded(m, ids4.to(DEV), mask4.to(DEV), max_new_frames=2, temperature=1.0, topk=1, stop_on_all_zeros=False)
     assert int(one.to(torch.int64).sum()) == c4["strong"]["tokens_checksum"]
     m._drop_engine()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the backbone attention's split merge inside the launch (attn.h: tickets, last arriver) against the attn_combine launch
+# ---------------------------------------------------------------------------------------------------
+def test_fused_split_merge_of_the_backbone_attention_is_bitwise_the_combine_launch():
+    """`fuse_attn_combine` (2-32 rows, default on): the last KV split of a (row, head) to arrive merges the partials with
+    attn_combine_kernel's arithmetic, term for term -- logits, last_h and tokens of 3 frames are equal bit for bit to the
+    two-launch form, at a context long enough for 4 splits, a left-padded row included."""
+    cfg = CSMConfig()
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV, bf16_representable=True)
+    m = CSMModel(cfg)
+    m.load_state_dict(sd)
+    del sd
+    B, T, n = 5, 300, 3
+    ids, mask = synth_context(cfg, B, T // 4, T - T // 4, seed=21)
+    ids[1, :37] = 0
+    mask[1, :37] = 0            # a left-padded row: its first valid key is 37
+    outs = []
+    for fuse in (1, 0):
+        eng = m._ensure_engine(B, T + n + 1, n, B * T)
+        eng.set_option("fuse_attn_combine", fuse)
+        eng.reset()
+        eng.set_kv_start(m._kv_starts(mask, B, T))
+        lt = torch.zeros(eng.max_frames, B, eng.C, eng.V, dtype=torch.float32, device=DEV)
+        ht = torch.zeros(eng.max_frames, B, eng.Hb, dtype=torch.float32, device=DEV)
+        eng.prefill(ids, mask)
+        s = eng.sampling(temperature=1.0, topk=1, seed=7, logits_trace=lt, last_h_trace=ht)
+        eng.generate(s, n, True)
+        outs.append((eng.read_frames(0, n).cpu(), lt[:n].cpu(), ht[:n].cpu()))
+    m._engine.set_option("fuse_attn_combine", 1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert float(outs[0][1].abs().max()) > 0.1        # (the traces were written)
+    m._drop_engine()
