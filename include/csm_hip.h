@@ -137,7 +137,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                attention + o_proj as one launch), "fuse_attn_combine" (backbone attention: the last KV split of a (row, head)
  *                merges the partials inside the launch), "fuse_sample" (greedy arg-max folded into the head launch),
  *                "two_token_pass" (positions 0 and 1 of the decoder as one 2-row pass, modeling_csm.py:534-552), "use_planes"
- *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (33-64 rows in one launch per linear),
+ *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (1: 17-128 rows in ONE launch per linear; 0: 32-row
+ *                launches; -1: 16-row launches -- the forms the width tests compare against, bit for bit),
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
  *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 24)
  *   prefill:     "gemm_wide", "gemm_dma", "gemm_256", "gemm_dma_skinny", "gemm_mx_skinny" (tile selection of the context GEMMs:
