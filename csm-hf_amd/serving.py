@@ -171,7 +171,10 @@ class ContinuousBatcher:
                     raise ValueError(f"generated token id {int(toks_dev[live].max())} is outside the codec's codebook ({dec.cfg.codebook_size})")
                 codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k] (the clamp only touches idle rows)
                 step = max(1, dec.max_frames // B)
-                wav = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1).cpu()   # [B, 1, k * spf]
+                wav_dev = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1)   # [B, 1, k * spf]
+                # only the live rows' samples cross to the host (one copy), indexed back by row below
+                wav_row = {b: i for i, b in enumerate(live)}
+                wav = wav_dev[torch.tensor(live, device=wav_dev.device)].cpu() if live else None
             now = self._clock()
             for b, r in enumerate(rows):
                 if r is None:
@@ -185,7 +188,7 @@ class ContinuousBatcher:
                     r[2].append(toks[b, i])
                     took += 1
                 if wav is not None and took:
-                    waves[b].append(wav[b, 0, :took * spf])
+                    waves[b].append(wav[wav_row[b], 0, :took * spf])
                 if took:
                     self._delivered(r[0], took, now)
                 if done or len(r[2]) >= r[1]:
