@@ -21,7 +21,7 @@ struct PrefillAttnArgs {
   size_t plane_stride;
   const int* seq_slot;  // nullable: sequence b of this launch lives in cache slot seq_slot[b] (continuous batching: several rows of a
                         // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
-  int map;              // attn_prefill_bf16_kernel: query-tile order (see the kernel)
+  int map;              // attn_prefill_bf16_kernel: 1 = alternate waves of 256 workgroups walk the query tiles in ascending order (see the kernel)
   uint8_t* oq;          // nullable (attn_prefill_bf16_kernel only): output as MX-fp8 rows [B*S][n_q*64] e4m3 + os [B*S][n_q*2] E8M0 scales
   uint8_t* os;          // (the OCP recipe of mx_quant_rows_kernel, gemm_mx.h; a 32-block = half a head = the lane pair of a query row) instead of `out`
 };
@@ -169,42 +169,42 @@ __device__ __forceinline__ int ap_vperm(int k) {
   return (((k >> 4) * 2 + ((w >> 2) & 1)) * 8) + (w & 3) + 4 * (w >> 3);
 }
 
-template <typename KT, int NT = 1>
-struct ApStage;   // one thread's share of a 64-key K / V tile (workgroup of 256 NT threads), in flight in registers while the previous tile is computed
-template <int NT>
-struct ApStage<float, NT> {
-  f32x4 k[4 / NT], v[4 / NT];
+template <typename KT>
+struct ApStage;   // one thread's share of a 64-key K / V tile, in flight in registers while the previous tile is computed
+template <>
+struct ApStage<float> {
+  f32x4 k[4], v[4];
   __device__ __forceinline__ void load(const float* kc, const float* vc, int lmax, int kt0, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4 / NT; ++i) {
-      const int idx = tid + i * 256 * NT;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
       const int key = min(kt0 + (idx & 63), lmax - 1);
       k[i] = *reinterpret_cast<const f32x4*>(kc + ((size_t)(idx >> 6) * lmax + key) * 4);
     }
-    const float* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * (16 / NT);
+    const float* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * 16;
 #pragma unroll
-    for (int i = 0; i < 4 / NT; ++i) v[i] = *reinterpret_cast<const f32x4*>(vsrc + 4 * i);
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(vsrc + 4 * i);
   }
   __device__ __forceinline__ uint2 kword(int i) const { return make_uint2(ap_pack2(k[i][0], k[i][1]), ap_pack2(k[i][2], k[i][3])); }
   __device__ __forceinline__ float kval(int i, int e) const { return k[i][e]; }   // exact mode: the fp32 value itself
-  __device__ __forceinline__ float vval(int d) const { return v[d >> 2][d & 3]; }   // V[key][(16 / NT) c + d]
-  // bf16 bits of V[key][(16 / NT) c + 2q] (low half) and V[key][(16 / NT) c + 2q + 1] (high half)
+  __device__ __forceinline__ float vval(int d) const { return v[d >> 2][d & 3]; }   // V[key][16c + d]
+  // bf16 bits of V[key][16c + 2q] (low half) and V[key][16c + 2q + 1] (high half)
   __device__ __forceinline__ uint32_t vpair(int q) const { return ap_pack2(v[q >> 1][(2 * q) & 3], v[q >> 1][(2 * q + 1) & 3]); }
 };
-template <int NT>
-struct ApStage<bf16_t, NT> {
-  uint2 k[4 / NT];
-  u32x4 v[2 / NT];
+template <>
+struct ApStage<bf16_t> {
+  uint2 k[4];
+  u32x4 v[2];
   __device__ __forceinline__ void load(const bf16_t* kc, const bf16_t* vc, int lmax, int kt0, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4 / NT; ++i) {
-      const int idx = tid + i * 256 * NT;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
       const int key = min(kt0 + (idx & 63), lmax - 1);
       k[i] = *reinterpret_cast<const uint2*>(kc + ((size_t)(idx >> 6) * lmax + key) * 4);
     }
-    const bf16_t* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * (16 / NT);
-#pragma unroll
-    for (int i = 0; i < 2 / NT; ++i) v[i] = *reinterpret_cast<const u32x4*>(vsrc + 8 * i);
+    const bf16_t* vsrc = vc + (size_t)min(kt0 + (tid & 63), lmax - 1) * 64 + (tid >> 6) * 16;
+    v[0] = *reinterpret_cast<const u32x4*>(vsrc);
+    v[1] = *reinterpret_cast<const u32x4*>(vsrc + 8);
   }
   __device__ __forceinline__ uint2 kword(int i) const { return k[i]; }
   __device__ __forceinline__ uint32_t vpair(int q) const { return v[q >> 2][q & 3]; }
@@ -218,32 +218,23 @@ __device__ __forceinline__ float ap_max3(float a, float b, float c) {   // no Na
   return r;
 }
 
-// NT = wave groups per workgroup (round 4).  NT = 1 (rounds 2-3): four waves, wave g = query head g of the kv-head, each walking
-// all 64 keys of a tile.  NT = 2: eight waves; waves 0-3 take keys 0-31 of every tile, waves 4-7 keys 32-63 of the SAME staged tile
-// (same LDS stage, same two barriers per tile), with their own running statistics; wave g + 4 hands (o, m, l) to wave g through
-// LDS at the end (the usual two-part softmax merge).  The launch is bound by the serial chain of its longest workgroup (32 key
-// tiles at 2 048 frames; knock-outs: profiles/r04_attn_prefill_knockout.txt): half the softmax and half the matrix work per
-// wave and tile was meant to shorten exactly that chain -- MEASURED THE SAME (2 048 frames 5.34 vs 5.36 ms, 512 frames 2.36 vs
-// 2.34): the library instantiates NT = 1.
-// PD = K / V tiles in flight in registers behind the tile being computed: 2 / 3 measured the same as 1 (not load latency).
-// VAR: TIMING-ONLY knock-outs (wrong results; not instantiated in the library): 1 = no exp2, 2 = no K / V loads after the
-// first tile, 4 = no barriers, 8 = no MFMAs, 16 = no LDS staging writes
-template <typename KT, int NT = 1, int PD = 1, int VAR = 0>
-__global__ __launch_bounds__(256 * NT) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
+// Measured and NOT kept (profiles/r04_attn_prefill_knockout.txt; the variants are in the history): two key groups per workgroup
+// on alternate key tiles (round 3: slower), two or three K / V tiles in flight instead of one, eight waves with waves 4-7 on keys
+// 32-63 of every tile (round 4: both the same as this form).  Knock-outs: no single stream (exp2, MFMAs, LDS writes, loads,
+// barriers) is worth more than 0.4 of 5.7 ms per 2 048-frame prefill; with all of them gone 23 of 60 us per launch remain.
+template <typename KT>
+__global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs a) {
   constexpr int HD = 64, LDK = 72;   // 144-byte LDS rows: 16-byte reads of 32 consecutive rows cover all banks evenly
-  constexpr int HPW = 2 / NT;        // 32-key halves of a tile per wave
   __shared__ __attribute__((aligned(16))) bf16_t kv_all[2 * 64 * LDK];
-  __shared__ float xch[NT > 1 ? 4 * 34 * 64 : 1];   // NT = 2: (o0, o1, m, l) of waves 4-7, lane-major
   bf16_t* const Ks = kv_all;                  // [key][d]
   bf16_t* const Vt = kv_all + 64 * LDK;       // [d][ap_vperm(key)]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int hw = wave & 3, kh = wave >> 2;    // query head within the group, key half (NT = 2)
   const int G = a.n_q / a.n_kv;
   // query tile of this workgroup.  Every workgroup of a 2 048-frame context is resident at once (two per CU), so nothing balances
-  // itself: a CU that holds two of the latest tiles (32 key tiles each) runs twice as long as the average one (MAP 0, rounds 2-3).
-  // MAP 1: every other wave of 256 workgroups walks the tiles in ascending order, so that the two workgroups of a CU (dispatch
-  // slots n and n + 256) hold a long and a short tile: 2 048 frames 5.69 -> 5.51 ms (bf16), 4.36 -> 4.17 ms (mxfp8).  (Pairing
-  // neighbours in dispatch order instead: no change -- the dispatcher is round-robin over the CUs.)
+  // itself: a CU holding two of the latest tiles (32 key tiles each) ran twice as long as the average one (rounds 2-3).  map = 1:
+  // every other wave of 256 workgroups walks the tiles in ascending order, so that the two workgroups of a CU (dispatch slots n and
+  // n + 256) hold a long and a short tile: 2 048 frames 5.69 -> 5.51 ms (bf16), 4.36 -> 4.17 ms (mxfp8).  (Pairing neighbours in
+  // dispatch order instead: no change -- the dispatcher is round-robin over the CUs.)
   int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
   if (a.map == 1) {
     const int n = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -252,8 +243,8 @@ __global__ __launch_bounds__(256 * NT) void attn_prefill_bf16_kernel(PrefillAttn
   const int j = blockIdx.y, b = blockIdx.z;
   const int s0 = qt * 32;
   const int li = lane & 31, lh = lane >> 5;
-  const bool head_live = hw < G;
-  const int h = j * G + (head_live ? hw : 0);
+  const bool head_live = wave < G;
+  const int h = j * G + (head_live ? wave : 0);
   const int bs = a.seq_slot ? a.seq_slot[b] : b;   // cache slot of this sequence
   const int kv_lo = a.kv_start ? a.kv_start[bs] : 0;
   const int s_last = min(a.S - 1, s0 + 31);
@@ -284,65 +275,52 @@ __global__ __launch_bounds__(256 * NT) void attn_prefill_bf16_kernel(PrefillAttn
   float m_run = -INFINITY, l_run = 0.f;
   constexpr float L2E = 1.4426950408889634f, SLACK = 8.f;
 
-  ApStage<KT, NT> st[PD];
+  ApStage<KT> st;
   int kt0 = kv_lo & ~63;
-#pragma unroll
-  for (int p = 0; p < PD; ++p)
-    if (kt0 + 64 * p <= kmax) st[p].load(kc, vc, a.lmax, kt0 + 64 * p, tid);
-  // where this thread's V share lands: rows d = (16 / NT) * wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
+  if (kt0 <= kmax) st.load(kc, vc, a.lmax, kt0, tid);
+  // where this thread's V share lands: rows d = 16*wave + 2q (+1 for odd lanes), word = the (key, key^1) pair
   const int vkey = tid & 63;
-  uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + (((16 / NT) * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
+  uint32_t* const vdst = reinterpret_cast<uint32_t*>(Vt) + ((16 * wave + (vkey & 1)) * LDK + ap_vperm(vkey & ~1)) / 2;
   // even lanes keep dimension 2q of (own key, next key), odd lanes dimension 2q+1 of (previous key, own key)
   const uint32_t vsel = (vkey & 1) ? 0x03020706u : 0x05040100u;   // v_perm_b32 byte selector over {theirs, mine}
-  auto sync = [&]() { if (!(VAR & 4)) __syncthreads(); };
-  auto tile = [&](ApStage<KT, NT>& sg) __attribute__((always_inline)) {
+  for (; kt0 <= kmax; kt0 += 64) {
     // ---- registers -> LDS ------------------------------------------------------------------------------------
-    if (!(VAR & 16)) {
 #pragma unroll
-      for (int i = 0; i < 4 / NT; ++i) {
-        const int idx = tid + i * 256 * NT;
-        *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = sg.kword(i);
-      }
-#pragma unroll
-      for (int q = 0; q < 8 / NT; ++q) {
-        const uint32_t mine = sg.vpair(q);
-        const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
-        vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<uint2*>(&Ks[(idx & 63) * LDK + (idx >> 6) * 4]) = st.kword(i);
     }
-    sync();
-    // this stage's registers are free again: tile kt0 + 64 PD goes in flight behind the math of PD tiles
-    if (!(VAR & 2) && kt0 + 64 * PD <= kmax) sg.load(kc, vc, a.lmax, kt0 + 64 * PD, tid);
-    // ---- S^T[key][row] = sum_d K[key][d] Q[row][d]: this wave's 32-key halves (kk = first half) ---------------------
-    f32x16 sc[HPW];
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) sc[hh] = (f32x16)(0.f);
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t mine = st.vpair(q);
+      const uint32_t theirs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, true);   // lane ^ 1
+      vdst[q * LDK] = __builtin_amdgcn_perm(theirs, mine, vsel);
+    }
+    __syncthreads();
+    if (kt0 + 64 <= kmax) st.load(kc, vc, a.lmax, kt0 + 64, tid);   // next tile in flight behind this tile's math
+    // ---- S^T[key][row] = sum_d K[key][d] Q[row][d], two 32-key halves ----------------------------------------------
+    f32x16 sc0 = (f32x16)(0.f), sc1 = (f32x16)(0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int hh = 0; hh < HPW; ++hh) {
-        const ap_bf16x8 kf = *reinterpret_cast<const ap_bf16x8*>(&Ks[(32 * (kh + hh) + li) * LDK + 16 * t + 8 * lh]);
-        if (VAR & 8) { sc[hh][t] += (float)kf[0]; continue; }
-        sc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], sc[hh], 0, 0, 0);
-      }
+      const ap_bf16x8 k0 = *reinterpret_cast<const ap_bf16x8*>(&Ks[li * LDK + 16 * t + 8 * lh]);
+      const ap_bf16x8 k1 = *reinterpret_cast<const ap_bf16x8*>(&Ks[(32 + li) * LDK + 16 * t + 8 * lh]);
+      sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[t], sc0, 0, 0, 0);
+      sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[t], sc1, 0, 0, 0);
     }
     // interior tiles (every key visible to every row) skip the mask
     const bool interior = tile_full && kt0 >= kv_lo && kt0 + 63 <= a.past + s0;
     if (!interior) {
-      const int base = kt0 + 32 * kh + 4 * lh - row_lo;
+      const int base = kt0 + 4 * lh - row_lo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rel = base + (r & 3) + 8 * (r >> 2);   // key - row_lo: valid iff 0 <= rel <= row_span
-#pragma unroll
-        for (int hh = 0; hh < HPW; ++hh) sc[hh][r] = (row_any && (unsigned)(rel + 32 * hh) <= row_span) ? sc[hh][r] : -INFINITY;
+        sc0[r] = (row_any && (unsigned)rel <= row_span) ? sc0[r] : -INFINITY;
+        sc1[r] = (row_any && (unsigned)(rel + 32) <= row_span) ? sc1[r] : -INFINITY;
       }
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (HPW == 2) mx = ap_max3(mx, sc[0][r], sc[HPW - 1][r]);
-      else mx = fmaxf(mx, sc[0][r]);
-    }
+    for (int r = 0; r < 16; ++r) mx = ap_max3(mx, sc0[r], sc1[r]);
     mx = xor32_max(mx) * L2E;
     const bool move = mx > m_run + SLACK;   // also the first tile with a visible key (m_run = -inf)
     if (__builtin_amdgcn_ballot_w64(move) != 0) {
@@ -358,62 +336,28 @@ __global__ __launch_bounds__(256 * NT) void attn_prefill_bf16_kernel(PrefillAttn
     const ap_f32x2 l2e2 = {L2E, L2E}, nm2 = {neg_m, neg_m};
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-#pragma unroll
-      for (int hh = 0; hh < HPW; ++hh) {
-        ap_f32x2 x = {sc[hh][r], sc[hh][r + 1]};
-        x = x * l2e2 + nm2;
-        if (!(VAR & 1)) { x[0] = __builtin_amdgcn_exp2f(x[0]); x[1] = __builtin_amdgcn_exp2f(x[1]); }
-        sum2 += x;
-        sc[hh][r] = x[0]; sc[hh][r + 1] = x[1];
-      }
+      ap_f32x2 x0 = {sc0[r], sc0[r + 1]}, x1 = {sc1[r], sc1[r + 1]};
+      x0 = x0 * l2e2 + nm2;
+      x1 = x1 * l2e2 + nm2;
+      x0[0] = __builtin_amdgcn_exp2f(x0[0]); x0[1] = __builtin_amdgcn_exp2f(x0[1]);
+      x1[0] = __builtin_amdgcn_exp2f(x1[0]); x1[1] = __builtin_amdgcn_exp2f(x1[1]);
+      sum2 += x0 + x1;
+      sc0[r] = x0[0]; sc0[r + 1] = x0[1];
+      sc1[r] = x1[0]; sc1[r + 1] = x1[1];
     }
     l_run += xor32_sum(sum2[0] + sum2[1]);
     // ---- O^T[d][row] += sum_key V[key][d] P[row][key] -------------------------------------------------------------
 #pragma unroll
-    for (int hh = 0; hh < HPW; ++hh) {
-#pragma unroll
-      for (int step = 0; step < 2; ++step) {
-        const int u = 2 * (kh + hh) + step;   // 16-key block of the tile
-        const int r0 = 8 * step;
-        const ap_bf16x8 pb = ap_pack8(sc[hh][r0], sc[hh][r0 + 1], sc[hh][r0 + 2], sc[hh][r0 + 3], sc[hh][r0 + 4], sc[hh][r0 + 5], sc[hh][r0 + 6], sc[hh][r0 + 7]);
-        const ap_bf16x8 v0 = *reinterpret_cast<const ap_bf16x8*>(&Vt[li * LDK + (2 * u + lh) * 8]);
-        const ap_bf16x8 v1 = *reinterpret_cast<const ap_bf16x8*>(&Vt[(32 + li) * LDK + (2 * u + lh) * 8]);
-        if (VAR & 8) { o0[u] += (float)v0[0] * (float)pb[0]; o1[u] += (float)v1[0] * (float)pb[1]; continue; }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
-      }
+    for (int u = 0; u < 4; ++u) {   // u = 2*hh + step
+      const f32x16& sc = (u < 2) ? sc0 : sc1;
+      const int r0 = 8 * (u & 1);
+      const ap_bf16x8 pb = ap_pack8(sc[r0], sc[r0 + 1], sc[r0 + 2], sc[r0 + 3], sc[r0 + 4], sc[r0 + 5], sc[r0 + 6], sc[r0 + 7]);
+      const ap_bf16x8 v0 = *reinterpret_cast<const ap_bf16x8*>(&Vt[li * LDK + (2 * u + lh) * 8]);
+      const ap_bf16x8 v1 = *reinterpret_cast<const ap_bf16x8*>(&Vt[(32 + li) * LDK + (2 * u + lh) * 8]);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
     }
-    sync();   // the tile is rewritten by the next one
-  };
-  while (kt0 <= kmax) {
-#pragma unroll
-    for (int p = 0; p < PD; ++p) {
-      if (kt0 > kmax) break;   // (uniform)
-      tile(st[p]);
-      kt0 += 64;
-    }
-  }
-  if (NT > 1) {
-    // waves 4-7 -> waves 0-3: (o0, o1, m, l) of every lane, lane-major (conflict-free)
-    float* mine_x = xch + (size_t)hw * 34 * 64 + lane;
-    if (kh == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { mine_x[r * 64] = o0[r]; mine_x[(16 + r) * 64] = o1[r]; }
-      mine_x[32 * 64] = m_run;
-      mine_x[33 * 64] = l_run;
-    }
-    __syncthreads();
-    if (kh == 1) return;
-    const float m1 = mine_x[32 * 64], l1 = mine_x[33 * 64];
-    const float m = fmaxf(m_run, m1);
-    const float w0 = m_run > -INFINITY ? __builtin_amdgcn_exp2f(m_run - m) : 0.f;
-    const float w1 = m1 > -INFINITY ? __builtin_amdgcn_exp2f(m1 - m) : 0.f;
-    l_run = l_run * w0 + l1 * w1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] = o0[r] * w0 + mine_x[r * 64] * w1;
-      o1[r] = o1[r] * w0 + mine_x[(16 + r) * 64] * w1;
-    }
+    __syncthreads();   // the tile is rewritten at the top of the next iteration
   }
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
   if (a.oq) {   // MX-fp8 output for the o_proj GEMM: dims 0-31 / 32-63 of the head are one scale block each, held by this lane and lane ^ 32
