@@ -579,7 +579,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
   else if (!strcmp(name, "decode_bf16")) e->decode_bf16 = value ? 1 : 0;
-  else if (!strcmp(name, "fuse_attn_combine")) e->fuse_attn_combine = value ? 1 : 0;
+  else if (!strcmp(name, "fuse_attn_combine")) e->fuse_attn_combine = value < 0 ? 0 : (value > 2 ? 2 : value);   // 2: at every batch size (A/B)
   else if (!strcmp(name, "prefill_bf16_attn")) e->prefill_bf16_attn = value;
   else if (!strcmp(name, "gemm_wide")) e->gemm_wide = value;
   else if (!strcmp(name, "gemm_dma")) e->gemm_dma = value;
@@ -757,7 +757,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = (&s == &e->bb) ? e->d_kv_start : nullptr;
     t.nsplit = nsplit; t.out = att; t.part = part;
-    t.tickets = (&s == &e->bb && nsplit > 1 && e->fuse_attn_combine && M >= 2 && M <= 32) ? e->attn_tickets : nullptr;
+    t.tickets = (&s == &e->bb && nsplit > 1 && (e->fuse_attn_combine == 2 || (e->fuse_attn_combine && M >= 2 && M <= 32))) ? e->attn_tickets : nullptr;
     t.one_wave = (&s == &e->bb) ? (e->attn_one_wave >> 1) & 1 : e->attn_one_wave & 1;
     t.tile_prefetch = (M == 1 ? e->attn_prefetch & 1 : (e->attn_prefetch >> 1) & 1);
     // the attention output goes to o_proj as planes too (staged in the SwiGLU plane buffer, which is free here)
