@@ -64,7 +64,7 @@ def bytes_step(cfg: CSMConfig, B: int, L: float, wbytes: int = 2, kvbytes: int =
     return w_step + B * (kv_bb * L + dec_reads + emb)
 
 
-def cpu_baseline(cfg, model, ids, mask, frames: int, gpu_tokens, budget_s: float = 40.0):
+def cpu_baseline(cfg, model, ids, mask, frames: int, gpu_tokens, budget_s: float = 40.0, want_bf16: bool = True):
     """Oracle (checker + CPU baseline only) on the host cores, fp32 arithmetic on the same weights: decode
     frames/s after the same prefill.  Bounded: one prefill, a 1-frame probe per candidate thread count, then
     at most `frames` frames / `budget_s` seconds with the fastest thread count (M=1 GEMVs do not scale to 256
@@ -99,41 +99,45 @@ def cpu_baseline(cfg, model, ids, mask, frames: int, gpu_tokens, budget_s: float
         cache = out.cache
         t0 = time.perf_counter()
         done = 0
-        while done < frames and time.perf_counter() - t0 < budget_s:
+        while done < frames and time.perf_counter() - t0 < budget_s / 2:
             out = step(toks[-1], cache)
             cache = out.cache
             toks.append(out.samples)
             done += 1
         dt_s = time.perf_counter() - t0
-    rec = dict(value=round(done * ids.shape[0] / dt_s, 3), unit="frames/s", cores=best_nt, threads_used=best_nt,
-               host_cores=ncpu, host_cpu_model=_cpu_model(), kind="port", arith="f32",
-               sample=f"csm-1b, same {ids.shape[1]}-frame context, {done} decode frames after prefill "
-                      f"(prefill {t_prefill:.2f}s excluded), B={ids.shape[0]}, greedy; thread-count probe "
-                      + ", ".join(f"{k}t:{1 / v:.2f}fps" for k, v in probe.items()))
+    f32 = dict(value=round(done * ids.shape[0] / dt_s, 3), unit="frames/s", threads_used=best_nt, frames=done, arith="f32")
     if gpu_tokens is not None:
         n = min(len(toks), gpu_tokens.shape[1])
-        rec["first_frames_equal_gpu"] = bool(torch.equal(torch.stack(toks[:n], 1), gpu_tokens[:, :n].cpu()))
-    # the reference's own dtype for this configuration is bf16 (README.md:73): the same oracle in bf16 arithmetic,
-    # same thread count, bounded to a third of the budget (its greedy stream is not comparable token for token:
-    # bf16 logits tie and the reference breaks ties with the RNG)
-    try:
-        sdb = {k: v.to(torch.bfloat16) for k, v in sd.items()}
-        with torch.inference_mode():
-            out = O.generate_frame(sdb, cfg, ids, mask, 1.0, 1, None, True)
-            cache, prev = out.cache, out.samples
-            t0 = time.perf_counter()
-            done_b = 0
-            while done_b < frames and time.perf_counter() - t0 < budget_s / 3:
-                row = torch.cat([prev, torch.zeros(ids.shape[0], 1, dtype=torch.long)], 1).unsqueeze(1)
-                m1 = torch.zeros(ids.shape[0], 1, C + 1, dtype=mask.dtype)
-                m1[:, :, :C] = 1
-                out = O.generate_frame(sdb, cfg, row, m1, 1.0, 1, cache, True)
+        f32["first_frames_equal_gpu"] = bool(torch.equal(torch.stack(toks[:n], 1), gpu_tokens[:, :n].cpu()))
+    sample = (f"csm-1b, same {ids.shape[1]}-frame context, decode frames after prefill (prefill {t_prefill:.2f}s excluded), "
+              f"B={ids.shape[0]}, greedy; thread-count probe " + ", ".join(f"{k}t:{1 / v:.2f}fps" for k, v in probe.items()))
+    rec = dict(value=f32["value"], unit="frames/s", cores=best_nt, threads_used=best_nt, host_cores=ncpu,
+               host_cpu_model=_cpu_model(), kind="port", arith="f32", sample=f"{done} frames; " + sample, f32=f32)
+    # The reference's own dtype for this configuration is bf16 (README.md:73), and that is the faster CPU path: when the
+    # model is bf16, `value` is the bf16 leg -- the same oracle in bf16 arithmetic, same thread count.
+    # Its greedy stream is not comparable token for token (bf16 logits tie and the reference breaks ties with the RNG,
+    # SURVEY.md section 8-c): the fp32 leg beside it carries the token comparison with the GPU.
+    if want_bf16:
+        try:
+            sdb = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+            with torch.inference_mode():
+                out = O.generate_frame(sdb, cfg, ids, mask, 1.0, 1, None, True)
                 cache, prev = out.cache, out.samples
-                done_b += 1
-            rec["bf16"] = dict(value=round(done_b * ids.shape[0] / (time.perf_counter() - t0), 3), unit="frames/s",
-                               threads_used=best_nt, frames=done_b)
-    except Exception as ex:   # the bf16 leg is informative; never let it break the bench line
-        rec["bf16"] = {"error": str(ex)[:200]}
+                t0 = time.perf_counter()
+                done_b = 0
+                while done_b < 2 * frames and time.perf_counter() - t0 < budget_s / 2:
+                    row = torch.cat([prev, torch.zeros(ids.shape[0], 1, dtype=torch.long)], 1).unsqueeze(1)
+                    m1 = torch.zeros(ids.shape[0], 1, C + 1, dtype=mask.dtype)
+                    m1[:, :, :C] = 1
+                    out = O.generate_frame(sdb, cfg, row, m1, 1.0, 1, cache, True)
+                    cache, prev = out.cache, out.samples
+                    done_b += 1
+                rec["bf16"] = dict(value=round(done_b * ids.shape[0] / (time.perf_counter() - t0), 3), unit="frames/s",
+                                   threads_used=best_nt, frames=done_b, arith="bf16")
+            rec["value"], rec["arith"] = rec["bf16"]["value"], "bf16"
+            rec["sample"] = f"{done_b} frames in bf16 arithmetic (the reference's dtype; fp32 leg of {done} frames beside it); " + sample
+        except Exception as ex:   # never let the bf16 leg break the bench line: the fp32 figure stays in `value`
+            rec["bf16"] = {"error": str(ex)[:200]}
     return rec
 
 
@@ -194,17 +198,43 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
     return out
 
 
-def traffic_record(batch: int, ctx: int, weights: str):
-    """the committed PMC record (profiles/hbm_traffic.json) of this workload, or None"""
+def lib_sha256() -> str:
+    """sha256 of the libcsm_hip.so this process runs (the PMC record names the build it was measured on)"""
+    import hashlib
+    from csm_hf_amd.build import LIB
+    path = os.environ.get("CSM_HIP_LIB") or LIB
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return "unreadable"
+
+
+def traffic_record(batch: int, ctx: int, weights: str, opts=()):
+    """the committed PMC record (profiles/hbm_traffic.json) of this workload, or None.  A record carries the sha256 of the
+    library it was measured on (`lib_sha256`, written by tools/pmc_record.py) and the engine options of its run; the caller
+    marks the figure stale when the running build differs."""
     pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         recs = json.load(open(pmc)).get("records", [])
     except Exception:
         return None
     for r in recs:
-        if r.get("batch") == batch and r.get("ctx") == ctx and r.get("weights", "bf16") == weights:
+        if r.get("batch") == batch and r.get("ctx") == ctx and r.get("weights", "bf16") == weights and \
+                sorted(r.get("opts", [])) == sorted(opts):
             return r
     return None
+
+
+def attach_traffic(dst: dict, rec: dict, algorithmic: float = None):
+    """`traffic` fields of a roofline / config4 record from a committed PMC record; `traffic_stale` = the record was
+    measured on another build of the library (or names none)."""
+    dst["traffic"] = rec["hbm_bytes_per_step"]
+    if algorithmic:
+        dst["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_step"] / float(algorithmic), 3)
+    dst["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
+    dst["traffic_lib_sha256"] = rec.get("lib_sha256")
+    dst["traffic_commit"] = rec.get("commit")
+    dst["traffic_stale"] = rec.get("lib_sha256") != lib_sha256()
 
 
 def pin_to_gpu_numa_node(local: int):
@@ -442,7 +472,8 @@ def main():
                         if a.weights == "fp8" else ""), "data": "synthetic",
             "config": {"workload": f"csm-1b ({a.weights}), B={B}/GPU, {a.ctx}-frame synthetic context prefilled (untimed), "
                                    f"{K} timed frame-steps after {W} warm-up, topk={a.topk} T={a.temperature}, "
-                                   f"hipGraph={'on' if use_graph else 'off'}",
+                                   f"hipGraph={'on' if use_graph else 'off'}, kv_dtype={a.kv_dtype}, decode_precision=exact, "
+                                   f"engine options: {' '.join(sorted(a.opt)) if a.opt else 'defaults'}",
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
             "tokens_checksum_per_rank": checks,
             "dist_backend": dist_backend,      # null: single process without a launcher (no process group)
@@ -487,11 +518,10 @@ def main():
         # figure is the separately collected rocprofv3 --pmc measurement of THIS command (tools/collect_pmc.sh: FETCH_SIZE
         # and WRITE_SIZE in their own passes, FETCH_SIZE x 2 for gfx950's wide reads, decode kernels only), committed as
         # profiles/hbm_traffic.json; null when no record matches the workload of this run.
-        rec = traffic_record(B, a.ctx, a.weights)
+        rec = traffic_record(B, a.ctx, a.weights, a.opt)
         if rec is not None:
-            out["roofline"]["traffic"] = rec["hbm_bytes_per_step"]
-            out["roofline"]["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_step"] / float(by), 3)
-            out["roofline"]["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
+            attach_traffic(out["roofline"], rec, by)
+        out["lib_sha256"] = lib_sha256()
         # parity of the benchmarked run against the reference's golden vectors (same context at rank 0, B=1)
         gpath = os.path.join(ROOT, "tests", "golden", "csm1b_cfg2_bf16w_fp32.npz")
         if B == 1 and a.ctx == 512 and a.topk == 1 and a.weights == "bf16" and os.path.exists(gpath):
@@ -519,8 +549,7 @@ def main():
         if c4 is not None:
             rec16 = traffic_record(16, a.ctx, "bf16")      # PMC record of the per-GPU shape of the weak leg (--batch 16)
             if rec16 is not None and c4["weak"]["rows_per_gpu"] == 16:
-                c4["weak"]["traffic"] = rec16["hbm_bytes_per_step"]
-                c4["weak"]["traffic_source"] = rec16.get("source", "profiles/hbm_traffic.json")
+                attach_traffic(c4["weak"], rec16)
             out["config4"] = c4
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -36,6 +36,7 @@ struct AttnArgs {
   int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
   int* tickets;       // nullable, [rows * n_q] zeroed once (self-resetting): with nsplit > 1 the LAST split of a (row, head) to arrive
                       // merges the partials itself -- no attn_combine launch (round 4: one launch less per backbone layer)
+  uint32_t* dbg;      // timeline probe slots (common.h TL_BEGIN) of the attention launch and, 4096 words on, of the combine launch; nullable
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float qs[16 * HD];  // up to 16 q-heads per kv-head
   __shared__ float pb[4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
   const int G = a.n_q / a.n_kv;
   int blk = blockIdx.x;
   int g0 = wave, gstep = 4;
@@ -183,14 +185,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
       }
     }
   }
+  TL_END(3);
 }
 
 // merge the per-split partials: out[row][h][d] = sum_s acc_s e^{m_s-M} / sum_s l_s e^{m_s-M}
 // one wave per (row, head); lane s owns split s (nsplit <= 64), then lane = output dim; all partial
 // loads are issued up front (predicated full unroll).
 template <int HD>
-__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out, bf16_t* oplanes, int pl1) {
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int n_q, int nsplit, float* out, bf16_t* oplanes, int pl1, uint32_t* dbg) {
   const int rh = blockIdx.x, lane = threadIdx.x;
+  TL_BEGIN(dbg);
   const float* pp = part + (size_t)rh * nsplit * (HD + 4);
   float pv[HD / 64][64];
 #pragma unroll
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* part, int
       store_planes(oplanes + (size_t)(row >> 4) * 3 * ps, ps, (rh % n_q) * HD + lane + 64 * i, row & 15, num * inv, pl1 != 0);
     }
   }
+  TL_END(4);
 }
 
 #endif  // CSM_ARGS_ONLY

@@ -30,6 +30,7 @@ struct AttnOprojArgs {
   float* out;            // residual stream [N], updated in place (batched form: [rows][ldo])
   int beside_streamer;   // host-side: refuse (-2) when a workgroup of this launch does not fit beside a resident streamer wave
   int dbg_onekey;        // TIMING ONLY (wrong results): every lane loads key 0 -- the launch without its K/V traffic
+  uint32_t* dbg;         // timeline probe slot (common.h TL_BEGIN), nullable
 };
 // (A batched form of this fusion -- one workgroup per (64-output slice, batch row) -- was measured SLOWER than the stand-alone
 //  attention + matrix-core o_proj pair at B = 16 (5.58 vs 5.09 ms per step: every workgroup pulls its row's K/V tiles once per
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
   using Tile = AttnTile32<KT, HD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[n_q][HD] | att[n_q][HD] | p[n_q][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
   const int nq = a.n_q, K = nq * HD;
   const int kpt = K >= 1024 ? 16 : 8, tpr = K / kpt;   // k per thread, threads per output row (32 or 64)
   float* qs = lds + wave * HD;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
   s = xor16_sum(s);
   if (tpr == 64) s = xor32_sum(s);
   if (part == 0) a.out[n] = resid + s * ws;
+  TL_END(2);
 }
 
 #endif  // CSM_ATTN_OPROJ_KERNEL

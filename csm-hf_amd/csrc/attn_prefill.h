@@ -237,8 +237,11 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   // dispatch order instead: no change -- the dispatcher is round-robin over the CUs.)
   int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
   if (a.map == 1) {
-    const int n = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if ((n >> 8) & 1) qt = blockIdx.x;
+    // the direction is chosen ONCE per (kv-head, sequence) row of the grid -- from the linear id of the row's first workgroup --
+    // so that every query tile of the row is computed exactly once whatever gridDim.x is (round-4 form flipped on bit 8 of
+    // the workgroup's own linear id: a 256-boundary inside a row left tiles uncomputed when ceil(S/32) did not divide 256)
+    const unsigned row0 = gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((row0 >> 8) & 1) qt = blockIdx.x;
   }
   const int j = blockIdx.y, b = blockIdx.z;
   const int s0 = qt * 32;

@@ -5,6 +5,25 @@
 
 #define CSM_WAVE 64
 
+// ---- in-step timeline probe (tools/b1_timeline.py builds libcsm_hip_timeline.so with -DCSM_TIMELINE): every workgroup of every
+// decode-path launch records the 100 MHz constant clock (s_memrealtime: the same counter on all XCDs) at kernel entry and after
+// its last store into this launch's slot [2048 workgroups][2] of the debug buffer (csm_set_debug_buffer); workgroup 0 tags the
+// slot with the kernel kind and grid size.  Compiled out of the product build (an s_memrealtime at entry is an SMEM wait).
+#ifdef CSM_TIMELINE
+#define TL_BEGIN(ptr) uint32_t* const tl_p_ = (ptr); const uint32_t tl_t0_ = tl_p_ ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u
+#define TL_END(kind)                                                                                                   \
+  do {                                                                                                                 \
+    if (tl_p_ && threadIdx.x == 0) {                                                                                   \
+      const unsigned b_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                              \
+      if (b_ < 2047u) { tl_p_[2 * b_] = tl_t0_; tl_p_[2 * b_ + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }      \
+      if (b_ == 0) tl_p_[4094] = (uint32_t)(kind) | ((gridDim.x * gridDim.y * gridDim.z) << 8);                        \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define TL_BEGIN(ptr)
+#define TL_END(kind)
+#endif
+
 typedef uint16_t bf16_t;  // raw bf16 bits; all arithmetic is done in fp32
 struct fp8_t { uint8_t v; };  // OCP e4m3fn byte (gfx950 v_cvt_*_fp8 is OCP, not fnuz); distinct type for overloads
 typedef __attribute__((ext_vector_type(2))) float f32x2;

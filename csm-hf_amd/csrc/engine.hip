@@ -239,6 +239,7 @@ struct csm_engine {
   std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
   uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
   int dbg_launches = 0;
+  int tl_n = 0;                            // timeline probe: slots handed out during the current capture
   long long pf_last[4] = {0, 0, 0, 0};
   int pf_last_frames = 0;   // schedule of the last replayed graph: segments, launches, scheduled bytes, streamed-launch bytes
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -609,6 +610,20 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   return 0;
 }
 
+// timeline probe (-DCSM_TIMELINE build, tools/b1_timeline.py): while a frame-step is captured with a debug buffer set, every
+// decode-path launch gets the next 4096-word slot, in launch order; null otherwise
+static uint32_t* tl_slot(csm_engine* e, int n = 1) {
+#ifdef CSM_TIMELINE
+  if (!e->pf_rec || !e->dbg_buf || e->tl_n + n > e->dbg_launches) return nullptr;
+  uint32_t* p = e->dbg_buf + (size_t)e->tl_n * 4096;
+  e->tl_n += n;
+  return p;
+#else
+  (void)e; (void)n;
+  return nullptr;
+#endif
+}
+
 // ---- decode-side GEMV with row grouping (M <= 4 per launch) -----------------------------------------
 static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
   const float* x = a.x;
@@ -686,7 +701,11 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     PfGeom geom{};
     geom.kind = -1;
     if (e->pf_rec) { a.prog = e->d_prog; a.geom_out = &geom; }   // capture: this launch is paced / streamed (prefetch.h)
+#ifdef CSM_TIMELINE
+    a.dbg = tl_slot(e);
+#else
     if (e->pf_rec && e->dbg_buf && (int)e->pf_rec->size() < e->dbg_launches) a.dbg = e->dbg_buf + e->pf_rec->size() * 4096;
+#endif
     const int r = launch_gemv(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a);
     a.prog = nullptr; a.geom_out = nullptr; a.dbg = nullptr;
     if (r) return r;
@@ -748,6 +767,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.pos_ptr = pos_ptr; f.pos_const = pos_const; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h;
     f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
     f.dbg_onekey = (e->dbg_skip >> 7) & 1;
+    f.dbg = tl_slot(e);
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
   }
@@ -764,6 +784,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     const bool att_planes = planes && (e->use_planes & 4);
     t.oplanes = att_planes ? e->pl_act : nullptr;
     t.pl1 = e->decode_bf16;
+    t.dbg = tl_slot(e, (nsplit > 1 && !t.tickets) ? 2 : 1);
     if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;
     if (att_planes) o.xplanes = e->pl_act;
@@ -828,6 +849,7 @@ static int backbone_step_impl(csm_engine* e, const csm_sampling_t* s, bool from_
   // batched decode on planes: the embedding sum hands layer 0 its operands like every later producer does
   const bool em_planes = planes_on(e, e->bb, B) && (e->use_planes & 16);
   if (em_planes) { em.oplanes = e->pl_h; em.oln = e->bb.layers[0].ln1; em.oss = e->pl_ss; em.oss_ld = PL_SS_LD; em.pl1 = e->decode_bf16; }
+  em.dbg = tl_slot(e);
   LCK(launch_embed(e->stream, emb_dtype(e), B, em));
   for (int l = 0; l < e->bb.c.layers; ++l)
     LCK(layer_decode(e, e->bb, l, B, e->h_bb, Hb, e->d_len, 0, e->q_bb, e->att_bb, e->part_bb, e->nsplit_eff(), e->act_bb, e->nt_backbone,
@@ -871,6 +893,7 @@ static int decoder_two_token_pass(csm_engine* e, float* x2) {
       AttnArgs t{};
       t.q = e->q_dec2; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
       t.row_seq = e->d_seq00; t.row_pos = e->d_pos01; t.nsplit = 1; t.out = e->att_dec2; t.one_wave = e->attn_one_wave & 1;
+      t.dbg = tl_slot(e);
       LCK(launch_attn(e->stream, e->cfg.kv_dtype, 2, t));
       GemvArgs o{};
       o.nt = nt_small; o.W = w.wo; o.wscale = w.so; o.N = H; o.K = A; o.x = e->att_dec2; o.ldx = A; o.out = x2; o.ldo = H;
@@ -895,6 +918,7 @@ static int decoder_two_token_pass(csm_engine* e, float* x2) {
         f.q = q1; f.kcache = s.kc[l]; f.vcache = s.vc[l]; f.n_q = nq; f.n_kv = nkv; f.hd = hd; f.lmax = s.lmax;
         f.pos_ptr = nullptr; f.pos_const = 1; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h1;
         f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
+        f.dbg = tl_slot(e);
         ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
         if (ao != -2) LCK(ao);
       }
@@ -902,6 +926,7 @@ static int decoder_two_token_pass(csm_engine* e, float* x2) {
         AttnArgs t{};
         t.q = q1; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
         t.pos_ptr = nullptr; t.pos_const = 1; t.nsplit = 1; t.out = e->att_dec2; t.one_wave = e->attn_one_wave & 1;
+        t.dbg = tl_slot(e);
         LCK(launch_attn(e->stream, e->cfg.kv_dtype, 1, t));
         GemvArgs o{};
         o.nt = nt_small; o.W = w.wo; o.wscale = w.so; o.N = H; o.K = A; o.x = e->att_dec2; o.ldx = A; o.out = h1; o.ldo = H;
@@ -940,6 +965,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     if (planes_on(e, e->dec, B) && (e->use_planes & 8)) {
       a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16; a.pl1 = e->decode_bf16;
     }
+    a.dbg = tl_slot(e);
     return launch_sample(e->stream, B, a);
   };
   // B == 1 greedy without traces: codebooks 1..C-2 need no sampler launch -- the head writes per-task argmax
@@ -1803,6 +1829,7 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       std::vector<PfGeom> geoms;
       HIPCK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
       e->pf_rec = &geoms;
+      e->tl_n = 0;
       int r = decode_frame_impl(e, s);
       if (!r) r = backbone_step_impl(e, s, false, true, want_h);
       e->pf_rec = nullptr;

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   __shared__ float part[4][2 * T * M];
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
 #ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
   const unsigned long long dbg_t0 = __builtin_readcyclecounter();   // before the first kernel argument is read
 #endif
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }
+  TL_END(0x10 + EPI + 8 * PRO);
 }
 
 template <typename WT, typename KT, int M, int PRO, int EPI, int KS>
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int U = 4;
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
   if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;
@@ -679,6 +682,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }
+  TL_END(0x40 + EPI + 8 * PRO);
 }
 
 #endif  // CSM_ARGS_ONLY

@@ -31,8 +31,8 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (e) return e;
   if (a.nsplit > 1 && !a.tickets) {
     if (a.nsplit > 64) return -1;
-    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1);
-    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1);
+    if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
+    else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
     e = (int)hipGetLastError();
   }
   return e;

@@ -32,6 +32,7 @@ struct EmbedArgs {
   const float* oln;  // [H] the consumer's norm weight
   float* oss;        // [rows][oss_ld]
   int oss_ld;
+  uint32_t* dbg;     // timeline probe slot (common.h TL_BEGIN), nullable
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
   __shared__ float part[4][512];
   __shared__ int nz[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
   const int k = blockIdx.y * 512 + lane * 8;
   const WT* te = reinterpret_cast<const WT*>(a.text_emb);
   const WT* ae = reinterpret_cast<const WT*>(a.audio_emb);
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedArgs a) {
     atomicAdd(a.zero_count + f, 1);
     if (a.row_done) a.row_done[row] = 1;
   }
+  TL_END(6);
 }
 
 #endif  // CSM_ARGS_ONLY
@@ -472,6 +475,7 @@ struct SampleArgs {
   const float* copy_src;
   float* copy_dst;
   int copy_n;
+  uint32_t* dbg;        // timeline probe slot (common.h TL_BEGIN), nullable
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ int s_wsum[4];
   __shared__ float s_mn[4];
   const int row = blockIdx.x, tid = threadIdx.x;
+  TL_BEGIN(a.dbg);
   const int V = a.V;
   const float* lg = a.logits + (size_t)row * a.ldl;
   const int f = a.frame_ptr ? *a.frame_ptr : 0;
@@ -789,6 +794,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
       if (tid < a.oss_n) a.oss[(size_t)row * a.oss_ld + tid] = tid == 0 ? (s_val[0] + s_val[1]) + (s_val[2] + s_val[3]) : 0.f;
     }
   }
+  TL_END(5);
 }
 #endif  // CSM_ARGS_ONLY
 
