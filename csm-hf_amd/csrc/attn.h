@@ -36,6 +36,8 @@ struct AttnArgs {
   int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
   int* tickets;       // nullable, [rows * n_q] zeroed once (self-resetting): with nsplit > 1 the LAST split of a (row, head) to arrive
                       // merges the partials itself -- no attn_combine launch (round 4: one launch less per backbone layer)
+  int gqa;            // host-side: 1 = attn_decode_gqa_kernel (head_dim 64, n_q / n_kv = 4: the key quarters of a split on the workgroup's four waves)
+  int no_combine;     // host-side: 1 = with nsplit > 1 leave the partials to the consumer (gemv.h gemv1_combine_kernel): no attn_combine launch
   uint32_t* dbg;      // timeline probe slots (common.h TL_BEGIN) of the attention launch and, 4096 words on, of the combine launch; nullable
 };
 
@@ -186,6 +188,94 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
   }
   TL_END(3);
+}
+
+// ---- round 5: single-sequence backbone attention with the K/V tiles SHARED by the G = 4 query heads of a kv-head ------------
+// attn_decode_kernel gives every query head of a kv-head its own wave, and each of those waves pulls the same K and V tile:
+// the workgroup's vector-memory instruction count (16 clocks each through the CU's one texture path) is what bounds it once a
+// workgroup walks more than one tile (profiles/r05_b1_timeline.md).  Here the 4 waves of a workgroup (row, kv-head, split) each
+// take a QUARTER of the split's keys for ALL G query heads -- a quarter of the tile loads per workgroup -- and their per-wave
+// online-softmax partials meet in LDS, one wave per head merging them.  That makes long splits affordable: 8 splits (64
+// workgroups) at a 512-frame context instead of 32, which in turn lets the o_proj launch merge the split partials in its own
+// prologue (gemv.h gemv1_combine_kernel) -- the attn_combine launch of the B = 1 backbone layer is gone.  head_dim 64, G = 4.
+template <typename KT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_decode_gqa_kernel(AttnArgs a) {
+  constexpr int HD = 64, G = 4;
+  using Tile = AttnTile32<KT, HD>;
+  __shared__ __attribute__((aligned(16))) float qs[4][G * HD];   // wave-private copies of the G query heads
+  __shared__ float pb[4][32];
+  __shared__ __attribute__((aligned(16))) float wpart[4][G][HD];
+  __shared__ float wstat[4][G][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
+  int blk = blockIdx.x;
+  const int sp = blk % a.nsplit;
+  blk /= a.nsplit;
+  const int j = blk % a.n_kv;
+  const int row = blk / a.n_kv;
+  const int b = a.row_seq ? a.row_seq[row] : row;
+  const int pos = row_position(a.row_pos, row, a.pos_ptr, a.pos_const);
+  const int t_lo0 = a.kv_start ? a.kv_start[b] : 0;
+  const int len = pos + 1 - t_lo0;
+  int span = (len + a.nsplit - 1) / a.nsplit;
+  span = (span + 15) & ~15;                       // a multiple of 16: the waves' quarters start on 64-byte boundaries of the K rows
+  const int t_lo = t_lo0 + sp * span;
+  const int t_hi = min(t_lo + span, pos + 1);
+  const int wspan = span >> 2;
+  const int w_lo = t_lo + wave * wspan;
+  const int w_hi = min(w_lo + wspan, t_hi);
+  const KT* kc = reinterpret_cast<const KT*>(a.kcache) + ((size_t)b * a.n_kv + j) * (size_t)(HD / 4) * a.lmax * 4;
+  const KT* vc = reinterpret_cast<const KT*>(a.vcache) + ((size_t)b * a.n_kv + j) * (size_t)a.lmax * HD;
+  Tile tile;
+  if (w_lo < w_hi) tile.load(kc, vc, a.lmax, w_lo, min(32, w_hi - w_lo), lane);   // in flight during the q staging
+  {
+    const float* qsrc = a.q + (size_t)row * a.n_q * HD + (size_t)(j * G) * HD + lane * 4;
+    *reinterpret_cast<f32x4*>(&qs[wave][lane * 4]) = *reinterpret_cast<const f32x4*>(qsrc);
+  }
+  __builtin_amdgcn_wave_barrier();
+  float m_run[G], l_run[G];
+  f32x4 acc[G];
+#pragma unroll
+  for (int h = 0; h < G; ++h) { m_run[h] = -INFINITY; l_run[h] = 0.f; acc[h] = (f32x4)(0.f); }
+  for (int t0 = w_lo; t0 < w_hi; t0 += 32) {
+    const int cnt = min(32, w_hi - t0);
+    Tile nxt;
+    const bool more = t0 + 32 < w_hi;
+    if (more) nxt.load(kc, vc, a.lmax, t0 + 32, min(32, w_hi - t0 - 32), lane);   // the next tile is requested before this one is consumed
+#pragma unroll
+    for (int h = 0; h < G; ++h) tile.accumulate(&qs[wave][h * HD], pb[wave], cnt, lane, m_run[h], l_run[h], acc[h]);
+    if (more) tile = nxt;
+  }
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    const f32x4 o = Tile::reduce(acc[h]);
+    if (lane < Tile::LPR) *reinterpret_cast<f32x4*>(&wpart[wave][h][4 * lane]) = o;
+    if (lane == 0) { wstat[wave][h][0] = m_run[h]; wstat[wave][h][1] = l_run[h]; }
+  }
+  __syncthreads();
+  {   // wave w merges query head j * G + w over the four key quarters; lane = output dim
+    const int h = wave;
+    float mj[4], lj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mj[q] = wstat[q][h][0]; lj[q] = wstat[q][h][1]; }
+    const float M = fmaxf(fmaxf(mj[0], mj[1]), fmaxf(mj[2], mj[3]));
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float al = mj[q] == -INFINITY ? 0.f : __expf(mj[q] - M);
+      L = fmaf(lj[q], al, L);
+      o = fmaf(al, wpart[q][h][lane], o);
+    }
+    const int hq = j * G + h;
+    if (a.nsplit == 1) {
+      a.out[(size_t)row * a.n_q * HD + (size_t)hq * HD + lane] = o * (1.f / L);
+    } else {
+      float* pp = a.part + (((size_t)row * a.n_q + hq) * a.nsplit + sp) * (HD + 4);
+      pp[lane] = o;
+      if (lane == 0) { pp[HD] = M; pp[HD + 1] = L; }   // an empty split: M = -inf, L = 0, o = 0
+    }
+  }
+  TL_END(8);
 }
 
 // merge the per-split partials: out[row][h][d] = sum_s acc_s e^{m_s-M} / sum_s l_s e^{m_s-M}

@@ -196,6 +196,10 @@ struct csm_engine {
                              // bit 1 batched rows (measured SLOWER at B = 16, 5.58 vs 5.09 ms: off)
   static constexpr int use_mfma = 1;
   static constexpr int flash_prefill = 1;
+  int stream_attn_oproj = 0;   // the fused decoder attention + o_proj launch in the weight streamer's schedule (round 2 form: slower; re-measured in round 5)
+  int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
+  int cmb_splits = 8;        // its split count (<= 8)
+  int attn_oproj_gqa = 1;    // the fused launch in its key-split form (attn_oproj_gqa_kernel: K/V tiles shared by the query heads of a kv-head)
   int fuse_sample = 1;   // B == 1 greedy: argmax folded into the head launch + next QKV prologue
   float2* am_part = nullptr;
   float* g16_slabs = nullptr;
@@ -208,6 +212,7 @@ struct csm_engine {
   // keeping at least ~256 workgroups; frozen into the graph at capture time.
   int nsplit_eff() const {
     if (nsplit_bb > 0) return nsplit_bb;
+    if (B == 1 && oproj_combine && cfg.backbone.head_dim == 64 && cfg.backbone.n_q == 4 * cfg.backbone.n_kv && cfg.backbone.n_q * 64 == 2048) return cmb_splits;
     int by_len = (h_len + 256 + 63) / 64;
     if (B >= 32) by_len = (by_len + 7) / 8;      // 32-64 rows: 256-512 (row, kv-head) pairs already fill the chip -- 2 splits at a 512-frame
                                                  // context: B = 64 frame-step 9.48 -> 9.25 ms (8 splits -> 2; profiles/r03_b64_rows64.txt)
@@ -576,6 +581,10 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   if (!e || !name) return fail(CSM_ERR_ARG, "null argument");
   if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
+  else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
+  else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value ? 1 : 0;
+  else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
+  else if (!strcmp(name, "combine_splits")) e->cmb_splits = value < 2 ? 2 : (value > 8 ? 8 : value);
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
   else if (!strcmp(name, "two_token_pass")) e->two_token_pass = value;
   else if (!strcmp(name, "use_planes")) e->use_planes = value;
@@ -768,10 +777,32 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
     f.dbg_onekey = (e->dbg_skip >> 7) & 1;
     f.dbg = tl_slot(e);
+    f.gqa = e->attn_oproj_gqa;
+    const bool rec = e->pf_rec && e->stream_attn_oproj;   // its 2 MB of weights in the streamer's schedule too
+    if (rec) f.prog = e->d_prog;
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
+    if (ao != -2 && rec) {
+      PfGeom g{};
+      const int K = nq * hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * nq / tpr;   // rows per workgroup (launchers.hip)
+      g.W = w.wo; g.N = H; g.K = K; g.esz = (int)w_esz(e); g.kind = 0; g.grid = H / rows; g.tpb = rows / 2; g.iters = 1; g.stride = 0;
+      g.ntask = H / 2; g.hd = hd; g.n_rope_heads = 0;
+      e->pf_rec->push_back(g);
+    }
   }
+  // B = 1 backbone (round 5): attention on few long splits with the K/V tiles shared by the query heads of a kv-head
+  // (attn_decode_gqa_kernel), the split merge folded into the o_proj launch (gemv1_combine_kernel): five launches per layer
+  const bool cmb = M == 1 && &s == &e->bb && e->oproj_combine && hd == 64 && nq == 4 * nkv && nq * hd == 2048 && nsplit > 1 && nsplit <= 8;
   if (ao != -2) {
+  } else if (cmb) {
+    AttnArgs t{};
+    t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
+    t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = e->d_kv_start;
+    t.nsplit = nsplit; t.out = att; t.part = part; t.gqa = 1; t.no_combine = 1;
+    t.dbg = tl_slot(e);
+    if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, 1, t));
+    o.cmb_part = part; o.cmb_ns = nsplit; o.x = nullptr;
+    if (!(sk & 4)) LCK(gemv_rows(e, 1, PRO_COMBINE, EPI_RESID, o));
   } else {
     AttnArgs t{};
     t.q = qb; t.kcache = s.kc[l]; t.vcache = s.vc[l]; t.n_q = nq; t.n_kv = nkv; t.hd = hd; t.lmax = s.lmax;
@@ -919,6 +950,7 @@ static int decoder_two_token_pass(csm_engine* e, float* x2) {
         f.pos_ptr = nullptr; f.pos_const = 1; f.W = w.wo; f.wscale = w.so; f.N = H; f.out = h1;
         f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
         f.dbg = tl_slot(e);
+        f.gqa = e->attn_oproj_gqa;
         ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
         if (ao != -2) LCK(ao);
       }

@@ -22,7 +22,7 @@
 #include "attn_tile.h"
 #endif
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_TOKNORM = 3 };
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_TOKNORM = 3 };   // PRO_COMBINE: gemv1_combine_kernel (the B = 1 backbone o_proj)
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
 
 struct GemvArgs {
@@ -80,6 +80,9 @@ struct GemvArgs {
   const int* tok_frame_ptr;
   int tok_max_frames, tok_C, tok_cb;
   float* tok_x_out;        // [K] residual stream of the new pass (written by workgroup 0)
+  // ---- PRO_COMBINE (B == 1 backbone o_proj): x is the split-KV attention output, merged here from the per-split partials
+  const float* cmb_part;   // [K / 64 heads][cmb_ns][64 + 4]: acc[64], m, l (attn.h: attn_decode_*_kernel with nsplit > 1)
+  int cmb_ns;              // splits (<= 8)
   int configure_only;  // host-side: only set the kernel's dynamic-LDS attribute, do not launch
   int force_generic;   // host-side: skip the M == 1 register fast path (A/B measurements)
   int no_mfma;         // host-side: rows >= 2 stay on the fp32-FMA kernel (two-token decoder pass: a row's arithmetic is then
@@ -451,6 +454,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     if (a.bump_b) *a.bump_b += 1;
   }
   TL_END(0x10 + EPI + 8 * PRO);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// B = 1 backbone o_proj with the split-KV merge as its prologue (round 5): out[n] += W[n, :] . att, where
+// att[h][d] = sum_s e^{m_s - M} acc_s[h][d] / sum_s e^{m_s - M} l_s is never written to memory.  Replaces the
+// attn_combine launch + the plain o_proj GEMV (one launch boundary and one cold activation round trip less per
+// backbone layer).  K == 2048 == 32 heads x 64: wave w of a workgroup merges heads 8w .. 8w + 7 (a lane: 8 dims of one
+// head, <= 8 splits -- the partial loads are issued with the weight loads, in front of them: they are consumed first),
+// the four quarters meet in LDS behind an LDS-only barrier (the weight loads stay in flight), then every wave multiplies
+// its row pair exactly like gemv1_kernel<PRO_PLAIN, EPI_RESID, U = 4> (pair accumulators, ascending chunks, wave_sum2).
+// ---------------------------------------------------------------------------------------------------
+template <typename WT, int SMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemv1_combine_kernel(GemvArgs a) {
+  constexpr int U = 4, HD = 64, K = 2048;
+  __shared__ __attribute__((aligned(16))) float xs[K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
+  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
+  const int ntask = (a.N + 1) >> 1;
+  const GemvTask k = gemv_map_task<EPI_RESID>(a, blockIdx.x * 4 + wave, ntask);
+  GemvEpi<float, EPI_RESID, 1> epi;
+  epi.prefetch(a, k);
+  const int S = a.cmb_ns;
+  const int h = wave * 8 + (lane >> 3), d0 = (lane & 7) * 8;
+  const float* pp = a.cmb_part + (size_t)h * S * (HD + 4);
+  f32x4 pa[SMAX], pb[SMAX];
+  f32x2 st[SMAX];
+  // every load is unconditional (a split beyond cmb_ns re-reads the last one and gets weight 0 below): with the loads inside
+  // `if (s < S)` the compiler put a vmcnt wait behind each split's loads -- eight dependent round trips, 8.6 us per launch
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) {
+    const int sc = s < S ? s : S - 1;
+    pa[s] = *reinterpret_cast<const f32x4*>(pp + sc * (HD + 4) + d0);
+    pb[s] = *reinterpret_cast<const f32x4*>(pp + sc * (HD + 4) + d0 + 4);
+    st[s] = *reinterpret_cast<const f32x2*>(pp + sc * (HD + 4) + HD);
+  }
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const int e0 = lane * 8;
+  W8<WT> w0[U], w1[U];
+  {
+    const WT* w0p = W + (size_t)(k.live ? k.r0 : 0) * K + e0;
+    const WT* w1p = W + (size_t)(k.has1 ? k.r1 : (k.live ? k.r0 : 0)) * K + e0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (a.nt) { w0[u].load_nt(w0p + u * 512); w1[u].load_nt(w1p + u * 512); }
+      else { w0[u].load(w0p + u * 512); w1[u].load(w1p + u * 512); }
+    }
+  }
+  {
+    float Mx = st[0][0];
+#pragma unroll
+    for (int s = 1; s < SMAX; ++s) Mx = fmaxf(Mx, st[s][0]);   // (a repeated split does not change the max)
+    float L = 0.f;
+    f32x4 xa = (f32x4)(0.f), xb = (f32x4)(0.f);
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const float al = (s >= S || st[s][0] == -INFINITY) ? 0.f : __expf(st[s][0] - Mx);
+      L = fmaf(st[s][1], al, L);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xa[c] = fmaf(al, pa[s][c], xa[c]); xb[c] = fmaf(al, pb[s][c], xb[c]); }
+    }
+    const float inv = 1.f / L;
+    *reinterpret_cast<f32x4*>(xs + wave * 512 + lane * 8) = xa * inv;
+    *reinterpret_cast<f32x4*>(xs + wave * 512 + lane * 8 + 4) = xb * inv;
+  }
+  lds_barrier();
+  f32x2 c0 = f32x2{0.f, 0.f}, c1 = f32x2{0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + e0 + u * 512), xb = *reinterpret_cast<const f32x4*>(xs + e0 + u * 512 + 4);
+    const f32x2 xp[4] = {f32x2{xa[0], xa[1]}, f32x2{xa[2], xa[3]}, f32x2{xb[0], xb[1]}, f32x2{xb[2], xb[3]}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c0 = PKFMA(w0[u].pair(i), xp[i], c0);
+      c1 = PKFMA(w1[u].pair(i), xp[i], c1);
+    }
+  }
+  float s0 = c0[0] + c0[1], s1 = c1[0] + c1[1];
+  wave_sum2(s0, s1);
+  if (lane == 0 && k.live) epi.store(a, k, 0, s0, s1);
+  TL_END(0x10 + EPI_RESID + 8 * PRO_COMBINE);
 }
 
 template <typename WT, typename KT, int M, int PRO, int EPI, int KS>

@@ -13,6 +13,15 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.nsplit < 1 || a.nsplit > 64) return -1;
   if (a.oplanes && rows > 128) return -1;
   const int G = a.n_q / a.n_kv;
+  if (a.gqa && a.hd == 64 && G == 4 && !a.oplanes && !a.tickets) {
+    const int g2 = rows * a.n_kv * a.nsplit;
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_gqa_kernel<bf16_t>), dim3(g2), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_decode_gqa_kernel<float>), dim3(g2), dim3(256), 0, st, a);
+    int e = (int)hipGetLastError();
+    if (e || a.nsplit == 1 || a.no_combine) return e;
+    hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
+    return (int)hipGetLastError();
+  }
   const int grid = rows * a.n_kv * a.nsplit * (a.one_wave ? G : 1);
   const int bd = a.one_wave ? 64 : 256;
   if (a.hd == 64) {
@@ -29,7 +38,7 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   }
   int e = (int)hipGetLastError();
   if (e) return e;
-  if (a.nsplit > 1 && !a.tickets) {
+  if (a.nsplit > 1 && !a.tickets && !a.no_combine) {
     if (a.nsplit > 64) return -1;
     if (a.hd == 64) hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
     else hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
@@ -193,7 +202,9 @@ static int launch_attn_oproj_t(hipStream_t st, const AttnOprojArgs& a) {
   const int K = a.n_q * a.hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * a.n_q / tpr;
   const dim3 grid(a.N / rows), block(64 * a.n_q);
   const size_t lds = ((size_t)2 * a.n_q * a.hd + (size_t)a.n_q * 32) * sizeof(float);
-  const void* fn = a.hd == 64 ? (const void*)attn_oproj_kernel<KT, WT, 64> : (const void*)attn_oproj_kernel<KT, WT, 128>;
+  const bool gqa = a.gqa && a.hd == 128 && a.n_q == 8 && a.n_kv == 2 && a.N % 8 == 0;
+  const void* fn = gqa ? (const void*)attn_oproj_gqa_kernel<KT, WT>
+                       : (a.hd == 64 ? (const void*)attn_oproj_kernel<KT, WT, 64> : (const void*)attn_oproj_kernel<KT, WT, 128>);
   if (a.beside_streamer) {
     // the weight streamer keeps one 72-register wave on every SIMD: a workgroup of this launch (n_q / 4 waves per SIMD)
     // must fit beside it, or the chain would stall until the streamer gives up (registers are allocated in blocks of 8)
@@ -201,6 +212,11 @@ static int launch_attn_oproj_t(hipStream_t st, const AttnOprojArgs& a) {
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -2;
     const int alloc = (fa.numRegs + 7) & ~7, per_simd = (a.n_q + 3) / 4;
     if (per_simd * alloc + ((PF_STREAMER_VGPRS + 7) & ~7) > 512) return -2;
+  }
+  if (gqa) {
+    const size_t lds2 = ((size_t)8 * 4 * 128 * 2 + 8 * 128 + 8 * 4 * 2) * sizeof(float);
+    hipLaunchKernelGGL((attn_oproj_gqa_kernel<KT, WT>), dim3(a.N / 8), dim3(512), lds2, st, a);
+    return (int)hipGetLastError();
   }
   if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 64>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 128>), grid, block, lds, st, a);
