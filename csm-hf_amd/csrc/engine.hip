@@ -196,6 +196,7 @@ struct csm_engine {
                              // bit 1 batched rows (measured SLOWER at B = 16, 5.58 vs 5.09 ms: off)
   static constexpr int use_mfma = 1;
   static constexpr int flash_prefill = 1;
+  int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
   int stream_attn_oproj = 0;   // the fused decoder attention + o_proj launch in the weight streamer's schedule (round 2 form: slower; re-measured in round 5)
   int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
   int cmb_splits = 8;        // its split count (<= 8)
@@ -233,7 +234,9 @@ struct csm_engine {
   unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
   unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
-  int pf_enable = 1, pf_window_mb = 24; static constexpr int pf_sub_kb = 4096, pf_grid = 256;
+  int pf_enable = 1, pf_window_mb = 6, pf_sub_kb = 4096; static constexpr int pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
+  // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
+  // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
   static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
   static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
   static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
@@ -582,6 +585,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
+  else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
   else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value ? 1 : 0;
   else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
   else if (!strcmp(name, "combine_splits")) e->cmb_splits = value < 2 ? 2 : (value > 8 ? 8 : value);
@@ -610,6 +614,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "rows64")) e->rows64 = value < 0 ? -1 : (value ? 1 : 0);   // -1: 16-row launches only (tests: every wider form against gemm16_kernel)
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
+  else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -757,7 +762,8 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     a.am_in = tok->am_in; a.am_n = tok->am_n; a.tok_table = tok->tok_table; a.tok_row_base = tok->tok_row_base;
     a.tok_forced = tok->tok_forced; a.tok_ring = tok->tok_ring; a.tok_frame_ptr = tok->tok_frame_ptr;
     a.tok_max_frames = tok->tok_max_frames; a.tok_C = tok->tok_C; a.tok_cb = tok->tok_cb; a.tok_x_out = h;
-    LCK(gemv_rows(e, M, PRO_TOKNORM, EPI_QKV, a));
+    a.smp = tok->smp; a.smp_row_done = tok->smp_row_done;
+    LCK(gemv_rows(e, M, tok->am_in ? PRO_TOKNORM : PRO_SAMPLE, EPI_QKV, a));
   } else if (!(sk & 1)) {
     LCK(gemv_rows(e, M, PRO_NORM, EPI_QKV, a));
   }
@@ -998,6 +1004,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       a.oplanes = e->pl_h; a.oln = e->dec.layers[0].ln1; a.oss = e->pl_ss; a.oss_ld = PL_SS_LD; a.oss_n = Hd / 16; a.pl1 = e->decode_bf16;
     }
     a.dbg = tl_slot(e);
+    a.spin_ticks = e->dbg_sample_spin;
     return launch_sample(e->stream, B, a);
   };
   // B == 1 greedy without traces: codebooks 1..C-2 need no sampler launch -- the head writes per-task argmax
@@ -1005,17 +1012,27 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
   const bool greedy = s->topk <= 1 || s->temperature == 0.f;
   const bool fused = e->fuse_sample && B == 1 && greedy && !s->noise && !s->logits_trace && Hd % 512 == 0 && Hd <= 1024 &&
                      (V + 1) / 2 <= 1088;
+  // B == 1 top-k sampling without traces (round 5): codebooks 1..C-2 need no sampler launch either -- the head writes its logits
+  // and every wave of the next pass's first QKV launch draws the token itself (sample_wave.h: sample_kernel's arithmetic, no
+  // workgroup barrier), under that launch's weight loads
+  const bool fused_smp = e->fuse_sample && B == 1 && !greedy && !s->logits_trace && Hd % 512 == 0 && Hd <= 1024 && V <= WS_VMAX && V >= WS_VMIN;
   LCK(sample(0, e->head_out + Hd, e->ld_head));
   if (two_tok) LCK(decoder_two_token_pass(e, e->dec_x2));
   for (int p = two_tok ? 1 : 0; p < C; ++p) {
     float* h = p == 0 ? e->head_out : decx;
     const int ldh = p == 0 ? e->ld_head : Hd;
     GemvArgs tok{};
-    const bool use_tok = fused && p >= 2;   // input of pass p = token of codebook p-1 (sampled by head p-1)
+    const bool use_tok = (fused || fused_smp) && p >= 2;   // input of pass p = token of codebook p-1 (sampled by head p-1)
     if (use_tok) {
       tok.am_in = e->am_part; tok.am_n = (V + 1) / 2; tok.tok_table = e->w.proj_table; tok.tok_row_base = (p - 1) * V;
       tok.tok_forced = s->forced; tok.tok_ring = e->ring; tok.tok_frame_ptr = e->d_frame;
       tok.tok_max_frames = e->cfg.max_frames; tok.tok_C = C; tok.tok_cb = p - 1;
+      if (fused_smp) {
+        tok.am_in = nullptr;
+        tok.smp.logits = e->logits_dec; tok.smp.V = V; tok.smp.temperature = s->temperature; tok.smp.topk = s->topk;
+        tok.smp.rng = e->d_rng; tok.smp.noise = s->noise ? s->noise + (size_t)(p - 1) * V : nullptr; tok.smp.cb = p - 1;
+        tok.smp_row_done = s->per_row_stop ? e->d_row_done : nullptr;
+      }
     }
     for (int l = 0; l < e->dec.c.layers && !(two_tok && p == 1); ++l)
       LCK(layer_decode(e, e->dec, l, B, h, ldh, nullptr, p, e->q_dec, e->att_dec, nullptr, 1, e->act_dec, e->nt_decoder,
@@ -1032,6 +1049,15 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
       a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
       a.out = e->logits_dec; a.ldo = (V + 3) & ~3; a.am_out = e->am_part; a.am_from = 0;
       if (!(e->dbg_skip & 64)) LCK(gemv_rows(e, B, PRO_NORM, EPI_ARGMAX, a));   // dbg_skip bit 6: the fused-argmax head launches (timing only)
+    } else if (p >= 1 && fused_smp && p < C - 1) {
+      GemvArgs a{};
+      a.nt = e->nt_backbone;
+      a.W = (const char*)e->w.audio_head_t + (size_t)(p - 1) * V * Hd * w_esz(e);
+      a.wscale = e->w.s_audio_head ? e->w.s_audio_head + (size_t)(p - 1) * V : nullptr;
+      a.N = V; a.K = Hd; a.x = h; a.ldx = ldh; a.ln = e->dec.final_norm; a.eps = e->dec.c.rms_eps;
+      a.out = e->logits_dec; a.ldo = (V + 3) & ~3;
+      a.store_div = s->temperature;                      // logits / T, the sampler's first step, done here once per logit
+      LCK(gemv_rows(e, B, PRO_NORM, EPI_STORE, a));      // logits only: the next pass's first launch samples from them
     } else if (p >= 1) {
       GemvArgs a{};
       a.nt = e->nt_backbone;  // each audio_head slice is read once per frame

@@ -18,11 +18,12 @@
 #pragma once
 #include "common.h"
 #include "prefetch.h"
+#include "sample_wave.h"
 #ifndef CSM_ARGS_ONLY
 #include "attn_tile.h"
 #endif
 
-enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_TOKNORM = 3 };   // PRO_COMBINE: gemv1_combine_kernel (the B = 1 backbone o_proj)
+enum { PRO_PLAIN = 0, PRO_NORM = 1, PRO_COMBINE = 2, PRO_TOKNORM = 3, PRO_SAMPLE = 4 };   // PRO_COMBINE: gemv1_combine_kernel (the B = 1 backbone o_proj)
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_ARGMAX = 4 };
 
 struct GemvArgs {
@@ -80,6 +81,12 @@ struct GemvArgs {
   const int* tok_frame_ptr;
   int tok_max_frames, tok_C, tok_cb;
   float* tok_x_out;        // [K] residual stream of the new pass (written by workgroup 0)
+  // ---- fused top-k sampling (B == 1, round 5): PRO_SAMPLE is PRO_TOKNORM with the token drawn by every wave of the launch
+  // from the previous head launch's logits (sample_wave.h) instead of reduced from arg-max pairs
+  WaveSampleArgs smp;      // logits / V / temperature / topk / rng / noise / cb (frame is read from tok_frame_ptr)
+  const int* smp_row_done; // nullable: per-row stop flag of row 0 (a finished row emits token 0)
+  float store_div;         // EPI_STORE: != 0 -> the stored value is v / store_div (the head launch in front of a PRO_SAMPLE launch divides
+                           // its logits by the temperature: the same IEEE division sample_kernel does, once per logit instead of in every wave)
   // ---- PRO_COMBINE (B == 1 backbone o_proj): x is the split-KV attention output, merged here from the per-split partials
   const float* cmb_part;   // [K / 64 heads][cmb_ns][64 + 4]: acc[64], m, l (attn.h: attn_decode_*_kernel with nsplit > 1)
   int cmb_ns;              // splits (<= 8)
@@ -181,6 +188,7 @@ struct GemvEpi {
     v0 *= sc0;
     v1 *= sc1;
     if (EPI == EPI_STORE) {
+      if (a.store_div != 0.f) { v0 = v0 / a.store_div; v1 = v1 / a.store_div; }
       a.out[(size_t)m * a.ldo + k.r0] = v0;
       if (k.has1) a.out[(size_t)m * a.ldo + k.r1] = v1;
     } else if (EPI == EPI_RESID) {
@@ -241,8 +249,10 @@ struct GemvEpi {
 // weight register; a row's arithmetic -- pair accumulators, ascending chunks, wave_sum2 -- is exactly the M = 1 form's).
 template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T, int M = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GemvArgs a) {
-  static_assert(M == 1 || (PRO != PRO_TOKNORM && EPI != EPI_ARGMAX), "fused greedy sampling is single-row");
+  static_assert(M == 1 || (PRO != PRO_TOKNORM && PRO != PRO_SAMPLE && EPI != EPI_ARGMAX), "fused sampling is single-row");
+  constexpr bool TOK = PRO == PRO_TOKNORM || PRO == PRO_SAMPLE;   // the input row comes from the projected-embedding table
   __shared__ float part[4][2 * T * M];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];   // PRO_SAMPLE: the sampler's histogram / candidate / survivor arrays
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
     k[t] = gemv_map_task<EPI>(a, (blockIdx.x * TPB + tw) * T + t, ntask);
     if (kw == 0) epi[t].prefetch(a, k[t]);
   }
-  if (PRO != PRO_TOKNORM) {
+  if (!TOK) {
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
         xb[m][u] = *reinterpret_cast<const f32x4*>(a.x + (size_t)m * a.ldx + e0 + u * 512 + 4);
       }
   }
-  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
+  if (PRO == PRO_NORM || TOK) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       la[u] = *reinterpret_cast<const f32x4*>(a.ln + e0 + u * 512);
@@ -302,6 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   // (The machine scheduler sinks half of these loads below the RMS prologue to stay at 63 VGPRs = 8 waves per
   // SIMD; pinning them here with __builtin_amdgcn_sched_barrier(0) costs 69 VGPRs and measured the same: with
   // every wave of the launch resident at once the other waves cover.)
+  int tok_bi = 0;
   if (PRO == PRO_TOKNORM) {
     // greedy token of the previous codebook = argmax over the head launch's per-task (value, index) pairs
     constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
@@ -319,11 +330,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       if (pv[j].x > bv || (pv[j].x == bv && ci < bi)) { bv = pv[j].x; bi = ci; }
     }
     wave_argmax(bv, bi);
+    tok_bi = bi;
+  }
+  if (PRO == PRO_SAMPLE) {
+    WaveSampleArgs sa = a.smp;
+    sa.frame = *a.tok_frame_ptr;
+    tok_bi = wg_sample_topk(sa, dyn_lds, tid);
+    if (a.smp_row_done && *a.smp_row_done) tok_bi = 0;   // per-row stop: a finished row stays silent
+  }
+  if (TOK) {
     const int f = *a.tok_frame_ptr;
     const size_t slot = (size_t)f * a.tok_C + a.tok_cb;   // B == 1: row 0
-    int64_t feed = bi;
+    int64_t feed = tok_bi;
     if (a.tok_forced) feed = a.tok_forced[slot];
-    if (blockIdx.x == 0 && tid == 0) a.tok_ring[slot] = bi;
+    if (blockIdx.x == 0 && tid == 0) a.tok_ring[slot] = tok_bi;
     const float* xsrc = a.tok_table + ((size_t)feed + (size_t)a.tok_row_base) * K;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       xb[0][u] = *reinterpret_cast<const f32x4*>(xsrc + e0 + u * 512 + 4);
     }
   }
-  if (PRO == PRO_TOKNORM && blockIdx.x == 0 && wave == 0) {   // the new pass's residual stream
+  if (TOK && blockIdx.x == 0 && wave == 0) {   // the new pass's residual stream
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       *reinterpret_cast<f32x4*>(a.tok_x_out + e0 + u * 512) = xa[0][u];
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       xp[m][u][2] = f32x2{xb[m][u][0], xb[m][u][1]};
       xp[m][u][3] = f32x2{xb[m][u][2], xb[m][u][3]};
     }
-  if (PRO == PRO_NORM || PRO == PRO_TOKNORM) {
+  if (PRO == PRO_NORM || TOK) {
     // KS == 1: the wave holds the whole row.  KS > 1 (round 3: the backbone's K = 2048 normed launches on this register path
     // with two waves per task): every wave sums its K slice and the KS waves of a task meet through LDS (LDS-only barrier:
     // the weight loads stay in flight) -- a fixed order, so the statistic is the same in every wave of the task.

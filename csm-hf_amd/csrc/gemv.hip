@@ -48,6 +48,11 @@ int gemv_configure_all() {
   a.configure_only = 1;
   static const int combos[5][2] = {{PRO_PLAIN, EPI_STORE}, {PRO_NORM, EPI_STORE}, {PRO_PLAIN, EPI_RESID},
                                    {PRO_NORM, EPI_SWIGLU}, {PRO_NORM, EPI_QKV}};
+  for (int wd = 0; wd < 3; ++wd)      // the in-launch sampler's dynamic-LDS limit (gemv1_kernel<PRO_SAMPLE, EPI_QKV>, K-split 1)
+    for (int kd = 0; kd < 2; ++kd) {
+      int r = launch_dispatch(nullptr, wd, kd, 1, PRO_SAMPLE, EPI_QKV, 1, a);
+      if (r && r != -2) return r;
+    }
   for (int wd = 0; wd < 3; ++wd)
     for (int kd = 0; kd < 2; ++kd)
       for (int M = 1; M <= 4; ++M)

@@ -2,6 +2,7 @@
 // RoPE + KV scatter for prefill rows (K4/K5), fused sample + feedback (K12/K13).
 #pragma once
 #include "common.h"
+#include "sample_wave.h"
 
 // ---------------------------------------------------------------------------------------------------
 // K1: out[r,:] = sum_{c<C} mask[r,c] * audio_emb[ids[r,c] + c*V, :] + mask[r,C] * text_emb[ids[r,C], :]
@@ -476,30 +477,11 @@ struct SampleArgs {
   float* copy_dst;
   int copy_n;
   uint32_t* dbg;        // timeline probe slot (common.h TL_BEGIN), nullable
+  int spin_ticks;       // TIMING ONLY: the launch idles this many 10 ns ticks before it starts (how a long launch in the chain affects the weight streamer)
 };
 
 #ifndef CSM_ARGS_ONLY
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t* out) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ uint32_t f32_key(float x) {  // monotone float -> uint map
-  const uint32_t u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
+// philox4x32_10 and f32_key: sample_wave.h (shared with the in-launch wave sampler)
 
 // block-wide argmax with lowest-index tie-break; result broadcast through LDS
 __device__ __forceinline__ int block_argmax(float v, int idx, float* s_val, int* s_idx) {
@@ -542,6 +524,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float s_mn[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   TL_BEGIN(a.dbg);
+  if (a.spin_ticks > 0) {
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < a.spin_ticks) __builtin_amdgcn_s_sleep(4);
+  }
   const int V = a.V;
   const float* lg = a.logits + (size_t)row * a.ldl;
   const int f = a.frame_ptr ? *a.frame_ptr : 0;

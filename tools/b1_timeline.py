@@ -88,6 +88,10 @@ for streamer in (1, 0):
         st, en = raw[i, :g, 0], raw[i, :g, 1]
         rows.append((kind, grid, int(st.min()), int(st.max()), int(en.min()), int(en.max())))
     n = len(rows)
+    if a.md:   # raw per-launch rows for offline analysis: kind, workgroups, first start, last start, first end, last end (10 ns ticks from the step's first start)
+        with open(a.md.replace(".md", f"_raw_streamer{streamer}.csv"), "w") as f:
+            for (kind, grid, s0, s1, e0, e1) in rows:
+                f.write(f"{kind_name(kind)},{grid},{s0 - rows[0][2]},{s1 - rows[0][2]},{e0 - rows[0][2]},{e1 - rows[0][2]}\n")
     emit(f"\n## streamer {'on' if streamer else 'off'}: {n} launches in the last replayed frame-step; step time of this (probe) build {ms * 1e3:.1f} us by HIP events "
          f"(product build: see bench); clock = s_memrealtime, 10 ns ticks")
     t_first, t_last = rows[0][2], rows[-1][5]

@@ -27,8 +27,12 @@ m.load_state_dict(sd)
 del sd
 ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
 eng = m._ensure_engine(1, 512 + 64, 64, 512)
+TOPK = 1
 for o in sys.argv[1:]:
     k, v = o.split("=")
+    if k == "topk":          # sampled path (top-k, T = 0.9) instead of greedy
+        TOPK = int(v)
+        continue
     eng.set_option(k, int(v))
 NL = 800
 res = {}
@@ -39,7 +43,7 @@ for mode in (0, 1):
     eng.reset()
     eng.set_kv_start([0])
     eng.prefill(ids, mask, want_outputs=False)
-    s = eng.sampling(temperature=1.0, topk=1)
+    s = eng.sampling(temperature=1.0 if TOPK == 1 else 0.9, topk=TOPK)
     eng.generate(s, 8, True)
     eng.sync()
     res[mode] = buf.cpu().clone()
