@@ -146,17 +146,27 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
     (the real engine on every rank, RCCL only gathers the finished frames), greedy, stop disabled.  Two legs:
     weak = 16 rows per GPU (16 x world rows in total), strong = 128 rows in total.  Times the whole call (prefill +
     decode + gather, max over ranks) and, separately, the decode frame-steps from the engine's HIP events."""
-    from csm_hf_amd.sharded import generate_sharded, shard_rows
+    from csm_hf_amd.sharded import generate_sharded, shard_rows, MAX_ROWS_PER_PASS
     out = {}
-    for leg, rows in (("weak", 16 * world), ("strong", 128)):
+    # exact = three exact bf16 planes per activation + fp32 KV cache (the mode the parity tests pin); exact_bf16kv = the same planes on
+    # the DEFAULT cache of a bf16 checkpoint (bf16, the reference's own cache dtype: CSMModel.kv_dtype = "auto"); bf16 = decode_precision
+    # AND prefill_precision "bf16" on the bf16 cache, the reference's own arithmetic class for the whole call.  Reported beside, never
+    # instead of, the exact record.
+    modes = [("exact", "exact", torch.float32)]
+    if os.environ.get("CSM_BENCH_NO_DECODE_BF16") != "1":
+        modes += [("exact_bf16kv", "exact", torch.bfloat16), ("bf16", "bf16", torch.bfloat16)]
+    legs = (("weak", 16 * world), ("strong", 128))
+    data = {leg: None for leg, _ in legs}
+    for leg, rows in legs:
         ids, mask = synth_context(cfg, rows, ctx // 4, ctx - ctx // 4, seed=4)
-        ids, mask = ids.to(dev), mask.to(dev)
-        a0, a1 = shard_rows(rows, rank, world)
-        # exact = the engine's default (three exact bf16 planes per activation); bf16 = decode_precision AND prefill_precision "bf16",
-        # the reference's own arithmetic class for the whole call (one nearest-even plane): reported beside it, never instead of it
-        for mode in (("exact",) if os.environ.get("CSM_BENCH_NO_DECODE_BF16") == "1" else ("exact", "bf16")):
-            model.decode_precision = mode
-            model.prefill_precision = mode
+        data[leg] = (ids.to(dev), mask.to(dev))
+    for name, prec, kvd in modes:
+        model.decode_precision = prec
+        model.prefill_precision = prec
+        model.kv_dtype = kvd
+        for leg, rows in legs:
+            ids, mask = data[leg]
+            a0, a1 = shard_rows(rows, rank, world)
             walls = []
             for it in range(2):          # first pass sizes the engine and captures the graph (untimed)
                 if dist is not None:
@@ -174,27 +184,99 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
             if dist is not None:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             assert toks.shape == (rows, frames, cfg.audio_num_codebooks), toks.shape
-            from csm_hf_amd.sharded import MAX_ROWS_PER_PASS
             passes = max(1, -(-(a1 - a0) // MAX_ROWS_PER_PASS))
             rows_pass = min(a1 - a0, MAX_ROWS_PER_PASS)
             step_ms = float(tm[1]) * 1e3 / frames                 # one frame-step of the last engine pass (rows_pass rows)
-            by = bytes_step(cfg, rows_pass, ctx + (frames - 1) / 2.0 + 1, kvbytes=4)
+            by = bytes_step(cfg, rows_pass, ctx + (frames - 1) / 2.0 + 1, kvbytes=4 if kvd == torch.float32 else 2)
             rec = {"rows_total": rows, "rows_per_gpu": a1 - a0, "frames": frames,
                    "ms_per_step_decode": round(step_ms, 4), "rows_per_engine_pass": rows_pass,
                    "roofline_frac_of_8TBs": round(by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "frames_per_s_end_to_end": round(rows * frames / float(tm[0]), 1),
                    "frames_per_s_decode_only": round(rows * frames / (float(tm[1]) * passes), 1),
                    "wall_s": round(float(tm[0]), 4), "decode_ms_last_pass": round(float(tm[1]) * 1e3, 2),
-                   "engine_passes_per_gpu": passes,
+                   "engine_passes_per_gpu": passes, "kv_dtype": "f32" if kvd == torch.float32 else "bf16",
                    "tokens_checksum": int(toks.to(torch.int64).sum().item())}
-            if mode == "exact":
+            if name == "exact":
                 out[leg] = rec
             else:
-                out[leg]["decode_precision_bf16"] = {k: rec[k] for k in ("ms_per_step_decode", "roofline_frac_of_8TBs", "frames_per_s_end_to_end",
-                                                                        "frames_per_s_decode_only", "wall_s", "tokens_checksum")}
-                out[leg]["decode_precision_bf16"]["prefill_precision"] = "bf16"
+                key = "default_bf16_kv" if name == "exact_bf16kv" else "decode_precision_bf16"
+                out[leg][key] = {k: rec[k] for k in ("ms_per_step_decode", "roofline_frac_of_8TBs", "frames_per_s_end_to_end",
+                                                     "frames_per_s_decode_only", "wall_s", "kv_dtype", "tokens_checksum")}
+                out[leg][key]["prefill_precision"] = prec
+    model.decode_precision = "exact"
+    model.prefill_precision = "exact"
+    model.kv_dtype = torch.float32
+    return out
+
+
+def run_configs_235(model, cfg, dev):
+    """End-to-end records of BASELINE configs[1], [2] and [4] through the public API (`CSMModel.generate`: prefill + frame loop +
+    the host-side bookkeeping of the call), each timed on its second call (the first sizes the engine and captures the graph).
+    Bounded: a few seconds each.  (configs[3] is `config4`, run_config4.)"""
+    import torch
+    out = {}
+
+    def timed(ids, mask, n, **kw):
+        best = None
+        for it in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks = model.generate(ids, mask, max_new_frames=n, stop_on_all_zeros=False, **kw)
+            torch.cuda.synchronize()
+            best = time.perf_counter() - t0
+        dec_ms = model._engine.last_generate_ms()
+        assert tuple(toks.shape) == (ids.shape[0], n, cfg.audio_num_codebooks), tuple(toks.shape)
+        return best, dec_ms, int(toks.to(torch.int64).sum().item())
+
+    try:
+        # configs[1]: csm-1b bf16, 512-frame prefill + 200 frames greedy, B = 1 -- both prefill precisions
+        ids, mask = synth_context(cfg, 1, 128, 384, seed=2)
+        ids, mask = ids.to(dev), mask.to(dev)
+        rec = {}
+        for prec in ("exact", "bf16"):
+            model.prefill_precision = prec
+            wall, dec_ms, ck = timed(ids, mask, 200, temperature=1.0, topk=1)
+            rec[f"prefill_{prec}"] = {"wall_s": round(wall, 4), "decode_ms": round(dec_ms, 2), "prefill_and_host_ms": round(wall * 1e3 - dec_ms, 2),
+                                      "frames_per_s_end_to_end": round(200 / wall, 1), "tokens_checksum": ck}
+        model.prefill_precision = "exact"
+        rec["workload"] = "csm-1b bf16, B=1, 512-frame context prefilled INSIDE the timed call + 200 frames greedy, CSMModel.generate, fp32 KV (exact mode)"
+        out["config2"] = rec
+        # configs[2]: B = 16 voice-cloning style context (text + audio frames), top-k 50, T = 1.0, hipGraph outer frame step
+        ids, mask = synth_context(cfg, 16, 128, 384, seed=3)
+        ids, mask = ids.to(dev), mask.to(dev)
+        rec = {}
+        for name, prec, kvd in (("exact", "exact", torch.float32), ("default_bf16_kv", "exact", "auto"), ("decode_precision_bf16", "bf16", "auto")):
+            model.decode_precision = prec
+            model.prefill_precision = prec
+            model.kv_dtype = kvd
+            wall, dec_ms, ck = timed(ids, mask, 100, temperature=1.0, topk=50, seed=5)
+            rec[name] = {"wall_s": round(wall, 4), "ms_per_step_decode": round(dec_ms / 100, 4), "frames_per_s_end_to_end": round(16 * 100 / wall, 1),
+                         "frames_per_s_decode_only": round(16 * 100 / (dec_ms / 1e3), 1), "tokens_checksum": ck}
         model.decode_precision = "exact"
         model.prefill_precision = "exact"
+        model.kv_dtype = torch.float32
+        rec["workload"] = "csm-1b bf16, B=16, 512-frame text+audio context + 100 frames, top-k 50 / T 1.0 (device Philox), CSMModel.generate"
+        out["config3"] = rec
+        # configs[4]: fp8 (e4m3 + row scales) linear weights, 2048-frame prefill + 500 frames greedy, B = 1
+        model.weight_format = "fp8"
+        ids, mask = synth_context(cfg, 1, 512, 1536, seed=6)
+        ids, mask = ids.to(dev), mask.to(dev)
+        rec = {}
+        for prec in ("exact", "mxfp8"):
+            model.prefill_precision = prec
+            wall, dec_ms, ck = timed(ids, mask, 500, temperature=1.0, topk=1)
+            rec[f"prefill_{prec}"] = {"wall_s": round(wall, 4), "decode_ms": round(dec_ms, 2), "ms_per_step_decode": round(dec_ms / 500, 4),
+                                      "prefill_and_host_ms": round(wall * 1e3 - dec_ms, 2), "frames_per_s_end_to_end": round(500 / wall, 1),
+                                      "tokens_checksum": ck}
+        rec["workload"] = "csm-1b fp8-e4m3 linear weights, B=1, 2048-frame context prefilled inside the timed call + 500 frames greedy, CSMModel.generate"
+        out["config5"] = rec
+    except Exception as ex:      # informative sub-records: never break the bench line
+        out["error"] = f"{type(ex).__name__}: {str(ex)[:300]}"
+    finally:
+        model.prefill_precision = "exact"
+        model.decode_precision = "exact"
+        model.weight_format = "native"
+        model.kv_dtype = torch.float32
     return out
 
 
@@ -545,7 +627,12 @@ def main():
     if want4 and not a.lean and a.weights == "bf16":
         del eng
         c4 = run_config4(model, cfg, rank, world, dist, dev, a.ctx, a.config4_frames)
+    e2e = None
+    if want4 and not a.lean and a.weights == "bf16" and world == 1 and os.environ.get("CSM_BENCH_NO_E2E") != "1":
+        e2e = run_configs_235(model, cfg, dev)
     if rank == 0:
+        if e2e is not None:
+            out.update(e2e)
         if c4 is not None:
             rec16 = traffic_record(16, a.ctx, "bf16")      # PMC record of the per-GPU shape of the weak leg (--batch 16)
             if rec16 is not None and c4["weak"]["rows_per_gpu"] == 16:

@@ -541,7 +541,15 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     for (int i = tid; i < a.copy_n; i += 256) a.copy_dst[i] = a.copy_src[i];
 
   int choice;
-  if (greedy) {
+  if (!greedy && V >= WS_VMIN && V <= WS_VMAX && a.temperature > 0.f) {
+    // round 5: the barrier-light selection of sample_wave.h (values in registers, one histogram pass, LDS-only barriers): 9.8 -> ~5 us
+    // per launch at top-k 50; term for term the arithmetic of the path below (tests: the two agree token for token)
+    WaveSampleArgs w{};
+    w.logits = lg; w.V = V; w.temperature = a.temperature; w.topk = a.topk; w.rng = a.rng; w.seed = a.seed;
+    w.noise = a.noise ? a.noise + (size_t)row * a.noise_ld : nullptr;
+    w.cb = a.cb; w.frame = f; w.row = row;
+    choice = wg_sample_topk<true>(w, sx, tid);
+  } else if (greedy) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = tid; i < V; i += 256) {

@@ -45,9 +45,11 @@ struct WaveSampleArgs {
   int V;
   float temperature;
   int topk;
-  const uint64_t* rng;     // device-resident {seed, global index of row 0}
+  const uint64_t* rng;     // nullable: device-resident {seed, global index of row 0} (overrides `seed`)
   const float* noise;      // nullable: explicit Exp(1) draws [V] of this row and codebook
   int cb, frame;
+  int row;                 // batch row (Philox counter word 1 = row + rng[1]); 0 for the B = 1 in-launch form
+  uint64_t seed;           // used when rng == nullptr (stand-alone csm_sample_topk)
 };
 
 constexpr int WS_NJ = 9;                        // values per thread: 2048 <= V <= 256 * 9 = 2304 (only a thread's LAST value can lie beyond V:
@@ -63,7 +65,9 @@ __device__ __forceinline__ int ws_prefix(uint64_t bal) {   // set bits of `bal` 
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: vmcnt untouched
 
 // returns the sampled index (uniform over the 256 threads, all of which must call).  `lds` = wave_sample_lds_words(V) words.
-// a.logits holds the logits ALREADY divided by the temperature (the head launch's epilogue divides: GemvArgs::store_div).
+// DIV = false: a.logits holds the logits ALREADY divided by the temperature (the head launch's epilogue divides: GemvArgs::store_div);
+// DIV = true (sample_kernel): raw logits, divided here.
+template <bool DIV = false>
 __device__ __forceinline__ int wg_sample_topk(const WaveSampleArgs& a, float* lds, int tid) {
   const int V = a.V;
   const int lane = tid & 63, wave = tid >> 6;
@@ -80,6 +84,10 @@ __device__ __forceinline__ int wg_sample_topk(const WaveSampleArgs& a, float* ld
     const int i = tid + 256 * (WS_NJ - 1);
     const float v = a.logits[i < V ? i : V - 1];
     x[WS_NJ - 1] = i < V ? v : -INFINITY;      // padding: below every finite value, outside every [lo, hi] below
+  }
+  if (DIV) {
+#pragma unroll
+    for (int j = 0; j < WS_NJ; ++j) x[j] = x[j] / a.temperature;   // (-inf stays -inf for T > 0)
   }
   const int ktop = a.topk < V ? a.topk : V;
   int krem = ktop;
@@ -229,8 +237,8 @@ __device__ __forceinline__ int wg_sample_topk(const WaveSampleArgs& a, float* ld
         q = a.noise[i];
       } else {
         uint32_t r[4];
-        const uint64_t seed = a.rng[0];
-        const uint32_t grow = (uint32_t)a.rng[1];   // B == 1: row 0 of this shard
+        const uint64_t seed = a.rng ? a.rng[0] : a.seed;
+        const uint32_t grow = (uint32_t)a.row + (a.rng ? (uint32_t)a.rng[1] : 0u);   // global row: shards draw distinct streams
         philox4x32_10((uint32_t)i, grow, (uint32_t)a.cb, (uint32_t)a.frame, (uint32_t)seed, (uint32_t)(seed >> 32), r);
         const float u = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         q = -logf(u);

@@ -308,6 +308,7 @@ class Engine:
         if weight_format not in ("native", "fp8"):
             raise ValueError(f"unknown weight_format {weight_format!r}")
         self.fp8 = weight_format == "fp8"
+        self.kv_dtype = torch.bfloat16 if kv_dtype == torch.bfloat16 else torch.float32
         if self.fp8 and dtype != torch.bfloat16:
             raise ValueError("weight_format='fp8' needs a bf16 model (embeddings and norms stay bf16)")
         self.lib = load_library()

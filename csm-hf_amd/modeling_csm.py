@@ -189,6 +189,7 @@ class CSMModel(nn.Module):
 
     config_class = CSMConfig
     base_model_prefix = "csm"
+    DEFAULT_KV_DTYPE = "auto"   # instances start with kv_dtype = this (tests/conftest.py pins the suites written against the exact mode to torch.float32)
 
     def __init__(self, config: CSMConfig):
         super().__init__()
@@ -210,7 +211,9 @@ class CSMModel(nn.Module):
         self._epoch = 0
         self._frame_pending = False
         self._caps = dict(max_batch=1, max_len=0, max_frames=0, max_prefill_rows=0)
-        self.kv_dtype = torch.float32
+        self.kv_dtype = type(self).DEFAULT_KV_DTYPE   # "auto" (default, round 5): the KV cache follows the model dtype -- a bf16 checkpoint caches bf16 K / V like the
+        # reference's DynamicCache of a bf16 model (README.md:73); torch.float32 = the exact mode (a bf16-weight model then reproduces the
+        # reference's fp32-arithmetic token stream bit for bit: what the parity tests and the headline bench pin); torch.bfloat16 forces bf16
         self.weight_format = "native"   # "fp8": linear weights as e4m3fn + per-row scales (BASELINE config 5)
         self.use_graph = True
         self.stop_check_interval = 8     # stop_on_all_zeros: frames replayed between two reads of the device-side stop counters
@@ -322,6 +325,13 @@ class CSMModel(nn.Module):
                 raise ValueError("parameters were modified in place while a KV cache is live: call reset_caches() first")
             self._drop_engine()
         c = self._caps
+        kv_eff = self.kv_dtype if self.kv_dtype not in (None, "auto") else (torch.bfloat16 if p.dtype == torch.bfloat16 else torch.float32)
+        if kv_eff not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"kv_dtype must be 'auto', torch.float32 or torch.bfloat16, got {self.kv_dtype!r}")
+        if self._engine is not None and self._engine.kv_dtype != kv_eff:
+            if cont:
+                raise ValueError("kv_dtype changed while a KV cache is live: call reset_caches() first")
+            self._drop_engine()
         if self._engine is not None and self._engine.fp8 != (self.weight_format == "fp8"):
             if cont:
                 raise ValueError("weight_format changed while a KV cache is live")
@@ -343,7 +353,7 @@ class CSMModel(nn.Module):
                 self._epoch += 1
             eng = Engine(self.config, self.state_dict(), p.device, p.dtype, max_batch=c["max_batch"],
                          max_len=c["max_len"], max_frames=c["max_frames"],
-                         max_prefill_rows=c["max_prefill_rows"], kv_dtype=self.kv_dtype, packed=packed,
+                         max_prefill_rows=c["max_prefill_rows"], kv_dtype=kv_eff, packed=packed,
                          weight_format=self.weight_format)
             if old is not None:      # continuation: re-home the live state, then release the old engine
                 eng.adopt_state(old)
