@@ -240,9 +240,10 @@ struct csm_engine {
   static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
   static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
   static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
-  static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_poll_sleep = 2, pf_depth = 0, pf_seg_sleep = 16, pf_stride = 0;
-  static constexpr int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed
-  static constexpr int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB
+  static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
+  int pf_depth = 0, pf_seg_sleep = 16, pf_poll_sleep = 2;   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
+  int pf_max_kb = 0;         // > 0: only launches whose matrix is at most this large are streamed whole (option prefetch_max_kb)
+  int pf_part_kb = 0;        // > 0: of larger matrices, stream only the first this-many KiB (option prefetch_part_kb)
   std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
   std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
   uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
@@ -614,6 +615,11 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "rows64")) e->rows64 = value < 0 ? -1 : (value ? 1 : 0);   // -1: 16-row launches only (tests: every wider form against gemm16_kernel)
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
+  else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
+  else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
@@ -699,6 +705,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       if (!a.g16_nw && e->g16_k16 && a.K == 2048 && a.xplanes) { a.g16_nw = e->g16_k16 & 0xff; a.g16_kb = (e->g16_k16 >> 8) & 0xff; }
       if (rec) { a.prog = e->d_prog; a.geom_out = &geom; }
       if (e->g16_slab >> 4) a.g16_slab = (a.g16_slab & 3) | (e->g16_slab & ~15);   // TIMING-ONLY in-kernel knock-outs (gemm16.h), every matrix-core launch
+      a.dbg = tl_slot(e);
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       a.prog = nullptr; a.geom_out = nullptr;

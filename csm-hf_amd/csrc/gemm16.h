@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   int* flag = reinterpret_cast<int*>(panel + PT * 256);
   float* stat = panel + PT * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TL_BEGIN(a.dbg);
   if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing
   const int K = a.K;
   const WT* W = reinterpret_cast<const WT*>(a.W);
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       *flag = last;
     }
     __syncthreads();
-    if (!*flag) return;
+    if (!*flag) { TL_END(0x70 + EPI + 8 * PRO); return; }
     const unsigned base_off = (unsigned)((size_t)blockIdx.x * KB * (PT * 256) * sizeof(float));
     for (int q = tid; q < PT * 64; q += 64 * NW) {
       f32x4 v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }
+  TL_END(0x70 + EPI + 8 * PRO);
 }
 #endif  // CSM_ARGS_ONLY
 

@@ -32,16 +32,16 @@ os.environ["CSM_HIP_LIB"] = TL_LIB
 from csm_hf_amd import CSMConfig, CSMModel  # noqa: E402
 from csm_hf_amd.synth import synth_state_dict, synth_context  # noqa: E402
 
-KINDS = {2: "attn_oproj", 3: "attn_decode", 4: "attn_combine", 5: "sample", 6: "embed_sum"}
-PRO = {0: "plain", 1: "norm", 3: "toknorm", 2: "pro2"}
+KINDS = {2: "attn_oproj", 3: "attn_decode", 4: "attn_combine", 5: "sample", 6: "embed_sum", 7: "attn_oproj_gqa", 8: "attn_decode_gqa"}
+PRO = {0: "plain", 1: "norm", 3: "toknorm", 2: "combine", 4: "sample"}
 EPI = {0: "store", 1: "resid", 2: "swiglu", 3: "qkv", 4: "argmax"}
 
 
 def kind_name(k):
     if k in KINDS:
         return KINDS[k]
-    fam = "gemv1" if 0x10 <= k < 0x40 else "gemv_lds" if 0x40 <= k < 0x70 else f"kind{k}"
-    v = k - (0x10 if k < 0x40 else 0x40)
+    fam = "gemv1" if 0x10 <= k < 0x40 else "gemv_lds" if 0x40 <= k < 0x70 else "gemm16" if 0x70 <= k < 0xa0 else f"kind{k}"
+    v = k - (0x10 if k < 0x40 else 0x40 if k < 0x70 else 0x70)
     return f"{fam}<{PRO.get(v >> 3, v >> 3)},{EPI.get(v & 7, v & 7)}>"
 
 
