@@ -307,6 +307,17 @@ def traffic_record(batch: int, ctx: int, weights: str, opts=()):
     return None
 
 
+def launch_kinds(batch: int):
+    """per-launch-kind table of the frame-step (gap / body / us per step by kernel and grid) from the committed in-step timeline
+    of this batch size (profiles/launch_kinds_b<B>.json <- tools/b1_timeline.py --json), marked stale when measured on another build"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", f"launch_kinds_b{batch}.json")))
+    except Exception:
+        return None
+    rec["stale"] = rec.get("product_lib_sha256") != lib_sha256()
+    return rec
+
+
 def attach_traffic(dst: dict, rec: dict, algorithmic: float = None):
     """`traffic` fields of a roofline / config4 record from a committed PMC record; `traffic_stale` = the record was
     measured on another build of the library (or names none)."""
@@ -604,6 +615,9 @@ def main():
         if rec is not None:
             attach_traffic(out["roofline"], rec, by)
         out["lib_sha256"] = lib_sha256()
+        lk = launch_kinds(B) if (a.ctx == 512 and a.weights == "bf16" and a.topk == 1) else None
+        if lk is not None:
+            out["roofline"]["launch_kinds"] = lk
         # parity of the benchmarked run against the reference's golden vectors (same context at rank 0, B=1)
         gpath = os.path.join(ROOT, "tests", "golden", "csm1b_cfg2_bf16w_fp32.npz")
         if B == 1 and a.ctx == 512 and a.topk == 1 and a.weights == "bf16" and os.path.exists(gpath):
@@ -637,6 +651,9 @@ def main():
             rec16 = traffic_record(16, a.ctx, "bf16")      # PMC record of the per-GPU shape of the weak leg (--batch 16)
             if rec16 is not None and c4["weak"]["rows_per_gpu"] == 16:
                 attach_traffic(c4["weak"], rec16)
+            lk16 = launch_kinds(16)
+            if lk16 is not None and c4["weak"]["rows_per_gpu"] == 16:
+                c4["weak"]["launch_kinds"] = lk16
             out["config4"] = c4
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -587,7 +587,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
-  else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value ? 1 : 0;
+  else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
   else if (!strcmp(name, "combine_splits")) e->cmb_splits = value < 2 ? 2 : (value > 8 ? 8 : value);
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
@@ -791,8 +791,8 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.dbg_onekey = (e->dbg_skip >> 7) & 1;
     f.dbg = tl_slot(e);
     f.gqa = e->attn_oproj_gqa;
-    const bool rec = e->pf_rec && e->stream_attn_oproj;   // its 2 MB of weights in the streamer's schedule too
-    if (rec) f.prog = e->d_prog;
+    const bool rec = e->pf_rec && e->stream_attn_oproj;   // its 2 MB of weights in the streamer's schedule too: 1 = as a paced launch of its own,
+    if (rec && e->stream_attn_oproj == 1) f.prog = e->d_prog;   // 2 = attached to the QKV launch in front of it (fetched with that launch's weights)
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
     if (ao != -2 && rec) {
@@ -800,6 +800,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
       const int K = nq * hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * nq / tpr;   // rows per workgroup (launchers.hip)
       g.W = w.wo; g.N = H; g.K = K; g.esz = (int)w_esz(e); g.kind = 0; g.grid = H / rows; g.tpb = rows / 2; g.iters = 1; g.stride = 0;
       g.ntask = H / 2; g.hd = hd; g.n_rope_heads = 0;
+      g.attach = e->stream_attn_oproj == 2;
       e->pf_rec->push_back(g);
     }
   }
@@ -1795,15 +1796,23 @@ extern "C" int csm_forward_loss(csm_engine_t* e, const int64_t* ids, const uint8
 }
 
 static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, GraphEntry& ent) {
-  ent.n_launch = (int)geoms.size();
+  // launch index of every recorded geometry: an attached one (PfGeom::attach) shares the index of the paced launch in front of it
+  std::vector<int> lidx(geoms.size(), 0);
+  int n_paced = 0;
+  for (size_t i = 0; i < geoms.size(); ++i) {
+    if (geoms[i].attach && n_paced > 0) lidx[i] = n_paced - 1;
+    else lidx[i] = n_paced++;
+  }
+  ent.n_launch = n_paced;
   if (geoms.empty()) return 0;
   for (const PfGeom& g : geoms)
     if (g.exclusive) return 0;   // a launch that needs whole CUs to itself: the streamer would hold the chain up (gemm16.h)
   std::vector<PfSeg> segs;
   std::vector<size_t> bytes;
   const size_t sub = (size_t)e->pf_sub_kb << 10;
-  for (int li = 0; li < (int)geoms.size(); ++li) {
-    const PfGeom& g = geoms[li];
+  for (int gi = 0; gi < (int)geoms.size(); ++gi) {
+    const PfGeom& g = geoms[gi];
+    const int li = lidx[gi];
     if (g.kind < 0 || !g.W || g.grid < 1 || g.tpb < 1) continue;
     size_t rb = (size_t)g.K * g.esz;
     size_t per_block = (size_t)g.iters * 2 * g.tpb * rb;

@@ -21,6 +21,7 @@ ap.add_argument("--ctx", type=int, default=512)
 ap.add_argument("--frames", type=int, default=12)
 ap.add_argument("--topk", type=int, default=1)
 ap.add_argument("--md", default=None)
+ap.add_argument("--json", default=None, help="write the streamer-on per-launch-kind table as JSON (bench.py attaches profiles/launch_kinds_b<B>.json to its record)")
 ap.add_argument("opts", nargs="*")
 a = ap.parse_args()
 
@@ -121,6 +122,20 @@ for streamer in (1, 0):
         c, g, rmp, body, spr = agg[key]
         emit(f"| `{kind_name(key[0])}` | {key[1]} | {c} | {g / c:.2f} | {rmp / c:.2f} | {body / c:.2f} | {spr / c:.2f} | {(g + body) / c:.2f} | {g + body:.1f} |")
     emit(f"| total | | {n} | {tot_gap / max(n - 1, 1):.2f} | | {tot_body / n:.2f} | | | {tot_gap + tot_body:.1f} |")
+    if a.json and streamer == 1:
+        import hashlib
+        import json
+        import subprocess
+        from csm_hf_amd.build import LIB
+        kinds = [{"kernel": kind_name(k[0]), "workgroups": k[1], "launches": agg[k][0], "gap_us": round(agg[k][1] / agg[k][0], 2),
+                  "body_us": round(agg[k][3] / agg[k][0], 2), "us_per_step": round(agg[k][1] + agg[k][3], 1)} for k in order]
+        rec = {"batch": B, "ctx": a.ctx, "topk": a.topk, "launches_per_step": n, "step_us_probe_build": round(tot_gap + tot_body, 1),
+               "how": "tools/b1_timeline.py: per-workgroup s_memrealtime at entry / after the last store in the -DCSM_TIMELINE build of the SAME sources "
+                      "(5-6 % slower than the product build), streamer on; gap = previous launch's last end -> first start, body = first start -> last end",
+               "product_lib_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest() if os.path.exists(LIB) else None,
+               "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
+               "kinds": kinds}
+        json.dump(rec, open(a.json, "w"), indent=1)
     eng.set_debug_buffer(None, 0)
 
 if a.md:
