@@ -275,10 +275,9 @@ class CSMModel(nn.Module):
     # ---- engine management ---------------------------------------------------------------------------------
     def _param_signature(self):
         """(storage address, version counter) of every parameter: changes when a parameter is replaced or written in place."""
-        ps = getattr(self, "_plist", None)
-        if ps is None or len(ps) != sum(1 for _ in self.parameters()):
-            ps = self._plist = list(self.parameters())
-        return tuple((q.data_ptr(), q._version) for q in ps)
+        # (the list is rebuilt on every call: a cached list missed `mod.weight = nn.Parameter(...)`, which keeps the parameter COUNT --
+        #  ADVICE r4; ~200 parameters, microseconds)
+        return tuple((id(q), q.data_ptr(), q._version) for q in self.parameters())
 
     def _drop_engine(self):
         self._plist = None

@@ -63,11 +63,15 @@ class ContinuousBatcher:
         self.join_budget_rows = int(join_budget_rows)
         self.deferred_to_next_batch = 0     # long contexts that were refused as a join and opened the next batch instead
         self.joins_deferred_by_budget = 0   # joins that waited one more chunk because the chunk's prefill budget was spent
+        self.skip_ahead = 4                 # requests that may overtake a head deferred to the next batch (in total, per deferred head)
+        self.overtakes = 0
+        self._overtaken: Dict[int, int] = {}
         self.frame_seconds = float(frame_seconds)
         import time as _time
         self._clock = clock or _time.perf_counter
         # per request: submit time, time to first frame, gaps between consecutive chunk deliveries, late chunks (gap > frames x 80 ms)
         self.latency: Dict[int, dict] = {}
+        self.errors: Dict[int, str] = {}       # requests that failed on their own (the batch they ran in did not)
 
     def submit(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_new_frames: Optional[int] = None) -> int:
         """input_ids / attention_mask `[T, 33]` (or `[1, T, 33]`) of ONE utterance; returns its request id."""
@@ -75,6 +79,9 @@ class ContinuousBatcher:
             input_ids, attention_mask = input_ids[0], attention_mask[0]
         if input_ids.dim() != 2 or input_ids.shape != attention_mask.shape:
             raise ValueError("one utterance: input_ids and attention_mask of shape [T, C+1]")
+        if input_ids.shape[0] + self.check_every + 1 > self.max_total_len:
+            # the cap on a batch's total length holds for the batch an utterance OPENS as well as for joins
+            raise ValueError(f"context of {input_ids.shape[0]} frames cannot be served within max_total_len = {self.max_total_len}")
         rid = self._next_id
         self._next_id += 1
         self._queue.append((rid, input_ids.cpu(), attention_mask.cpu(), int(max_new_frames or self.default_budget)))
@@ -167,8 +174,6 @@ class ContinuousBatcher:
                 # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of
                 # idle / finished rows are decoded too and dropped; ids beyond the codec's codebook cannot come from a real model)
                 live = [b for b, r in enumerate(rows) if r is not None]
-                if live and not self.clamp_audio_ids and int(toks_dev[live].max()) >= dec.cfg.codebook_size:
-                    raise ValueError(f"generated token id {int(toks_dev[live].max())} is outside the codec's codebook ({dec.cfg.codebook_size})")
                 codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k] (the clamp only touches idle rows)
                 step = max(1, dec.max_frames // B)
                 wav_dev = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1)   # [B, 1, k * spf]
@@ -187,7 +192,16 @@ class ContinuousBatcher:
                         break
                     r[2].append(toks[b, i])
                     took += 1
-                if wav is not None and took:
+                if dec is not None and took and not self.clamp_audio_ids and int(toks[b, :took].max()) >= dec.cfg.codebook_size:
+                    # only the frames actually DELIVERED are checked (frames behind a row's stop or budget are never decoded for anyone),
+                    # and only this request fails: its tokens are returned, its audio is not, the batch goes on
+                    self.errors[r[0]] = (f"generated token id {int(toks[b, :took].max())} is outside the codec's codebook "
+                                         f"({dec.cfg.codebook_size}); no audio for this request")
+                    done = True
+                    waves[b] = []
+                elif wav is not None and took:
+                    pass
+                if wav is not None and took and r[0] not in self.errors:
                     waves[b].append(wav[wav_row[b], 0, :took * spf])
                 if took:
                     self._delivered(r[0], took, now)
@@ -209,7 +223,23 @@ class ContinuousBatcher:
                 if not self._queue:
                     break
                 st, eng = self._join(eng, b, k, any(r is not None for r in rows))
-                if st is None:                      # the head of the queue waits (budget spent / growth cap): FIFO, nothing overtakes it
+                if st is None and getattr(self, "_deferred_rid", None) == self._queue[0][0]:
+                    # the head waits for the NEXT batch (growth cap): up to `skip_ahead` shorter requests behind it may take idle rows
+                    # meanwhile -- a bounded overtake, so the deferred head cannot starve (rows sat idle behind it)
+                    head = self._queue[0][0]
+                    if self._overtaken.get(head, 0) >= self.skip_ahead:
+                        break
+                    for pos in range(1, min(len(self._queue), 1 + self.skip_ahead)):
+                        if self._queue[pos][1].shape[0] <= eng.length and self._queue[pos][1].shape[0] <= self._budget_left:
+                            self._overtaken[head] = self._overtaken.get(head, 0) + 1
+                            self._queue.rotate(-pos)
+                            item = self._queue.popleft()
+                            self._queue.rotate(pos)
+                            self._queue.appendleft(item)
+                            self.overtakes += 1
+                            st, eng = self._join(eng, b, k, any(r is not None for r in rows))
+                            break
+                if st is None:                      # the head of the queue waits (budget spent / growth cap)
                     break
                 rows[b] = st
                 if dec is not None:

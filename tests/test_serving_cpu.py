@@ -3,6 +3,8 @@ when, budgets, the all-zero end-of-utterance frame, contexts longer than the run
 up), idle rows offered the queue again after every chunk, the frame ring wrapping."""
 import types
 
+import pytest
+
 import torch
 
 from csm_hf_amd.serving import ContinuousBatcher
@@ -216,6 +218,7 @@ def test_growth_is_capped_a_too_long_context_opens_the_next_batch():
     and opens the NEXT batch when the running one has drained."""
     m = StubModel(max_frames=64)
     cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=4, max_shift=100)
+    cb.skip_ahead = 0                                            # strict FIFO (round 5 default: a bounded overtake, tested below)
     a = cb.submit(*utterance(1, 3), max_new_frames=2)
     b = cb.submit(*utterance(2, 3), max_new_frames=14)
     c = cb.submit(*utterance(3, 900), max_new_frames=2)          # 900 - 7 > max_shift: may not join the running batch
@@ -225,6 +228,18 @@ def test_growth_is_capped_a_too_long_context_opens_the_next_batch():
     assert len(m.engines) == 2 and cb.deferred_to_next_batch == 1 and cb.shifted_for_long_context == 0
     assert not any(x[0] == "shift" for x in m.engines[0].log) and not any(x[0] == "join" for x in m.engines[0].log)
     assert m.engines[1].log[0] == ("prefill", 2, 900)            # c and d opened the next batch together
+    # round 5: with the default bounded overtake the short request behind the deferred head takes the idle row of the
+    # RUNNING batch instead of waiting for it to drain; the head still opens the next batch
+    m3 = StubModel(max_frames=64)
+    cb3 = ContinuousBatcher(m3, batch_size=2, topk=1, check_every=4, max_shift=100)
+    a3 = cb3.submit(*utterance(1, 3), max_new_frames=2)
+    b3 = cb3.submit(*utterance(2, 3), max_new_frames=14)
+    c3 = cb3.submit(*utterance(3, 900), max_new_frames=2)
+    d3 = cb3.submit(*utterance(4, 3), max_new_frames=2)
+    out3 = cb3.run()
+    assert [out3[x].shape[0] for x in (a3, b3, c3, d3)] == [2, 14, 2, 2]
+    assert cb3.overtakes == 1 and cb3.deferred_to_next_batch == 1 and len(m3.engines) == 2
+    assert any(x[0] == "join" for x in m3.engines[0].log) and m3.engines[1].log[0][0] == "prefill" and m3.engines[1].log[0][2] == 900
     # within the cap the join happens as before; the number of moves per batch is bounded too
     m2 = StubModel(max_frames=64)
     cb2 = ContinuousBatcher(m2, batch_size=2, topk=1, check_every=2, max_shift=100, max_shifts_per_batch=1)
@@ -278,3 +293,25 @@ def test_join_budget_per_chunk_and_latency_record():
     assert long_one["late_chunks"] >= 1 and max(long_one["chunk_gaps_s"]) >= 0.40 - 1e-9     # 0.10 generate + 0.30 join > 2 x 80 ms
     s = cb.latency_summary()
     assert s["requests"] == 6 and s["late_chunks"] >= 1 and s["chunk_deadline_s"] == 0.16 and s["ttff_s"]["max"] >= s["ttff_s"]["p50"]
+
+
+def test_round5_serving_limits_and_param_signature():
+    """a context that cannot fit `max_total_len` is refused at submit (the cap also holds for the batch an utterance
+    opens); `errors` exists for requests that fail on their own; the parameter signature notices a REPLACED parameter of unchanged
+    count."""
+    import torch
+    from csm_hf_amd import CSMConfig, CSMModel
+    from csm_hf_amd.serving import ContinuousBatcher as BatchServer
+    cfg = CSMConfig.tiny()
+    m = CSMModel(cfg)
+    srv = BatchServer(m, 2, max_total_len=64, check_every=4)
+    assert srv.errors == {} and srv.skip_ahead >= 1
+    ids = torch.zeros(80, cfg.audio_num_codebooks + 1, dtype=torch.long)
+    with pytest.raises(ValueError, match="max_total_len"):
+        srv.submit(ids, torch.ones_like(ids))
+    srv.submit(ids[:20], torch.ones_like(ids[:20]))
+    m2 = CSMModel(cfg)
+    m2.load_state_dict({k: torch.zeros(v.shape) for k, v in m2.state_dict().items()})
+    sig0 = m2._param_signature()
+    m2.projection.weight = torch.nn.Parameter(torch.zeros_like(m2.projection.weight), requires_grad=False)
+    assert m2._param_signature() != sig0
