@@ -36,6 +36,7 @@ struct AttnArgs {
   int tile_prefetch;  // host-side: 1 = the kernel variant that requests tile i+1 before it consumes tile i (head_dim 64)
   int* tickets;       // nullable, [rows * n_q] zeroed once (self-resetting): with nsplit > 1 the LAST split of a (row, head) to arrive
                       // merges the partials itself -- no attn_combine launch (round 4: one launch less per backbone layer)
+  int prio;           // 1 = s_setprio 3 at kernel entry (issue priority over the weight streamer's resident waves)
   int gqa;            // host-side: 1 = attn_decode_gqa_kernel (head_dim 64, n_q / n_kv = 4: the key quarters of a split on the workgroup's four waves)
   int no_combine;     // host-side: 1 = with nsplit > 1 leave the partials to the consumer (gemv.h gemv1_combine_kernel): no attn_combine launch
   uint32_t* dbg;      // timeline probe slots (common.h TL_BEGIN) of the attention launch and, 4096 words on, of the combine launch; nullable
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   __shared__ float pb[4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   const int G = a.n_q / a.n_kv;
   int blk = blockIdx.x;
   int g0 = wave, gstep = 4;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   __shared__ float wstat[4][G][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   int blk = blockIdx.x;
   const int sp = blk % a.nsplit;
   blk /= a.nsplit;

@@ -32,6 +32,7 @@ struct AttnOprojArgs {
   int dbg_onekey;        // TIMING ONLY (wrong results): every lane loads key 0 -- the launch without its K/V traffic
   uint32_t* dbg;         // timeline probe slot (common.h TL_BEGIN), nullable
   unsigned* prog;        // weight streamer pacing (prefetch.h): launches-started counter bumped by workgroup 0, nullable
+  int prio;              // 1 = s_setprio 3 at kernel entry (A/B)
   int gqa;               // host-side: 1 = the key-split form below (attn_oproj_gqa_kernel) where the shape allows it
 };
 // (A batched form of this fusion -- one workgroup per (64-output slice, batch row) -- was measured SLOWER than the stand-alone
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AttnOprojArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[8 waves][G * HD] | part[8 waves][G][HD] | att[NQ][HD] | stat[8][G][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // A/B: issue priority over the resident weight-streamer waves of the CU
   if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);
   float* const qs = lds + wave * (G * HD);
   float* const partb = lds + 8 * G * HD;

@@ -196,6 +196,8 @@ struct csm_engine {
                              // bit 1 batched rows (measured SLOWER at B = 16, 5.58 vs 5.09 ms: off)
   static constexpr int use_mfma = 1;
   static constexpr int flash_prefill = 1;
+  int kernel_prio = 7;         // s_setprio 3 at kernel entry (issue priority over the resident weight-streamer waves): bit 0 the fused decoder
+                               // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
   int stream_attn_oproj = 0;   // the fused decoder attention + o_proj launch in the weight streamer's schedule (round 2 form: slower; re-measured in round 5)
   int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
@@ -586,6 +588,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   if (!strcmp(name, "nsplit_backbone")) e->nsplit_bb = value < 0 ? 0 : (value > 64 ? 64 : value);
   else if (!strcmp(name, "fuse_attn_oproj")) e->fuse_attn_oproj = value;
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
+  else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
   else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
@@ -722,6 +725,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
     PfGeom geom{};
     geom.kind = -1;
     if (e->pf_rec) { a.prog = e->d_prog; a.geom_out = &geom; }   // capture: this launch is paced / streamed (prefetch.h)
+    a.prio = (e->kernel_prio >> 1) & 1;
 #ifdef CSM_TIMELINE
     a.dbg = tl_slot(e);
 #else
@@ -791,6 +795,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.dbg_onekey = (e->dbg_skip >> 7) & 1;
     f.dbg = tl_slot(e);
     f.gqa = e->attn_oproj_gqa;
+    f.prio = e->kernel_prio & 1;
     const bool rec = e->pf_rec && e->stream_attn_oproj;   // its 2 MB of weights in the streamer's schedule too: 1 = as a paced launch of its own,
     if (rec && e->stream_attn_oproj == 1) f.prog = e->d_prog;   // 2 = attached to the QKV launch in front of it (fetched with that launch's weights)
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
@@ -814,6 +819,7 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     t.pos_ptr = pos_ptr; t.pos_const = pos_const; t.kv_start = e->d_kv_start;
     t.nsplit = nsplit; t.out = att; t.part = part; t.gqa = 1; t.no_combine = 1;
     t.dbg = tl_slot(e);
+    t.prio = (e->kernel_prio >> 2) & 1;
     if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, 1, t));
     o.cmb_part = part; o.cmb_ns = nsplit; o.x = nullptr;
     if (!(sk & 4)) LCK(gemv_rows(e, 1, PRO_COMBINE, EPI_RESID, o));
@@ -965,6 +971,7 @@ static int decoder_two_token_pass(csm_engine* e, float* x2) {
         f.beside_streamer = e->pf_enable && e->pf_rot >= 0;
         f.dbg = tl_slot(e);
         f.gqa = e->attn_oproj_gqa;
+        f.prio = e->kernel_prio & 1;
         ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
         if (ao != -2) LCK(ao);
       }
@@ -1013,6 +1020,7 @@ static int decode_frame_impl(csm_engine* e, const csm_sampling_t* s) {
     }
     a.dbg = tl_slot(e);
     a.spin_ticks = e->dbg_sample_spin;
+    a.prio = (e->kernel_prio >> 2) & 1;
     return launch_sample(e->stream, B, a);
   };
   // B == 1 greedy without traces: codebooks 1..C-2 need no sampler launch -- the head writes per-task argmax

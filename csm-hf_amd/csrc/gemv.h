@@ -55,6 +55,7 @@ struct GemvArgs {
   int* bump_a;
   int* bump_b;
   int nt;  // non-temporal weight loads
+  int prio;  // 1 = s_setprio 3 at kernel entry: issue priority over the weight streamer's resident waves (round 5)
   const void* Wt;  // MFMA kernel only: the same weights in 16-row x 32-k fragment order (tile16_kernel), nullable
   // MFMA kernel only -- activations handed from launch to launch as ready-made B operands ("planes"): the exact
   // 3-way bf16 split of x (* the consumer's norm weight), in fragment order [3][K/128][4][64 lanes][8], plus per-tile
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
 #ifdef CSM_PROBE   // tools/streamer_probe.py builds libcsm_hip_probe.so with -DCSM_PROBE; even a disabled probe costs 6 % per frame
   const unsigned long long dbg_t0 = __builtin_readcyclecounter();   // before the first kernel argument is read
 #endif
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   __shared__ __attribute__((aligned(16))) float xs[K];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int ntask = (a.N + 1) >> 1;
   const GemvTask k = gemv_map_task<EPI_RESID>(a, blockIdx.x * 4 + wave, ntask);
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int TPB = 4 / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing: this launch has started
   const int kw = wave % KS, tw = wave / KS;
   const int K = a.K;

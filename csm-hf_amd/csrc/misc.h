@@ -477,6 +477,7 @@ struct SampleArgs {
   float* copy_dst;
   int copy_n;
   uint32_t* dbg;        // timeline probe slot (common.h TL_BEGIN), nullable
+  int prio;             // 1 = s_setprio 3 at kernel entry
   int spin_ticks;       // TIMING ONLY: the launch idles this many 10 ns ticks before it starts (how a long launch in the chain affects the weight streamer)
 };
 
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   __shared__ float s_mn[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (a.spin_ticks > 0) {
     const long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < a.spin_ticks) __builtin_amdgcn_s_sleep(4);
