@@ -236,14 +236,15 @@ struct csm_engine {
   unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
   unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
-  int pf_enable = 1, pf_window_mb = 6, pf_sub_kb = 4096; static constexpr int pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
+  int pf_enable = 1, pf_window_mb = 6, pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
   // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
   static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
   static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
   static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
-  int pf_depth = 0, pf_seg_sleep = 16, pf_poll_sleep = 2;   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
+  int pf_depth = 0, pf_seg_sleep = 0, pf_poll_sleep = 2;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
+  // streamer no longer slows the chain's latency-bound launches: B = 1 3.09 -> 2.95 ms (profiles/r05_b1_budget.md)   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
   int pf_max_kb = 0;         // > 0: only launches whose matrix is at most this large are streamed whole (option prefetch_max_kb)
   int pf_part_kb = 0;        // > 0: of larger matrices, stream only the first this-many KiB (option prefetch_part_kb)
   std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
@@ -620,6 +621,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
   else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
   else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
