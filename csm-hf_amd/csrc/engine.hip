@@ -208,7 +208,7 @@ struct csm_engine {
   float* g16_slabs = nullptr;
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
-  static constexpr int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
+  int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
                                            // consumed lines are then the first victims in L2 (3.32 -> 3.30 ms per step)
   // KV splits of the backbone decode attention: the kernel is latency-bound per 32-key tile, so aim for
   // <= 2 tiles per workgroup at the current length (+ headroom for the frames of this generate call) while
@@ -240,8 +240,8 @@ struct csm_engine {
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
   // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
   static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
-  static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
-  static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
+  int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
+  int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
   int pf_depth = 0, pf_seg_sleep = 0, pf_poll_sleep = 2;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
   // streamer no longer slows the chain's latency-bound launches: B = 1 3.09 -> 2.95 ms (profiles/r05_b1_budget.md)   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
@@ -621,6 +621,10 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value < 0 ? 0 : value;
+  else if (!strcmp(name, "nt_backbone")) e->nt_backbone = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value < 0 ? 0 : (value > 2 ? 2 : value);
+  else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
+  else if (!strcmp(name, "g16_k16")) e->g16_k16 = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
   else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
   else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 0 ? 0 : value;
@@ -711,6 +715,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       if (rec) { a.prog = e->d_prog; a.geom_out = &geom; }
       if (e->g16_slab >> 4) a.g16_slab = (a.g16_slab & 3) | (e->g16_slab & ~15);   // TIMING-ONLY in-kernel knock-outs (gemm16.h), every matrix-core launch
       a.dbg = tl_slot(e);
+      a.prio = (e->kernel_prio >> 1) & 1;
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       a.prog = nullptr; a.geom_out = nullptr;

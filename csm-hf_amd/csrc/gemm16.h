@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   float* stat = panel + PT * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing
   const int K = a.K;
   const WT* W = reinterpret_cast<const WT*>(a.W);
