@@ -31,8 +31,7 @@ struct AttnOprojArgs {
   int beside_streamer;   // host-side: refuse (-2) when a workgroup of this launch does not fit beside a resident streamer wave
   int dbg_onekey;        // TIMING ONLY (wrong results): every lane loads key 0 -- the launch without its K/V traffic
   uint32_t* dbg;         // timeline probe slot (common.h TL_BEGIN), nullable
-  unsigned* prog;        // weight streamer pacing (prefetch.h): launches-started counter bumped by workgroup 0, nullable
-  int prio;              // 1 = s_setprio 3 at kernel entry (A/B)
+  int prio;              // 1 = s_setprio 3 at kernel entry
   int gqa;               // host-side: 1 = the key-split form below (attn_oproj_gqa_kernel) where the shape allows it
 };
 // (A batched form of this fusion -- one workgroup per (64-output slice, batch row) -- was measured SLOWER than the stand-alone
@@ -50,7 +49,6 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[n_q][HD] | att[n_q][HD] | p[n_q][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
-  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);
   const int nq = a.n_q, K = nq * HD;
   const int kpt = K >= 1024 ? 16 : 8, tpr = K / kpt;   // k per thread, threads per output row (32 or 64)
   float* qs = lds + wave * HD;
@@ -129,8 +127,7 @@ __global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AttnOprojArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[8 waves][G * HD] | part[8 waves][G][HD] | att[NQ][HD] | stat[8][G][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TL_BEGIN(a.dbg);
-  if (a.prio) __builtin_amdgcn_s_setprio(3);   // A/B: issue priority over the resident weight-streamer waves of the CU
-  if (a.prog && blockIdx.x == 0 && tid == 0) atomicAdd(a.prog, 1u);
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over the resident weight-streamer waves of the CU (B = 1 step -1.3 %)
   float* const qs = lds + wave * (G * HD);
   float* const partb = lds + 8 * G * HD;
   float* const att = partb + 8 * G * HD;

@@ -199,7 +199,6 @@ struct csm_engine {
   int kernel_prio = 7;         // s_setprio 3 at kernel entry (issue priority over the resident weight-streamer waves): bit 0 the fused decoder
                                // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
-  int stream_attn_oproj = 0;   // the fused decoder attention + o_proj launch in the weight streamer's schedule (round 2 form: slower; re-measured in round 5)
   int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
   int cmb_splits = 8;        // its split count (<= 8)
   int attn_oproj_gqa = 1;    // the fused launch in its key-split form (attn_oproj_gqa_kernel: K/V tiles shared by the query heads of a kv-head)
@@ -208,7 +207,7 @@ struct csm_engine {
   float* g16_slabs = nullptr;
   size_t g16_slab_floats = 0;
   int* g16_tickets = nullptr;
-  int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
+  static constexpr int nt_backbone = 1, nt_decoder = 2;   // decoder: the large streams (gate/up, down) non-temporal -- beside the weight streamer their
                                            // consumed lines are then the first victims in L2 (3.32 -> 3.30 ms per step)
   // KV splits of the backbone decode attention: the kernel is latency-bound per 32-key tile, so aim for
   // <= 2 tiles per workgroup at the current length (+ headroom for the frames of this generate call) while
@@ -236,17 +235,18 @@ struct csm_engine {
   unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
   unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
-  int pf_enable = 1, pf_window_mb = 6, pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
+  int pf_enable = 1, pf_window_mb = 6; static constexpr int pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
   // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
   static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
-  int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
-  int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
+  static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
+  static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
-  int pf_depth = 0, pf_seg_sleep = 0, pf_poll_sleep = 2;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
+  static constexpr int pf_depth = 0, pf_poll_sleep = 2;
+  int pf_seg_sleep = 0;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
   // streamer no longer slows the chain's latency-bound launches: B = 1 3.09 -> 2.95 ms (profiles/r05_b1_budget.md)   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
-  int pf_max_kb = 0;         // > 0: only launches whose matrix is at most this large are streamed whole (option prefetch_max_kb)
-  int pf_part_kb = 0;        // > 0: of larger matrices, stream only the first this-many KiB (option prefetch_part_kb)
+  static constexpr int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed whole
+  static constexpr int pf_part_kb = 0;       // > 0: of larger matrices, stream only the first this-many KiB (round 5 sweep: monotone worse)
   std::vector<PfGeom>* pf_rec = nullptr;   // non-null while a frame-step is being captured
   std::vector<PfGeom> last_geoms;          // launches of the last captured frame-step (debug / tools)
   uint32_t* dbg_buf = nullptr;             // debug probe: [launch][2048 workgroups][2] (csm_set_debug_buffer)
@@ -591,7 +591,6 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
   else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
-  else if (!strcmp(name, "stream_attn_oproj")) e->stream_attn_oproj = value < 0 ? 0 : (value > 2 ? 2 : value);
   else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
   else if (!strcmp(name, "combine_splits")) e->cmb_splits = value < 2 ? 2 : (value > 8 ? 8 : value);
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
@@ -619,17 +618,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "rows64")) e->rows64 = value < 0 ? -1 : (value ? 1 : 0);   // -1: 16-row launches only (tests: every wider form against gemm16_kernel)
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
-  else if (!strcmp(name, "prefetch_max_kb")) e->pf_max_kb = value < 0 ? 0 : value;
-  else if (!strcmp(name, "prefetch_part_kb")) e->pf_part_kb = value < 0 ? 0 : value;
-  else if (!strcmp(name, "nt_backbone")) e->nt_backbone = value < 0 ? 0 : (value > 2 ? 2 : value);
-  else if (!strcmp(name, "nt_decoder")) e->nt_decoder = value < 0 ? 0 : (value > 2 ? 2 : value);
-  else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
-  else if (!strcmp(name, "g16_k16")) e->g16_k16 = value < 0 ? 0 : value;
-  else if (!strcmp(name, "prefetch_grid")) e->pf_grid = value < 8 ? 8 : (value & ~7);
-  else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
-  else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
-  else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -803,18 +792,8 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     f.dbg = tl_slot(e);
     f.gqa = e->attn_oproj_gqa;
     f.prio = e->kernel_prio & 1;
-    const bool rec = e->pf_rec && e->stream_attn_oproj;   // its 2 MB of weights in the streamer's schedule too: 1 = as a paced launch of its own,
-    if (rec && e->stream_attn_oproj == 1) f.prog = e->d_prog;   // 2 = attached to the QKV launch in front of it (fetched with that launch's weights)
     ao = launch_attn_oproj(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, f);
     if (ao != -2) LCK(ao);
-    if (ao != -2 && rec) {
-      PfGeom g{};
-      const int K = nq * hd, tpr = K / (K >= 1024 ? 16 : 8), rows = 64 * nq / tpr;   // rows per workgroup (launchers.hip)
-      g.W = w.wo; g.N = H; g.K = K; g.esz = (int)w_esz(e); g.kind = 0; g.grid = H / rows; g.tpb = rows / 2; g.iters = 1; g.stride = 0;
-      g.ntask = H / 2; g.hd = hd; g.n_rope_heads = 0;
-      g.attach = e->stream_attn_oproj == 2;
-      e->pf_rec->push_back(g);
-    }
   }
   // B = 1 backbone (round 5): attention on few long splits with the K/V tiles shared by the query heads of a kv-head
   // (attn_decode_gqa_kernel), the split merge folded into the o_proj launch (gemv1_combine_kernel): five launches per layer
@@ -1811,23 +1790,15 @@ extern "C" int csm_forward_loss(csm_engine_t* e, const int64_t* ids, const uint8
 }
 
 static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, GraphEntry& ent) {
-  // launch index of every recorded geometry: an attached one (PfGeom::attach) shares the index of the paced launch in front of it
-  std::vector<int> lidx(geoms.size(), 0);
-  int n_paced = 0;
-  for (size_t i = 0; i < geoms.size(); ++i) {
-    if (geoms[i].attach && n_paced > 0) lidx[i] = n_paced - 1;
-    else lidx[i] = n_paced++;
-  }
-  ent.n_launch = n_paced;
+  ent.n_launch = (int)geoms.size();
   if (geoms.empty()) return 0;
   for (const PfGeom& g : geoms)
     if (g.exclusive) return 0;   // a launch that needs whole CUs to itself: the streamer would hold the chain up (gemm16.h)
   std::vector<PfSeg> segs;
   std::vector<size_t> bytes;
   const size_t sub = (size_t)e->pf_sub_kb << 10;
-  for (int gi = 0; gi < (int)geoms.size(); ++gi) {
-    const PfGeom& g = geoms[gi];
-    const int li = lidx[gi];
+  for (int li = 0; li < (int)geoms.size(); ++li) {
+    const PfGeom& g = geoms[li];
     if (g.kind < 0 || !g.W || g.grid < 1 || g.tpb < 1) continue;
     size_t rb = (size_t)g.K * g.esz;
     size_t per_block = (size_t)g.iters * 2 * g.tpb * rb;

@@ -32,8 +32,6 @@ struct PfGeom {
   int ntask;
   int hd, n_rope_heads;   // kind 1: head_dim, n_q + n_kv
   int exclusive;          // this launch's workgroups fill a CU's register file: nothing (no streamer) can stay resident beside it
-  int attach;             // 1: not a paced launch of its own (it does not bump the launch counter): its bytes ride with the PREVIOUS recorded
-                          // launch -- fetched when that launch's are, consumed (for the window) when that launch starts
 };
 constexpr int PF_STREAMER_VGPRS = 72;   // registers of weight_prefetch_kernel (checked by the build log); one wave per SIMD
 

@@ -128,24 +128,30 @@ int csm_bind_weights(csm_engine_t* e, const csm_weights_t* w);
 int csm_build_proj_table(csm_engine_t* e, float* proj_table_out);
 int csm_set_proj_table(csm_engine_t* e, const float* proj_table);
 int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; graphs stay */
-/* Engine options -- the COMPLETE list (ABI 6 removed 36 A/B knobs whose losing variants left the library; an unknown name is
- * CSM_ERR_ARG).  Defaults are the measured best; every call drops the captured graphs.
+/* Engine options -- the COMPLETE list (ABI 6 removed 36 A/B knobs whose losing variants left the library; round 5 added six names,
+ * no entry point: the ABI number is unchanged; an unknown name is CSM_ERR_ARG).  Defaults are the measured best; every call drops the captured graphs.
  *   precision:   "prefill_bf16" (context activations rounded to bf16), "prefill_mx" (context linears on the MX-fp8 matrix
  *                instruction; needs csm_bind_mx_weights), "prefill_bf16_attn" (context attention on the bf16 pipe in those
  *                modes), "decode_bf16" (batched decode on ONE nearest-even activation plane: the reference's own bf16 class)
  *   decode:      "nsplit_backbone" (KV splits of the backbone attention, 0 = by length), "fuse_attn_oproj" (B = 1 decoder
  *                attention + o_proj as one launch), "fuse_attn_combine" (backbone attention: the last KV split of a (row, head)
- *                merges the partials inside the launch), "fuse_sample" (greedy arg-max folded into the head launch),
+ *                merges the partials inside the launch), "fuse_sample" (B = 1: greedy arg-max folded into the head launch, top-k sampling into the next QKV launch),
  *                "two_token_pass" (positions 0 and 1 of the decoder as one 2-row pass, modeling_csm.py:534-552), "use_planes"
  *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (1: 17-128 rows in ONE launch per linear; 0: 32-row
  *                launches; -1: 16-row launches -- the forms the width tests compare against, bit for bit),
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
- *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 24)
+ *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 6: round 5), "prefetch_seg_sleep"
+ *                (its pause per 4 MiB run, default 0 since the decode kernels run at s_setprio 3), "kernel_prio" (bit mask of the
+ *                launch families that raise their issue priority: 1 decoder attention + o_proj, 2 GEMV / skinny GEMM, 4 backbone
+ *                attention + samplers; default 7), "attn_oproj_gqa" (B = 1 decoder attention + o_proj with the K/V tiles shared by
+ *                the query heads of a kv-head), "oproj_combine" / "combine_splits" (B = 1 backbone: split-KV merge inside the o_proj
+ *                launch, on this many splits <= 8)
  *   prefill:     "gemm_wide", "gemm_dma", "gemm_256", "gemm_dma_skinny", "gemm_mx_skinny" (tile selection of the context GEMMs:
  *                used by the bitwise tile-vs-tile tests), "prefill_splitk", "prefill_splitk_gu" (K splits of short prefills),
  *                "prefill_fuse_rope" (RoPE + cache append as the QKV GEMM's epilogue, modeling_llama.py:130-176 / 267-281),
  *                "prefill_fuse_quant" / "mx_fuse_swiglu" (MX quantisation fused into the producing kernels)
- *   measurement: "dbg_skip" (TIMING ONLY, wrong results: knock launch kinds out of the decode chain) */
+ *   measurement: "dbg_skip" (TIMING ONLY, wrong results: knock launch kinds out of the decode chain), "dbg_sample_spin" (TIMING ONLY:
+ *                every sampler launch idles this many 10 ns ticks first -- how a pause in the chain affects the weight streamer) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
 
 /* ---- CSMModel.forward, S>=1 rows on an empty or partly filled cache (modeling_csm.py:321-365).
