@@ -89,6 +89,20 @@ for streamer in (1, 0):
         st, en = raw[i, :g, 0], raw[i, :g, 1]
         rows.append((kind, grid, int(st.min()), int(st.max()), int(en.min()), int(en.max())))
     n = len(rows)
+    if a.md and streamer == 1:   # per-workgroup durations of the first launch of every (kind, grid): where inside a launch the time goes
+        import numpy as np
+        seen = set()
+        with open(a.md.replace(".md", "_per_wg.txt"), "w") as f:
+            for i, (kind, grid, s0, s1, e0, e1) in enumerate(rows[40:], 40):
+                if (kind, grid) in seen:
+                    continue
+                seen.add((kind, grid))
+                g = min(grid, 2047)
+                st, en = raw[i, :g, 0] - s0, raw[i, :g, 1] - s0
+                d = (en - st) / 100.0
+                q = lambda x, p: float(np.percentile(x, p))
+                f.write(f"{kind_name(kind)} wgs {grid}: start offset us p0/p50/p100 {q(st,0)/100:.2f}/{q(st,50)/100:.2f}/{q(st,100)/100:.2f}  "
+                        f"per-wg duration us p0/p10/p50/p90/p100 {q(d,0):.2f}/{q(d,10):.2f}/{q(d,50):.2f}/{q(d,90):.2f}/{q(d,100):.2f}  end p50/p100 {q(en,50)/100:.2f}/{q(en,100)/100:.2f}\n")
     if a.md:   # raw per-launch rows for offline analysis: kind, workgroups, first start, last start, first end, last end (10 ns ticks from the step's first start)
         with open(a.md.replace(".md", f"_raw_streamer{streamer}.csv"), "w") as f:
             for (kind, grid, s0, s1, e0, e1) in rows:
