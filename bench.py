@@ -281,12 +281,11 @@ def run_configs_235(model, cfg, dev):
 
 
 def lib_sha256() -> str:
-    """sha256 of the libcsm_hip.so this process runs (the PMC record names the build it was measured on)"""
-    import hashlib
-    from csm_hf_amd.build import LIB
-    path = os.environ.get("CSM_HIP_LIB") or LIB
+    """sha256 of the kernel SOURCES this library was built from (csm_hf_amd.build.sources_sha256): the PMC / timeline records name the
+    build they were measured on by it -- a rebuild of the same sources is the same build, whatever its bytes are"""
+    from csm_hf_amd.build import sources_sha256
     try:
-        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+        return sources_sha256()
     except OSError:
         return "unreadable"
 
@@ -314,7 +313,7 @@ def launch_kinds(batch: int):
         rec = json.load(open(os.path.join(ROOT, "profiles", f"launch_kinds_b{batch}.json")))
     except Exception:
         return None
-    rec["stale"] = rec.get("product_lib_sha256") != lib_sha256()
+    rec["stale"] = rec.get("src_sha256") != lib_sha256()
     return rec
 
 
@@ -325,9 +324,9 @@ def attach_traffic(dst: dict, rec: dict, algorithmic: float = None):
     if algorithmic:
         dst["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_step"] / float(algorithmic), 3)
     dst["traffic_source"] = rec.get("source", "profiles/hbm_traffic.json")
-    dst["traffic_lib_sha256"] = rec.get("lib_sha256")
+    dst["traffic_src_sha256"] = rec.get("src_sha256")
     dst["traffic_commit"] = rec.get("commit")
-    dst["traffic_stale"] = rec.get("lib_sha256") != lib_sha256()
+    dst["traffic_stale"] = rec.get("src_sha256") != lib_sha256()
 
 
 def pin_to_gpu_numa_node(local: int):
@@ -614,7 +613,7 @@ def main():
         rec = traffic_record(B, a.ctx, a.weights, a.opt)
         if rec is not None:
             attach_traffic(out["roofline"], rec, by)
-        out["lib_sha256"] = lib_sha256()
+        out["src_sha256"] = lib_sha256()
         lk = launch_kinds(B) if (a.ctx == 512 and a.weights == "bf16" and a.topk == 1) else None
         if lk is not None:
             out["roofline"]["launch_kinds"] = lk

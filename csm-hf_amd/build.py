@@ -35,6 +35,20 @@ def _sources_mtime() -> float:
     return m
 
 
+def sources_sha256() -> str:
+    """sha256 over the kernel sources and the C header (sorted file names + contents): identifies the BUILD INPUT of the library.  Measurement
+    records (profiles/hbm_traffic.json, profiles/launch_kinds_b*.json) are stamped with it and bench.py marks them stale when it differs --
+    a rebuilt library of the same sources is the same build, whatever its bytes are."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inc"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "csm_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
     """`defines` / `out`: A/B variants of the same ABI (e.g. ("CSM_NO_PROBE",) -> libcsm_hip_noprobe.so), selected at
     run time with the CSM_HIP_LIB environment variable."""

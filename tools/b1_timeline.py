@@ -146,7 +146,7 @@ for streamer in (1, 0):
         rec = {"batch": B, "ctx": a.ctx, "topk": a.topk, "launches_per_step": n, "step_us_probe_build": round(tot_gap + tot_body, 1),
                "how": "tools/b1_timeline.py: per-workgroup s_memrealtime at entry / after the last store in the -DCSM_TIMELINE build of the SAME sources "
                       "(5-6 % slower than the product build), streamer on; gap = previous launch's last end -> first start, body = first start -> last end",
-               "product_lib_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest() if os.path.exists(LIB) else None,
+               "src_sha256": __import__("csm_hf_amd.build", fromlist=["sources_sha256"]).sources_sha256(),
                "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
                "kinds": kinds}
         json.dump(rec, open(a.json, "w"), indent=1)
