@@ -271,7 +271,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     const int hq = j * G + h;
     if (a.nsplit == 1) {
-      a.out[(size_t)row * a.n_q * HD + (size_t)hq * HD + lane] = o * (1.f / L);
+      const float on = o * (1.f / L);
+      a.out[(size_t)row * a.n_q * HD + (size_t)hq * HD + lane] = on;
+      if (a.oplanes) {   // batched decode: the output also as MFMA B-operand planes for o_proj (rows 16.. : further plane groups)
+        const size_t ps = (size_t)a.n_q * HD * 16;
+        store_planes(a.oplanes + (size_t)(row >> 4) * 3 * ps, ps, hq * HD + lane, row & 15, on, a.pl1 != 0);
+      }
     } else {
       float* pp = a.part + (((size_t)row * a.n_q + hq) * a.nsplit + sp) * (HD + 4);
       pp[lane] = o;

@@ -199,6 +199,7 @@ struct csm_engine {
   int kernel_prio = 7;         // s_setprio 3 at kernel entry (issue priority over the resident weight-streamer waves): bit 0 the fused decoder
                                // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
+  int attn_gqa_wide = 1;     // backbone attention of > 32 rows on attn_decode_gqa_kernel
   int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
   int cmb_splits = 8;        // its split count (<= 8)
   int attn_oproj_gqa = 1;    // the fused launch in its key-split form (attn_oproj_gqa_kernel: K/V tiles shared by the query heads of a kv-head)
@@ -591,6 +592,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
   else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
+  else if (!strcmp(name, "attn_gqa_wide")) e->attn_gqa_wide = value ? 1 : 0;
   else if (!strcmp(name, "oproj_combine")) e->oproj_combine = value ? 1 : 0;
   else if (!strcmp(name, "combine_splits")) e->cmb_splits = value < 2 ? 2 : (value > 8 ? 8 : value);
   else if (!strcmp(name, "fuse_sample")) e->fuse_sample = value;
@@ -821,6 +823,10 @@ static int layer_decode(csm_engine* e, Stack& s, int l, int M, float* h, int ldh
     const bool att_planes = planes && (e->use_planes & 4);
     t.oplanes = att_planes ? e->pl_act : nullptr;
     t.pl1 = e->decode_bf16;
+    // round 5: batches too wide for the in-launch merge (> 32 rows) take the key-quarter kernel -- the four query heads of a kv-head share every
+    // K / V tile load; the backbone attention of a 128-row step is bound by its load instructions and bytes, not its arithmetic
+    t.gqa = (&s == &e->bb) && e->attn_gqa_wide && !t.tickets && M > 32;
+    t.prio = 0;
     t.dbg = tl_slot(e, (nsplit > 1 && !t.tickets) ? 2 : 1);
     if (!(sk & 2)) LCK(launch_attn(e->stream, e->cfg.kv_dtype, M, t));
     o.x = att;

@@ -13,7 +13,7 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.nsplit < 1 || a.nsplit > 64) return -1;
   if (a.oplanes && rows > 128) return -1;
   const int G = a.n_q / a.n_kv;
-  if (a.gqa && a.hd == 64 && G == 4 && !a.oplanes && !a.tickets) {
+  if (a.gqa && a.hd == 64 && G == 4 && !a.tickets && (!a.oplanes || rows <= 128)) {
     const int g2 = rows * a.n_kv * a.nsplit;
     if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_gqa_kernel<bf16_t>), dim3(g2), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_decode_gqa_kernel<float>), dim3(g2), dim3(256), 0, st, a);
