@@ -110,6 +110,24 @@ def test_b1_fused_topk_sampler_equals_the_sampler_launch_and_the_oracle(csm1b_bf
     a, _ = _b1_sampled(m, ids, mask, n, 1, noise=noise, topk=50, temperature=1.0)
     b, _ = _b1_sampled(m, ids, mask, n, 0, noise=noise, topk=50, temperature=1.0)
     assert torch.equal(a, b), int((a != b).sum())
+    # teacher-forced (the fed-back row comes from `forced`, the samples are still recorded) and per-row stop: fused == stand-alone launches
+    forced = torch.randint(0, V, (1, 64, C), generator=torch.Generator().manual_seed(9))
+    rec = []
+    for fuse in (1, 0):
+        eng = m._ensure_engine(1, ids.shape[1] + 7, 64, ids.shape[1])
+        eng.set_option("fuse_sample", fuse)
+        try:
+            eng.reset()
+            eng.set_kv_start([0])
+            eng.prefill(ids, mask, want_outputs=False)
+            fz = torch.zeros(1, eng.max_frames, C, dtype=torch.int64, device=DEV)
+            fz[:, :64] = forced.to(DEV)
+            eng.generate(eng.sampling(temperature=0.8, topk=20, seed=77, forced=fz, per_row_stop=True), 6, True)
+            eng.sync()
+            rec.append(eng.read_frames(0, 6).cpu())
+        finally:
+            eng.set_option("fuse_sample", 1)
+    assert torch.equal(rec[0], rec[1]), int((rec[0] != rec[1]).sum())
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     want = O.generate(sd, cfg, ids, mask, max_new_frames=n, temperature=1.0, topk=50, stop_on_all_zeros=False, noise=noise)
     same = (a == want)
