@@ -602,8 +602,9 @@ def main():
                     "algorithmic_bytes_per_launch": wb, "us_per_launch_chain": round(us, 3),
                     "achieved": round(wb / us / 1e3, 1), "unit": "GB/s", "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4),
                     "share_of_step_time": round(124 * us / (step_s * 1e6), 3),
-                    "how": "side chain of 200 dependent launches of this kernel (csm_bench_gemv), NOT read from the step; the "
-                           "in-step rocprofv3 trace (profiles/r04_b1_step_timeline.md, streamer off, under the profiler: 6.84 us duration) agrees"}
+                    "how": "side chain of 200 dependent launches of this kernel (csm_bench_gemv: no streamer beside it), NOT read from the "
+                           "step; in the step itself (roofline.launch_kinds, profiles/r05_b1_timeline.md) the same launch costs 1.6 us gap + "
+                           "3.8-3.9 us body with the streamer delivering part of its weights ahead (5.3 us of body without)"}
             except Exception as ex:      # never let the side measurement break the bench line
                 out["roofline"]["dominant_kernel"] = {"error": str(ex)[:200]}
         # `traffic`: HBM bytes per frame-step from the PMC counters.  Counters cannot be read inside this process, so the
