@@ -12,11 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcsm_hip.so")
-UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "gemm_mx", "train", "attn_prefill", "launchers", "engine", "mimi"]
+UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w1_k2", "gemv_w1_k4", "gemv_w2_k1", "gemv_w2_k2", "gemv_w2_k4", "gemm16", "gemm32", "gemm128", "gemm_mx", "train", "attn_prefill", "launchers", "engine", "mimi"]
 # gemm16 / gemm32: no implicit multiply-add contraction -- the batched decode launches of every width (16 / 32 / 64 / 128 rows,
 # several template instantiations of the same epilogues) must round alike, bit for bit (tests: logits of wide launches against
 # 16-row launches); the few fused operations these epilogues want are spelled out (__fmaf_rn)
-UNIT_FLAGS = {"attn_prefill": ["-mllvm", "--amdgpu-mfma-vgpr-form"], "gemm16": ["-ffp-contract=off"], "gemm32": ["-ffp-contract=off"]}
+UNIT_FLAGS = {"attn_prefill": ["-mllvm", "--amdgpu-mfma-vgpr-form"], "gemm16": ["-ffp-contract=off"], "gemm32": ["-ffp-contract=off"], "gemm128": ["-ffp-contract=off", "-mllvm", "--amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 
 

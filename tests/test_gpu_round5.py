@@ -194,3 +194,39 @@ def test_default_kv_cache_of_a_bf16_checkpoint_is_bf16_and_stays_in_the_referenc
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_ffn_launches_beyond_64_rows_on_gemm128_are_bitwise_the_gemm32_launches(csm1b_bf16, weights):
+    """65..128 batched rows: the FFN launches (gate/up with the RMS scale + SwiGLU, down_proj with the residual + output planes +
+    sums of squares; decoder and backbone shapes, K split across workgroups and two k groups in one workgroup) run on gemm128_kernel
+    (weight rows split over the waves, planes through LDS, csrc/gemm128.h) and must leave every logit and the backbone's last hidden
+    state equal, bit for bit, to the gemm32_kernel launches (`g128 = 0`): 70 rows (a partial fifth batch tile: clamped plane tile,
+    masked rows), 96, 128; exact planes and `decode_precision = "bf16"` (one plane); bf16 and fp8 weights (fragments widened in
+    registers, per-row scale in the epilogue); the other shape (one weight tile per wave, one k group per workgroup: `g128_shape = 65`) as well."""
+    m = csm1b_bf16
+    cfg = m.config
+    m._drop_engine()
+    m.weight_format = "fp8" if weights == "fp8" else "native"
+    try:
+        for B, precs in ((70, ("exact",)), (96, ("exact", "bf16")), (128, ("exact", "bf16"))):
+            ids, mask = synth_context(cfg, B, 10, 14, seed=61)
+            forced = torch.randint(0, cfg.audio_vocab_size, (B, 3, cfg.audio_num_codebooks), generator=torch.Generator().manual_seed(5))
+            for prec in precs:
+                m.decode_precision = prec
+                outs = []
+                for opts in ({"g128": 0}, {"g128": 1}, {"g128": 1, "g128_shape": 64 + 1}):
+                    T = ids.shape[1]
+                    eng = m._ensure_engine(B, T + 3 + 1, 3, B * T)
+                    for k, v in {"g128": 1, "g128_shape": 0, **opts}.items():
+                        eng.set_option(k, v)
+                    outs.append(_traced(m, ids, mask, 3, forced))
+                    assert m._engine is eng and (weights == "fp8") == bool(eng.fp8)
+                for o in outs[1:]:
+                    assert torch.equal(outs[0][0], o[0]), (B, prec, weights, "logits", float((outs[0][0] - o[0]).abs().max()))
+                    assert torch.equal(outs[0][1], o[1]), (B, prec, weights, "last_h")
+                assert float(outs[0][0].abs().max()) > 0
+    finally:
+        m.decode_precision = "exact"
+        m._drop_engine()
+        m.weight_format = "native"
