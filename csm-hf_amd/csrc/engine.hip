@@ -199,6 +199,7 @@ struct csm_engine {
   int kernel_prio = 7;         // s_setprio 3 at kernel entry (issue priority over the resident weight-streamer waves): bit 0 the fused decoder
                                // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
+  int g16_kfast = 1;   // K-split matrix-core launches: the k split as the fastest grid index
   int g128 = 1, g128_min = 64, g128_shape = 0;   // gemm128.h for the FFN launches of batches beyond g128_min rows (shape: A/B override)
   int attn_gqa_wide = 1;     // backbone attention of > 32 rows on attn_decode_gqa_kernel
   int oproj_combine = 1;     // B = 1 backbone: split-KV merge folded into the o_proj launch (gemv1_combine_kernel), attention on bb_nsplit_b1 long splits
@@ -594,6 +595,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
   else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
+  else if (!strcmp(name, "g16_kfast")) e->g16_kfast = value != 0;
   else if (!strcmp(name, "g128")) e->g128 = value != 0;
   else if (!strcmp(name, "g128_min")) e->g128_min = value < 32 ? 32 : value;
   else if (!strcmp(name, "g128_shape")) e->g128_shape = value;
@@ -690,6 +692,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       const int cap = (e->rows64 > 0 && m0 % 128 == 0 && left > 64) ? 128 : ((e->rows64 > 0 && m0 % 64 == 0 && left > 32) ? 64 : 32);
       const int m = left < cap ? left : cap;
       slice(m);
+      a.kfast = e->g16_kfast;
       int r = -2;
       if (e->g128 && m > e->g128_min) {   // 65..128 rows, FFN launches: weight rows split over the waves, planes shared through LDS (gemm128.h)
         a.g128_shape = e->g128_shape;
@@ -718,6 +721,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       if (e->g16_slab >> 4) a.g16_slab = (a.g16_slab & 3) | (e->g16_slab & ~15);   // TIMING-ONLY in-kernel knock-outs (gemm16.h), every matrix-core launch
       a.dbg = tl_slot(e);
       a.prio = (e->kernel_prio >> 1) & 1;
+      a.kfast = rec ? 0 : e->g16_kfast;   // (the streamer's recorded geometry is panels-fastest)
       const int r = launch_gemm16(e->stream, e->cfg.weight_dtype, e->cfg.kv_dtype, m, pro, epi, a, e->g16_slabs,
                                   e->g16_slab_floats, e->g16_tickets, 4096);
       a.prog = nullptr; a.geom_out = nullptr;

@@ -133,12 +133,17 @@ __global__ __launch_bounds__(256 * H) void gemm128_kernel(const G128Args a) {
   const int K = a.K;
   const int m = lane & 15, g = lane >> 4;
   const int mtiles = (M + 15) >> 4;
+  // K split across workgroups (KB > 1): the k group is the FASTEST grid index, so that the workgroups of one group -- they read the same
+  // 1 024-wide slice of the planes -- run on one XCD (workgroup id mod 8 with KB = 8) and that slice (786 KB at 128 rows) stays in its
+  // L2; with the panels fastest every XCD walked all 6.3 MB of a down_proj's planes (FETCH_SIZE 75 MB per launch for 17 MB of weights)
+  const int pid = KB > 1 ? (int)blockIdx.y : (int)blockIdx.x, np = KB > 1 ? (int)gridDim.y : (int)gridDim.x;   // panel of 4 x PT weight tiles
+  const int kid = KB > 1 ? (int)blockIdx.x : 0;                                                                 // k group
   const int mt0 = (int)blockIdx.z * 4;
   const int mtw = (wave >> 2) * MT;                                    // this wave's first batch tile among the workgroup's four
-  const int bx = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;   // slab / ticket slot
-  const int wp = (int)blockIdx.x * 4 + (wave & 3);                     // this wave's panel of PT weight tiles
+  const int bx = (int)blockIdx.z * np + pid;                           // slab / ticket slot
+  const int wp = pid * 4 + (wave & 3);                     // this wave's panel of PT weight tiles
   const int G = (K >> 10) / KB;                                        // 1 024-wide k groups of this workgroup: one (K split across workgroups) or all (KB == 1)
-  const int c0 = (int)blockIdx.y * 8 * G;                              // first 128-wide chunk of this workgroup
+  const int c0 = kid * 8 * G;                              // first 128-wide chunk of this workgroup
   const size_t ps = (size_t)K * 16;
 
   // ---- epilogue inputs first (oldest in the vmcnt queue): residual quads, the consumer's norm weight, the sums of squares ----------
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256 * H) void gemm128_kernel(const G128Args a) {
     constexpr int U = 4 * H * PT * MT;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
     const unsigned tile_b = (unsigned)((wave * PT * MT) * 1024 + lane * 16);
-    const unsigned slab_off = (unsigned)(((size_t)bx * KB + blockIdx.y) * (U * 256) * sizeof(float)) + tile_b;
+    const unsigned slab_off = (unsigned)(((size_t)bx * KB + kid) * (U * 256) * sizeof(float)) + tile_b;
 #pragma unroll
     for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(256 * H) void gemm128_kernel(const G128Args a) {
   }
   if ((ko & 64) && lane == 0 && wave < 4) a.dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 16 + 9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
   if ((ko & 64) && lane == 0 && wave < 4) a.dbg[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 16 + 13] = (uint32_t)__builtin_amdgcn_s_memtime();
-  if (a.bump_a && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+  if (a.bump_a && pid == 0 && blockIdx.z == 0 && tid == 0) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }

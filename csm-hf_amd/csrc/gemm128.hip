@@ -26,7 +26,7 @@ static int launch_g128(hipStream_t st, int M, int KB, const GemvArgs& a, float* 
   g.Wt = a.Wt; g.xplanes = a.xplanes; g.xss = a.xss; g.oplanes = a.oplanes; g.oln = a.oln; g.oss = a.oss; g.out = a.out; g.wscale = a.wscale;
   g.slabs = slabs; g.tickets = tickets; g.bump_a = a.bump_a; g.bump_b = a.bump_b; g.dbg = nullptr;
   g.xss_n = a.xss_n; g.xss_ld = a.xss_ld; g.oss_ld = a.oss_ld; g.ldo = a.ldo; g.K = a.K; g.N = a.N; g.M = M; g.KB = KB; g.eps = a.eps;
-  hipLaunchKernelGGL(fn, dim3(gx, KB, Z), dim3(256 * H), lds, st, g);
+  hipLaunchKernelGGL(fn, KB > 1 ? dim3(KB, gx, Z) : dim3(gx, 1, Z), dim3(256 * H), lds, st, g);   // K split: the k group fastest (gemm128.h)
   return (int)hipGetLastError();
 }
 
@@ -46,7 +46,10 @@ static int launch_gemm128_t(hipStream_t st, int M, int pro, int epi, const GemvA
     return launch_g128<WT, PRO_NORM, EPI_SWIGLU, 2>(st, M, groups, a, slabs, sf, tk, nt);
   }
   if (pro == PRO_PLAIN && epi == EPI_RESID && a.K > 2048) {   // down_proj; the o_proj launches (K = 1 024 / 2 048: 8-16 workgroups here) stay on gemm32.h
-    if (pt == 2) return launch_g128<WT, PRO_PLAIN, EPI_RESID, 2>(st, M, groups, a, slabs, sf, tk, nt);
+    // one weight tile per wave while that fills the chip in one round (decoder: 16 panels x 8 k groups x 2 row groups = 256 workgroups);
+    // two for the backbone's 2 048 rows (the same 256 instead of 512 in two rounds)
+    const bool two = pt ? pt == 2 : (size_t)(a.N / 64) * groups * ((M + 63) / 64) > 256;
+    if (two) return launch_g128<WT, PRO_PLAIN, EPI_RESID, 2>(st, M, groups, a, slabs, sf, tk, nt);
     return launch_g128<WT, PRO_PLAIN, EPI_RESID, 1>(st, M, groups, a, slabs, sf, tk, nt);
   }
   return -2;

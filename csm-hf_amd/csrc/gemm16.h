@@ -119,14 +119,19 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   int* flag = reinterpret_cast<int*>(panel + PT * 256);
   float* stat = panel + PT * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // K split across workgroups with a.kfast: the k split is the FASTEST grid index (launcher: dim3(KB, panels)), so that the workgroups that
+  // read the same k slice of the activation planes run on one XCD (workgroup id mod 8) and share it in that L2 (round 5, gemm128.h)
+  const bool kf = KB > 1 && a.kfast;
+  const int bix = kf ? (int)blockIdx.y : (int)blockIdx.x, biy = kf ? (int)blockIdx.x : (int)blockIdx.y, gdx = kf ? (int)gridDim.y : (int)gridDim.x;
+  (void)gdx;
   TL_BEGIN(a.dbg);
   if (a.prio) __builtin_amdgcn_s_setprio(3);
-  if (a.prog && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing
+  if (a.prog && bix == 0 && biy == 0 && tid == 0) atomicAdd(a.prog, 1u);   // weight streamer pacing
   const int K = a.K;
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const int m = lane & 15, g = lane >> 4;
   const bool mlive = m < M;
-  const int chunk = (int)blockIdx.y * NW + wave;          // 128-wide k chunk of this wave
+  const int chunk = biy * NW + wave;          // 128-wide k chunk of this wave
   const int k0 = chunk * 128 + (TL ? g * 8 : g * 32);     // first k of this lane; step j adds (TL ? 32 : 8) * j
   constexpr int KJ = TL ? 32 : 8;
 
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     if (QUAD) {
       if (EPI == EPI_RESID && tid < PT * 64) {
         const int t = tid >> 6, l = tid & 63, mm = l & 15;
-        const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+        const int n0 = g16_row<EPI, PT>(a, bix, t, (l >> 4) * 4);
         if (mm < M && n0 < a.N) {
           rq = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
           if (a.oplanes && a.oln) lq = *reinterpret_cast<const f32x4*>(a.oln + n0);   // the consumer's norm weight
@@ -165,12 +170,12 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       if (i < PT * 256) {
         const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
         const int mm = l & 15, r = (l >> 4) * 4 + reg;
-        const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+        const int n = g16_row<EPI, PT>(a, bix, t, r);
         if (mm < M && n < a.N) {
           if (EPI == EPI_QKV) {
             ppos[e] = row_position(a.row_pos, mm, a.pos_ptr, a.pos_const);
             const int half = a.hd >> 1, spp = half / 16;
-            const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
+            const int head = bix / spp, sidx = bix - head * spp;
             if (t == 0 && head < a.n_q + a.n_kv) {
               pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
               pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       // tile index of this panel tile (its first row is a multiple of 16); rows >= N are zero in the copy
       // (the last panel of a matrix whose tile count is not a multiple of PT -- the 2 051-row heads -- must not read past the copy: its
     //  extra tiles re-read the last real one and are dropped by the epilogue's n < N)
-    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
+    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, bix, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
       const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
         wf[t][j].load(wr + j * 512, a.nt);
       }
     } else {
-      int n = g16_row<EPI, PT>(a, blockIdx.x, t, lane & 15);
+      int n = g16_row<EPI, PT>(a, bix, t, lane & 15);
       n = n < a.N ? n : a.N - 1;  // clamp (partial last tile); results of clamped rows are never stored
       const WT* wr = W + (size_t)n * K + k0;
 #pragma unroll
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     // A two-launch variant (partials, then a reduce kernel) measured the same or slower (dec 11.7 vs 11.1 us,
     // backbone 19.6 vs 16.9 us at M = 16). ---------------------
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
-    const unsigned slab_off = (unsigned)(((size_t)blockIdx.x * KB + blockIdx.y) * (PT * 256) * sizeof(float));
+    const unsigned slab_off = (unsigned)(((size_t)bix * KB + biy) * (PT * 256) * sizeof(float));
 #pragma unroll
     for (int e = 0; e < NQ; ++e) {
       const int q = tid + e * 64 * NW;
@@ -364,14 +369,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const int tk = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int tk = __hip_atomic_fetch_add(tickets + bix, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = tk == KB - 1;
-      if (last) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last) __hip_atomic_store(tickets + bix, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *flag = last;
     }
     __syncthreads();
     if (!*flag) { TL_END(0x70 + EPI + 8 * PRO); return; }
-    const unsigned base_off = (unsigned)((size_t)blockIdx.x * KB * (PT * 256) * sizeof(float));
+    const unsigned base_off = (unsigned)((size_t)bix * KB * (PT * 256) * sizeof(float));
     for (int q = tid; q < PT * 64; q += 64 * NW) {
       f32x4 v[16];  // all KB (<= 16) slab loads in flight at once, then a fixed-order sum
 #pragma unroll
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
   if (QUAD) {
     if (tid < PT * 64) {
       const int t = tid >> 6, l = tid & 63, mm = l & 15;
-      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      const int n0 = g16_row<EPI, PT>(a, bix, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         f32x4 pv = *reinterpret_cast<const f32x4*>(panel + t * 256 + l * 4);
         // XP + norm: the planes carry x * norm_weight, the RMS scale of the row multiplies the finished dot product
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     const int t = i >> 8, l = (i >> 2) & 63, reg = i & 3;
     const int mm = l & 15, r = (l >> 4) * 4 + reg;
     if (mm >= M) continue;
-    const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+    const int n = g16_row<EPI, PT>(a, bix, t, r);
     if (n >= a.N) continue;
     // XP + norm: the planes carry x * norm_weight, the RMS scale of the row multiplies the finished dot product
     const float rs = (XP && PRO == PRO_NORM) ? stat[mm] : 1.f;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
       }
     } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
       const int half = a.hd >> 1, spp = half / 16;
-      const int head = blockIdx.x / spp, s = blockIdx.x - head * spp;
+      const int head = bix / spp, s = bix - head * spp;
       const int hi = s * 16 + r;  // index inside the half
       const int b = a.row_seq ? a.row_seq[mm] : a.seq_base + mm;
       const int pos = ppos[e];
@@ -483,14 +488,14 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(GemvArgs a, int M, int 
     __syncthreads();
     if (tid < PT * 16) {
       const int t = tid >> 4, mm = tid & 15;
-      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
+      const int n0 = g16_row<EPI, PT>(a, bix, t, 0);
       if (mm < M && n0 < a.N) {
         const float q = (red[t * 64 + mm] + red[t * 64 + 16 + mm]) + (red[t * 64 + 32 + mm] + red[t * 64 + 48 + mm]);
         a.oss[(size_t)mm * a.oss_ld + (n0 >> 4)] = q;
       }
     }
   }
-  if (a.bump_a && blockIdx.x == 0 && tid == 0) {
+  if (a.bump_a && bix == 0 && tid == 0) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }

@@ -27,10 +27,10 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
     }
   }
   if (a.pl1 && !a.xplanes && a.oplanes) return -1;   // one-plane mode exists on the planes path only (every producer of planes is itself fed planes)
-  if (a.xplanes && a.pl1) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true, true>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  if (a.xplanes && a.pl1) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  else if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 

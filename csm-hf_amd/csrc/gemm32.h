@@ -23,13 +23,18 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   int* flag = reinterpret_cast<int*>(panel + U * 256);
   float* stat = panel + U * 256 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // K split across workgroups with a.kfast: the k split is the FASTEST grid index (launcher: dim3(KB, panels)), so that the workgroups that
+  // read the same k slice of the activation planes run on one XCD (workgroup id mod 8) and share it in that L2 (round 5, gemm128.h)
+  const bool kf = KB > 1 && a.kfast;
+  const int bix = kf ? (int)blockIdx.y : (int)blockIdx.x, biy = kf ? (int)blockIdx.x : (int)blockIdx.y, gdx = kf ? (int)gridDim.y : (int)gridDim.x;
+  (void)gdx;
   const int K = a.K;
   const int m = lane & 15, g = lane >> 4;
-  const int chunk = (int)blockIdx.y * NW + wave;
+  const int chunk = biy * NW + wave;
   // batch rows split across workgroups (blockIdx.z): this workgroup owns the batch tiles mt0 .. mt0 + MT - 1 of the launch.  The
   // small launches of a 128-row step (QKV: 48 panels) otherwise leave most of the chip idle while every wave walks 786 KB of planes
   const int mt0 = (int)blockIdx.z * MT;
-  const int bx = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;   // slab / ticket slot of this (panel, row group)
+  const int bx = (int)blockIdx.z * gdx + bix;   // slab / ticket slot of this (panel, row group)
   constexpr bool QUAD = (EPI == EPI_RESID || EPI == EPI_SWIGLU);
   constexpr int NQE = (U * 64 + 64 * NW - 1) / (64 * NW);   // epilogue quads per thread (2 with eight batch tiles x two weight tiles)
   constexpr int NE = (U * 256 + 64 * NW - 1) / (64 * NW);
@@ -46,11 +51,11 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       if (i < U * 256) {
         const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
         const int mm = (mt0 + mt) * 16 + (l & 15), r = (l >> 4) * 4 + reg;
-        const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+        const int n = g16_row<EPI, PT>(a, bix, t, r);
         if (mm < M && n < a.N) {
           ppos[e] = row_position(a.row_pos, mm, a.pos_ptr, a.pos_const);
           const int half = a.hd >> 1, spp = half / 16;
-          const int head = blockIdx.x / spp, sidx = blockIdx.x - head * spp;
+          const int head = bix / spp, sidx = bix - head * spp;
           if (t == 0 && head < a.n_q + a.n_kv) {
             pre0[e] = a.cos_tab[(size_t)ppos[e] * half + sidx * 16 + r];
             pre1[e] = a.sin_tab[(size_t)ppos[e] * half + sidx * 16 + r];
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   for (int t = 0; t < PT; ++t) {
     // (the last panel of a matrix whose tile count is not a multiple of PT -- the 2 051-row heads -- must not read past the copy: its
     //  extra tiles re-read the last real one and are dropped by the epilogue's n < N)
-    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, blockIdx.x, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
+    const size_t tile = (size_t)min(g16_row<EPI, PT>(a, bix, t, 0) >> 4, ((a.N + 15) >> 4) - 1);
     const WT* wr = reinterpret_cast<const WT*>(a.Wt) + ((tile * (size_t)(K >> 7) + chunk) * 4) * 512 + lane * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[t][j].load(wr + j * 512, a.nt);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
     const int q = tid + e * 64 * NW;
     if (EPI == EPI_RESID && q < U * 64) {
       const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = (mt0 + mt) * 16 + (l & 15);
-      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      const int n0 = g16_row<EPI, PT>(a, bix, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         rq[e] = *reinterpret_cast<const f32x4*>(a.out + (size_t)mm * a.ldo + n0);
         if (a.oplanes && a.oln) lq[e] = *reinterpret_cast<const f32x4*>(a.oln + n0);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
   }
   if (KB > 1) {   // split-K across workgroups: 16-byte sc1 slab stores + ticket, the last arriver combines with sc1 loads (gemm16.h)
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, 0x7ffffff0, 0x00020000);
-    const unsigned slab_off = (unsigned)(((size_t)bx * KB + blockIdx.y) * (U * 256) * sizeof(float));
+    const unsigned slab_off = (unsigned)(((size_t)bx * KB + biy) * (U * 256) * sizeof(float));
 #pragma unroll
     for (int e = 0; e < NQ; ++e) {
       const int q = tid + e * 64 * NW;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       const int q = tid + e * 64 * NW;
       if (q >= U * 64) continue;
       const int u = q >> 6, t = u / MT, mt = u - t * MT, l = q & 63, mm = (mt0 + mt) * 16 + (l & 15);
-      const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, (l >> 4) * 4);
+      const int n0 = g16_row<EPI, PT>(a, bix, t, (l >> 4) * 4);
       if (mm < M && n0 < a.N) {
         f32x4 pv = *reinterpret_cast<const f32x4*>(panel + u * 256 + l * 4);
         const float rs = (PRO == PRO_NORM) ? stat[mt * 16 + (l & 15)] : 1.f;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       __syncthreads();
       if (tid < U * 16) {
         const int u = tid >> 4, t = u / MT, mt = u - t * MT, mm = (mt0 + mt) * 16 + (tid & 15);
-        const int n0 = g16_row<EPI, PT>(a, blockIdx.x, t, 0);
+        const int n0 = g16_row<EPI, PT>(a, bix, t, 0);
         if (mm < M && n0 < a.N) {
           const int c = tid & 15;
           a.oss[(size_t)mm * a.oss_ld + (n0 >> 4)] = (red[u * 64 + c] + red[u * 64 + 16 + c]) + (red[u * 64 + 32 + c] + red[u * 64 + 48 + c]);
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       const int u = i >> 8, t = u / MT, mt = u - t * MT, l = (i >> 2) & 63, reg = i & 3;
       const int mm = (mt0 + mt) * 16 + (l & 15), r = (l >> 4) * 4 + reg;
       if (mm >= M) continue;
-      const int n = g16_row<EPI, PT>(a, blockIdx.x, t, r);
+      const int n = g16_row<EPI, PT>(a, bix, t, r);
       if (n >= a.N) continue;
       const float rs = (PRO == PRO_NORM) ? stat[mt * 16 + (l & 15)] : 1.f;
       const float v = panel[i] * (a.wscale ? a.wscale[n] : 1.f) * rs;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
         a.out[(size_t)mm * a.ldo + n] = v;
       } else {  // EPI_QKV, PT == 2: tile 0 = first RoPE half, tile 1 = second half of the same head rows
         const int half = a.hd >> 1, spp = half / 16;
-        const int head = blockIdx.x / spp, s = blockIdx.x - head * spp;
+        const int head = bix / spp, s = bix - head * spp;
         const int hi = s * 16 + r;
         const int b = a.row_seq ? a.row_seq[mm] : a.seq_base + mm;
         const int pos = ppos[e];
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int 
       }
     }
   }
-  if (a.bump_a && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+  if (a.bump_a && bix == 0 && blockIdx.z == 0 && tid == 0) {
     *a.bump_a += 1;
     if (a.bump_b) *a.bump_b += 1;
   }

@@ -25,7 +25,7 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
     }
   }
   if (a.configure_only) return 0;
-  hipLaunchKernelGGL(fn, dim3(gx, KB, Z), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  hipLaunchKernelGGL(fn, (KB > 1 && a.kfast) ? dim3(KB, gx, Z) : dim3(gx, KB, Z), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
   return (int)hipGetLastError();
 }
 

@@ -99,6 +99,7 @@ struct GemvArgs {
   int norm_ks;         // host-side: 2 = single-row normed launches with K = 2048 take the register path with two waves per task (K split in the workgroup)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
+  int kfast;                   // gemm16.h / gemm32.h with K split across workgroups: the k split as the fastest grid index (planes of a k slice in one XCD's L2)
   int g128_shape;              // host-side A/B override of gemm128.hip's shape choice (0 = auto): low nibble = weight tiles per wave, bit 4 = split K across workgroups
   int g16_slab;  // bits 4-7: TIMING-ONLY knock-outs of the -DCSM_G16_KO variant build (gemm16.h); the split-K slab exchange is write-through (sc1) stores + sc1 loads
   // weight streamer (prefetch.h): launches-started counter bumped by workgroup 0 (nullable), and a host-side slot

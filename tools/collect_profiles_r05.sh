@@ -34,19 +34,21 @@ cd $R
 rm -rf $O/b128o
 # gemm128_kernel alone, with its chunk time stamps (tools/ubench/g128_bench.hip; -DCSM_G128_VARIANT=64 build)
 if [ -x tools/ubench/bin/g128_bench_h1_0 ]; then
-  { for b in tools/ubench/bin/g128_bench_h1_0 tools/ubench/bin/g128_bench_h1_64 tools/ubench/bin/g128_bench_h2_0; do for k in gateup down; do timeout 60 $b $k 300 | head -4 | cut -c1-260; done; done
+  { for b in tools/ubench/bin/g128_bench_h1_0 tools/ubench/bin/g128_bench_h1_64; do for k in gateup down; do timeout 60 $b $k 300 | head -4 | cut -c1-260; done; done
     timeout 60 tools/ubench/bin/g128_bench_h1_0 gateup 300 64; timeout 60 tools/ubench/bin/g128_bench_h1_0 down 300 64; } > $O/g128_ubench.txt 2>&1
 fi
 # HBM traffic (separate --pmc passes): B = 1 and the config-4 per-GPU shape
 bash tools/collect_pmc.sh $O > $O/pmc_b1.log 2>&1
 bash tools/collect_pmc.sh $O "--batch 16" > $O/pmc_b16.log 2>&1
+bash tools/collect_pmc.sh $O "--batch 128" > $O/pmc_b128.log 2>&1
+bash tools/collect_pmc.sh $O "--batch 128 --opt g128=0" > $O/pmc_b128off.log 2>&1
 # in-step timelines (streamer on) + the per-launch-kind tables the bench line attaches
 CSM_TL_LIB=$R/csm-hf_amd/libcsm_hip_timeline.so timeout 600 python tools/b1_timeline.py --md $O/b1_timeline.md --json $O/launch_kinds_b1.json > /dev/null 2>&1
 CSM_TL_LIB=$R/csm-hf_amd/libcsm_hip_timeline.so timeout 600 python tools/b1_timeline.py --topk 50 --md $O/b1_timeline_topk50.md > /dev/null 2>&1
 CSM_TL_LIB=$R/csm-hf_amd/libcsm_hip_timeline.so timeout 600 python tools/b1_timeline.py --batch 16 --md $O/b16_timeline.md --json $O/launch_kinds_b16.json > /dev/null 2>&1
 # other configurations through the bench
 : > $O/bench_other_configs.jsonl
-for extra in "--opt weight_prefetch=0" "--topk 50 --temperature 0.9" "--topk 50 --temperature 0.9 --opt fuse_sample=0" "--batch 16 --steps 100" "--batch 16 --topk 50 --temperature 1.0 --steps 100" \
+for extra in "--opt weight_prefetch=0" "--topk 50 --temperature 0.9" "--topk 50 --temperature 0.9 --opt fuse_sample=0" "--batch 16 --steps 100" "--batch 16 --steps 100 --opt g16_kfast=0" "--batch 16 --topk 50 --temperature 1.0 --steps 100" \
              "--weights fp8 --ctx 2048 --steps 500 --warmup 4" "--ctx 2048" "--kv-dtype bf16" "--batch 64 --steps 50" "--batch 96 --steps 30" "--batch 128 --steps 30" "--batch 128 --steps 30 --opt g128=0" "--batch 128 --steps 30 --kv-dtype bf16"; do
   timeout 300 python bench.py --no-cpu-baseline --config4 0 $extra >> $O/bench_other_configs.jsonl 2>> $O/bench_other.err
 done

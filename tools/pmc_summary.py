@@ -15,7 +15,7 @@ def per_kernel(path, counter, frames):
     # pattern and put 0.74 GB per step of prefill attention into the round-3 record.
     q = ("select name, counter_value from pmc_events where counter_name=? and (name like '%gemv%' or "
          "name like '%attn_decode%' or name like '%attn_combine%' or name like '%attn_oproj%' or name like '%gemm16_kernel%' or "
-         "name like '%gemm32_kernel%' or name like '%dec_persist%' or name like 'sample_kernel%' or name like '%embed_sum%') "
+         "name like '%gemm32_kernel%' or name like '%gemm128_kernel%' or name like '%dec_persist%' or name like 'sample_kernel%' or name like '%embed_sum%') "
          "and name not like '%at::native%' and name not like '%prefill%'")
     per = {}
     for name, v in db.cursor().execute(q, (counter,)):
@@ -32,12 +32,12 @@ frames = float(sys.argv[2])
 rows = per_kernel(sys.argv[1], "FETCH_SIZE", frames)
 raw_kib = sum(r[2] for r in rows)
 out = {
-    "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, gemm16 / gemm32, attn_decode / combine / oproj, dec_persist, sample, embed_sum; no prefill kernel)",
+    "counter": "FETCH_SIZE (KiB), decode-path kernels only (gemv*, gemm16 / gemm32 / gemm128, attn_decode / combine / oproj, dec_persist, sample, embed_sum; no prefill kernel)",
     "frames_profiled": frames,
     "fetch_kib_raw_per_step": raw_kib / frames,
     "gfx950_wide_read_correction": 2.0,
     "hbm_read_bytes_per_step": int(2.0 * raw_kib * 1024 / frames),
-    "top_kernels": [{"kernel": r[0][:80], "launches": r[1], "avg_MB_corrected": round(2.0 * r[2] / r[1] / 1024, 3)} for r in rows[:8]],
+    "top_kernels": [{"kernel": r[0][:80], "launches": r[1], "avg_MB_corrected": round(2.0 * r[2] / r[1] / 1024, 3)} for r in rows[:10]],
 }
 if len(sys.argv) > 3:
     w = per_kernel(sys.argv[3], "WRITE_SIZE", frames)

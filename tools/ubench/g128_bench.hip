@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (down) hipLaunchKernelGGL(fd, dim3(gx, KB, Z), dim3(256 * CSM_G128_H), lds, st, a);
+    if (down) hipLaunchKernelGGL(fd, dim3(KB, gx, Z), dim3(256 * CSM_G128_H), lds, st, a);
     else hipLaunchKernelGGL(fu, dim3(gx, KB, Z), dim3(256 * CSM_G128_H), lds, st, a);
   };
   for (int i = 0; i < 20; ++i) launch();
