@@ -17,7 +17,8 @@ def test_committed_records_match_the_kernel_sources():
     assert {(r["batch"], r["ctx"], r["weights"]) for r in recs} >= {(1, 512, "bf16"), (16, 512, "bf16")}
     for r in recs:
         assert r.get("src_sha256") == sha, ("profiles/hbm_traffic.json is stale for", r["batch"], r.get("commit"))
-        assert 0.9 * 9.0e9 < r["hbm_bytes_per_step"] < 1.6 * 9.7e9
+        # weights 9.0-9.7 GB per step; beyond 16 rows the fp32 KV cache of the rows (4.3 + 2.4 GB at 128 rows) and the planes' L2 misses add to it
+        assert 0.9 * 9.0e9 < r["hbm_bytes_per_step"] < (1.6 if r["batch"] <= 16 else 3.2) * 9.7e9
     for b in (1, 16):
         lk = json.load(open(os.path.join(ROOT, "profiles", f"launch_kinds_b{b}.json")))
         assert lk["src_sha256"] == sha, f"profiles/launch_kinds_b{b}.json is stale"
