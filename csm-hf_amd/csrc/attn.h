@@ -59,8 +59,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   int blk = blockIdx.x;
   int g0 = wave, gstep = 4;
   if (a.one_wave) {
-    g0 = blk % G;
-    blk /= G;
+    // the G one-wave workgroups of a (row, kv-head) read the same K / V tile: `per` workgroups apart in the grid, i.e. on ONE XCD when
+    // rows x kv-heads is a multiple of 8 (workgroup id mod 8), so that three of the four reads hit that XCD's L2.  As the fastest index
+    // (round 4) they sat on four XCDs: 19 MB fetched per decoder attention launch of a 128-row step for 4-8 MB of K / V
+    const int per = (int)gridDim.x / G;
+    g0 = blk / per;
+    blk -= g0 * per;
     gstep = G;
   }
   const int sp = blk % a.nsplit;
