@@ -23,6 +23,7 @@ struct PrefillAttnArgs {
                         // running batch prefilled at once); kv_start is indexed by the slot too.  q / out rows stay b * S + s
   int map;              // attn_prefill_bf16_kernel: 1 = alternate waves of 256 workgroups walk the query tiles in ascending order (see the kernel)
   uint8_t* oq;          // nullable (attn_prefill_bf16_kernel only): output as MX-fp8 rows [B*S][n_q*64] e4m3 + os [B*S][n_q*2] E8M0 scales
+  int kvfast;           // attn_prefill_bf16_kernel: grid (n_kv, query tiles, B) instead of (query tiles, n_kv, B)
   uint8_t* os;          // (the OCP recipe of mx_quant_rows_kernel, gemm_mx.h; a 32-block = half a head = the lane pair of a query row) instead of `out`
 };
 
@@ -235,15 +236,23 @@ __global__ __launch_bounds__(256) void attn_prefill_bf16_kernel(PrefillAttnArgs 
   // every other wave of 256 workgroups walks the tiles in ascending order, so that the two workgroups of a CU (dispatch slots n and
   // n + 256) hold a long and a short tile: 2 048 frames 5.69 -> 5.51 ms (bf16), 4.36 -> 4.17 ms (mxfp8).  (Pairing neighbours in
   // dispatch order instead: no change -- the dispatcher is round-robin over the CUs.)
-  int qt = gridDim.x - 1 - blockIdx.x;   // longest (latest) query tiles are dispatched first
-  if (a.map == 1) {
+  // a.kvfast (n_kv == 8): the kv-head is the FASTEST grid index, i.e. workgroup id mod 8 = XCD = kv-head: every query tile of a head reads
+  // that head's K / V through ONE L2 instead of eight (round 5; the decode kernels' k-split / query-head grouping, same reason)
+  const int bxq = a.kvfast ? (int)blockIdx.y : (int)blockIdx.x, nqx = a.kvfast ? (int)gridDim.y : (int)gridDim.x;
+  int qt = nqx - 1 - bxq;   // longest (latest) query tiles are dispatched first
+  if (a.map == 1 && a.kvfast) {
+    // rounds of 256 workgroups = 32 query positions x 8 heads: even rounds walk down from the latest tile, odd rounds up from the first,
+    // so that dispatch slots n and n + 256 (one CU) hold a long and a short tile; a bijection on [0, nqx) for every nqx
+    const int r = bxq >> 5, i = bxq & 31;
+    qt = (r & 1) ? (r >> 1) * 32 + i : nqx - 1 - (r >> 1) * 32 - i;
+  } else if (a.map == 1) {
     // the direction is chosen ONCE per (kv-head, sequence) row of the grid -- from the linear id of the row's first workgroup --
     // so that every query tile of the row is computed exactly once whatever gridDim.x is (round-4 form flipped on bit 8 of
     // the workgroup's own linear id: a 256-boundary inside a row left tiles uncomputed when ceil(S/32) did not divide 256)
     const unsigned row0 = gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if ((row0 >> 8) & 1) qt = blockIdx.x;
   }
-  const int j = blockIdx.y, b = blockIdx.z;
+  const int j = a.kvfast ? (int)blockIdx.x : (int)blockIdx.y, b = blockIdx.z;
   const int s0 = qt * 32;
   const int li = lane & 31, lh = lane >> 5;
   const bool head_live = wave < G;

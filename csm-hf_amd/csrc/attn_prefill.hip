@@ -18,8 +18,10 @@ int launch_attn_prefill(hipStream_t st, int kvdtype, int B, int hd, const Prefil
     // (round 4, profiles/r04_attn_prefill_knockout.txt: two or three K / V tiles in flight instead of one change nothing; the
     //  longest workgroup's chain of 32 key tiles sets the launch time at 2 048 frames)
     a.map = 1;
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), grid, dim3(256), 0, st, a);
+    if (a.n_kv != 8) a.kvfast = 0;
+    const dim3 g2 = a.kvfast ? dim3(a.n_kv, (a.S + 31) / 32, B) : grid;
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_bf16_kernel<bf16_t>), g2, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_bf16_kernel<float>), g2, dim3(256), 0, st, a);
     return (int)hipGetLastError();
   }
   if (kvdtype == 1) hipLaunchKernelGGL((attn_prefill_kernel<bf16_t>), grid, dim3(256), 0, st, a);

@@ -199,6 +199,7 @@ struct csm_engine {
   int kernel_prio = 7;         // s_setprio 3 at kernel entry (issue priority over the resident weight-streamer waves): bit 0 the fused decoder
                                // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
+  int prefill_attn_kvfast = 1;   // bf16-class context attention: kv-head as the fastest grid index (one XCD per kv-head)
   int g16_kfast = 1;   // K-split matrix-core launches: the k split as the fastest grid index
   int g128 = 1, g128_min = 64, g128_shape = 0;   // gemm128.h for the FFN launches of batches beyond g128_min rows (shape: A/B override)
   int attn_gqa_wide = 1;     // backbone attention of > 32 rows on attn_decode_gqa_kernel
@@ -595,6 +596,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "attn_oproj_gqa")) e->attn_oproj_gqa = value ? 1 : 0;
   else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefill_attn_kvfast")) e->prefill_attn_kvfast = value != 0;
   else if (!strcmp(name, "g16_kfast")) e->g16_kfast = value != 0;
   else if (!strcmp(name, "g128")) e->g128 = value != 0;
   else if (!strcmp(name, "g128_min")) e->g128_min = value < 32 ? 32 : value;
@@ -1287,6 +1289,7 @@ static int stack_rows_mx(csm_engine* e, Stack& s, void* const* kc, void* const* 
       LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     }
     PrefillAttnArgs fa{};
+    fa.kvfast = e->prefill_attn_kvfast;
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
     fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     // the bf16 flash kernel leaves its output already MX-quantised (a 32-block is half a head: the lane pair of a query row)
@@ -1432,6 +1435,7 @@ static int stack_rows(csm_engine* e, Stack& s, void* const* kc, void* const* vc,
       LCK(launch_rope_scatter(e->stream, e->cfg.kv_dtype, (int)R, ra));
     }
     PrefillAttnArgs fa{};
+    fa.kvfast = e->prefill_attn_kvfast;
     fa.q = e->p_q; fa.kcache = kc[l]; fa.vcache = vc[l]; fa.n_q = nq; fa.n_kv = nkv; fa.lmax = lmax;
     fa.S = S; fa.past = past; fa.kv_start = kv_start; fa.seq_slot = e->p_seq_slot; fa.out = e->p_att;
     if (pl) { fa.oplanes = e->p_pl_h; fa.plane_stride = ps_att; }

@@ -153,7 +153,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *   prefill:     "gemm_wide", "gemm_dma", "gemm_256", "gemm_dma_skinny", "gemm_mx_skinny" (tile selection of the context GEMMs:
  *                used by the bitwise tile-vs-tile tests), "prefill_splitk", "prefill_splitk_gu" (K splits of short prefills),
  *                "prefill_fuse_rope" (RoPE + cache append as the QKV GEMM's epilogue, modeling_llama.py:130-176 / 267-281),
- *                "prefill_fuse_quant" / "mx_fuse_swiglu" (MX quantisation fused into the producing kernels)
+ *                "prefill_fuse_quant" / "mx_fuse_swiglu" (MX quantisation fused into the producing kernels), "prefill_attn_kvfast" (bf16-class
+ *                context attention: the kv-head as the fastest grid index -- one XCD per kv-head)
  *   measurement: "dbg_skip" (TIMING ONLY, wrong results: knock launch kinds out of the decode chain), "dbg_sample_spin" (TIMING ONLY:
  *                every sampler launch idles this many 10 ns ticks first -- how a pause in the chain affects the weight streamer) */
 int csm_set_option(csm_engine_t* e, const char* name, int value);
