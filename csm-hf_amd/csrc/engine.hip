@@ -200,6 +200,7 @@ struct csm_engine {
                                // attention + o_proj launch, bit 1 the GEMV family, bit 2 backbone attention and the samplers
   int dbg_sample_spin = 0;     // TIMING ONLY: every sampler launch idles this many 10 ns ticks first
   int prefill_attn_kvfast = 1;   // bf16-class context attention: kv-head as the fastest grid index (one XCD per kv-head)
+  int g16_xcdmap = 1;  // gemm128 gate/up panels on the XCD that reads their h columns in the down_proj launch (needs g16_kfast)
   int g16_kfast = 1;   // K-split matrix-core launches: the k split as the fastest grid index
   int g128 = 1, g128_min = 64, g128_shape = 0;   // gemm128.h for the FFN launches of batches beyond g128_min rows (shape: A/B override)
   int attn_gqa_wide = 1;     // backbone attention of > 32 rows on attn_decode_gqa_kernel
@@ -597,6 +598,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "kernel_prio")) e->kernel_prio = value & 7;
   else if (!strcmp(name, "dbg_sample_spin")) e->dbg_sample_spin = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefill_attn_kvfast")) e->prefill_attn_kvfast = value != 0;
+  else if (!strcmp(name, "g16_xcdmap")) e->g16_xcdmap = value != 0;
   else if (!strcmp(name, "g16_kfast")) e->g16_kfast = value != 0;
   else if (!strcmp(name, "g128")) e->g128 = value != 0;
   else if (!strcmp(name, "g128_min")) e->g128_min = value < 32 ? 32 : value;
@@ -694,7 +696,7 @@ static int gemv_rows(csm_engine* e, int M, int pro, int epi, GemvArgs a) {
       const int cap = (e->rows64 > 0 && m0 % 128 == 0 && left > 64) ? 128 : ((e->rows64 > 0 && m0 % 64 == 0 && left > 32) ? 64 : 32);
       const int m = left < cap ? left : cap;
       slice(m);
-      a.kfast = e->g16_kfast;
+      a.kfast = e->g16_kfast; a.xcdmap = e->g16_kfast && e->g16_xcdmap;
       int r = -2;
       if (e->g128 && m > e->g128_min) {   // 65..128 rows, FFN launches: weight rows split over the waves, planes shared through LDS (gemm128.h)
         a.g128_shape = e->g128_shape;

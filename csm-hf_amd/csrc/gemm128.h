@@ -54,6 +54,7 @@ struct G128Args {
   uint32_t* dbg;           // tools/ubench/g128_bench.hip time stamps
   int xss_n, xss_ld, oss_ld, ldo, K, N, M, KB;
   float eps;
+  int xcdmap;
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256 * H) void gemm128_kernel(const G128Args a) {
   // every field of the argument segment requested in ONE batch at entry
   asm volatile("" ::"s"(a.Wt), "s"(a.xplanes), "s"(a.xss), "s"(a.oplanes), "s"(a.oln), "s"(a.oss), "s"(a.out), "s"(a.wscale));
   asm volatile("" ::"s"(a.slabs), "s"(a.tickets), "s"(a.bump_a), "s"(a.bump_b), "s"(a.dbg), "s"(a.xss_n), "s"(a.xss_ld), "s"(a.oss_ld), "s"(a.ldo), "s"(a.K),
-               "s"(a.N), "s"(a.M), "s"(a.KB), "s"(a.eps));
+               "s"(a.N), "s"(a.M), "s"(a.KB), "s"(a.eps), "s"(a.xcdmap));
   const int M = a.M, KB = a.KB;
   float* const slabs = a.slabs;
   int* const tickets = a.tickets;
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(256 * H) void gemm128_kernel(const G128Args a) {
   // K split across workgroups (KB > 1): the k group is the FASTEST grid index, so that the workgroups of one group -- they read the same
   // 1 024-wide slice of the planes -- run on one XCD (workgroup id mod 8 with KB = 8) and that slice (786 KB at 128 rows) stays in its
   // L2; with the panels fastest every XCD walked all 6.3 MB of a down_proj's planes (FETCH_SIZE 75 MB per launch for 17 MB of weights)
-  const int pid = KB > 1 ? (int)blockIdx.y : (int)blockIdx.x, np = KB > 1 ? (int)gridDim.y : (int)gridDim.x;   // panel of 4 x PT weight tiles
+  int pid = KB > 1 ? (int)blockIdx.y : (int)blockIdx.x;                                                        // panel of 4 x PT weight tiles
+  const int np = KB > 1 ? (int)gridDim.y : (int)gridDim.x;
+  if (EPI == EPI_SWIGLU && a.xcdmap && KB == 1 && (np & 7) == 0) pid = (pid & 7) * (np >> 3) + (pid >> 3);   // gate/up: the XCD that reads these h columns as a k group of the down_proj launch (128 rows 10.28 -> 10.18 ms)
   const int kid = KB > 1 ? (int)blockIdx.x : 0;                                                                 // k group
   const int mt0 = (int)blockIdx.z * 4;
   const int mtw = (wave >> 2) * MT;                                    // this wave's first batch tile among the workgroup's four

@@ -25,7 +25,7 @@ static int launch_g128(hipStream_t st, int M, int KB, const GemvArgs& a, float* 
   G128Args g{};
   g.Wt = a.Wt; g.xplanes = a.xplanes; g.xss = a.xss; g.oplanes = a.oplanes; g.oln = a.oln; g.oss = a.oss; g.out = a.out; g.wscale = a.wscale;
   g.slabs = slabs; g.tickets = tickets; g.bump_a = a.bump_a; g.bump_b = a.bump_b; g.dbg = nullptr;
-  g.xss_n = a.xss_n; g.xss_ld = a.xss_ld; g.oss_ld = a.oss_ld; g.ldo = a.ldo; g.K = a.K; g.N = a.N; g.M = M; g.KB = KB; g.eps = a.eps;
+  g.xss_n = a.xss_n; g.xss_ld = a.xss_ld; g.oss_ld = a.oss_ld; g.ldo = a.ldo; g.K = a.K; g.N = a.N; g.M = M; g.KB = KB; g.eps = a.eps; g.xcdmap = a.xcdmap;
   hipLaunchKernelGGL(fn, KB > 1 ? dim3(KB, gx, Z) : dim3(gx, 1, Z), dim3(256 * H), lds, st, g);   // K split: the k group fastest (gemm128.h)
   return (int)hipGetLastError();
 }

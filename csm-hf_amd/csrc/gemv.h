@@ -99,6 +99,8 @@ struct GemvArgs {
   int norm_ks;         // host-side: 2 = single-row normed launches with K = 2048 take the register path with two waves per task (K split in the workgroup)
   int grid_cap;        // host-side: max workgroups of the generic kernel (0 = 1024)
   int g16_nw, g16_kb, g16_pt;  // host-side: override waves / K-splits / panel tiles of the MFMA kernel (0 = auto)
+  int xcdmap;                  // gemm128.h gate/up launches: panel p on XCD p / (panels / 8), i.e. the XCD that reads those 1 024 h columns as a k group of the down_proj launch (kfast).
+                               // (The same map in gemm16.h / gemm32.h: 16 rows 5.21 -> 5.33 ms, 4 rows 5.01 -> 5.12, 32 / 64 rows nothing -- not used there.)
   int kfast;                   // gemm16.h / gemm32.h with K split across workgroups: the k split as the fastest grid index (planes of a k slice in one XCD's L2)
   int g128_shape;              // host-side A/B override of gemm128.hip's shape choice (0 = auto): low nibble = weight tiles per wave, bit 4 = split K across workgroups
   int g16_slab;  // bits 4-7: TIMING-ONLY knock-outs of the -DCSM_G16_KO variant build (gemm16.h); the split-K slab exchange is write-through (sc1) stores + sc1 loads

@@ -147,6 +147,7 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                the query heads of a kv-head), "oproj_combine" / "combine_splits" (B = 1 backbone: split-KV merge inside the o_proj
  *                launch, on this many splits <= 8), "attn_gqa_wide" (backbone attention beyond 32 rows on the kernel that shares K/V tiles
  *                among the query heads of a kv-head), "g16_kfast" (K-split matrix-core launches: the k split as the fastest grid index -- one XCD per k slice of the activation planes),
+ *                "g16_xcdmap" (65-128 rows: a gate/up panel runs on the XCD that reads its output columns as a k group of the down_proj launch),
  *                "g128" / "g128_min" / "g128_shape" (FFN launches of batches beyond g128_min = 64 rows on
  *                gemm128.h: weight rows split over the waves, planes shared through LDS; shape = A/B override: low nibble weight tiles per
  *                wave, bit 6 one k group per workgroup for gate/up)
