@@ -238,7 +238,19 @@ struct csm_engine {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned* d_prog = nullptr;      // launches started (bumped by the streamed launches)
-  unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status
+  unsigned* d_pf_misc = nullptr;   // [0..7] per-XCD tickets, [8..11] status, [12..15] stop record, [16..23] XCD probe, [32..33] concurrency probe,
+                                   // [40..42] lifetime counters (never reset): give-ups, finished, streamer launches
+  // streamer health (round 6): the status words of every streamer launch are copied to pinned host memory behind the kernel on its own
+  // stream; the NEXT csm_generate reads them once `ev_join` has completed (no extra synchronisation) and, after a give-up, re-runs the
+  // stream-concurrency probe and switches the streamer off for this engine rather than stalling every call (pf_harvest)
+  unsigned* h_pf = nullptr;        // pinned mirror of d_pf_misc[8..47]
+  int pf_pending = 0;              // streamer launches whose mirror has not been read yet
+  unsigned pf_seen_gaveup = 0;     // lifetime give-ups already accounted for
+  int pf_strikes = 0, pf_clean = 0, pf_probe_runs = 0;
+  int pf_disabled = 0;             // 0 on;  1 the two streams share a hardware queue (probe);  2 repeated give-ups with the probe passing;
+                                   // 3 dispatch not round-robin over the XCDs;  4 the probe at engine creation failed
+  int pf_budget_us = 20000;        // no launch starting for this long while launches are outstanding = a stalled chain
+  int pf_force_serial = 0;         // test hook: streamer (and probe) on the ENGINE stream -- the failure mode of two streams on one hardware queue
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
   int pf_enable = 1, pf_window_mb = 6; static constexpr int pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
@@ -312,6 +324,60 @@ static int check_stack(const csm_llama_cfg_t& c, const char* name) {
   if (c.head_dim != 64 && c.head_dim != 128) return fail(CSM_ERR_ARG, "%s: head_dim must be 64 or 128, got %d", name, c.head_dim);
   if (c.n_q % c.n_kv || c.n_q / c.n_kv > 16) return fail(CSM_ERR_ARG, "%s: unsupported GQA ratio", name);
   return 0;
+}
+
+
+// ---- weight-streamer health (prefetch.h) ----
+// Stream-concurrency probe: a waiter on the streamer's stream must see a flag raised by a kernel submitted AFTER it on the engine
+// stream.  If the two HIP streams share a hardware queue the waiter times out (3 ms) and the streamer, which is submitted ahead of the
+// replays it feeds, would hold them up for one budget per call.  Synchronises both streams.
+static int pf_probe_concurrency(csm_engine* e, int* seen_out) {
+  unsigned seen = 0;
+  hipStream_t waiter = e->pf_force_serial ? e->stream : e->stream2;
+  HIPCK(hipStreamSynchronize(e->stream2));
+  HIPCK(hipMemsetAsync(e->d_pf_misc + 32, 0, 2 * sizeof(unsigned), e->stream));
+  HIPCK(hipStreamSynchronize(e->stream));
+  LCK(launch_pf_concurrency_probe(waiter, e->stream, e->d_pf_misc + 32, e->d_pf_misc + 33));
+  HIPCK(hipStreamSynchronize(e->stream2));
+  HIPCK(hipStreamSynchronize(e->stream));
+  HIPCK(hipMemcpy(&seen, e->d_pf_misc + 33, sizeof(seen), hipMemcpyDeviceToHost));
+  e->pf_probe_runs++;
+  *seen_out = (int)seen;
+  return 0;
+}
+
+// Reads the pinned status mirror of the streamer launches that have completed (`wait`: block until the last one has) and acts on
+// give-ups: the probe is run again; if the streams turn out to be serialised the streamer is off for this engine (reason 1), and so it
+// is after two give-ups within 64 calls with the probe passing (reason 2: a chain that stalls beside the resident streamer for another
+// reason).  A single give-up with a passing probe (a host that was descheduled between two graph launches) costs nothing further.
+static int pf_harvest(csm_engine* e, bool wait) {
+  if (!e->pf_pending || !e->h_pf) return 0;
+  if (wait) HIPCK(hipEventSynchronize(e->ev_join));
+  else if (hipEventQuery(e->ev_join) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  e->pf_pending = 0;
+  const unsigned gave = e->h_pf[32];   // d_pf_misc[40]
+  if (gave == e->pf_seen_gaveup) {
+    if (++e->pf_clean >= 64) { e->pf_clean = 0; if (e->pf_strikes > 0) e->pf_strikes--; }
+    return 0;
+  }
+  e->pf_seen_gaveup = gave;
+  e->pf_strikes++;
+  e->pf_clean = 0;
+  int seen = 0;
+  if (int r = pf_probe_concurrency(e, &seen)) return r;
+  if (!seen) e->pf_disabled = 1;
+  else if (e->pf_strikes >= 2) e->pf_disabled = 2;
+  return 0;
+}
+static const char* pf_reason(int r) {
+  switch (r) {
+    case 0: return "on";
+    case 1: return "off: the streamer's stream and the engine stream share a hardware queue (give-up, then probe)";
+    case 2: return "off: two give-ups within 64 calls although the streams run concurrently";
+    case 3: return "off: workgroups are not dispatched round-robin over the XCDs";
+    case 4: return "off: the stream-concurrency probe failed at engine creation";
+  }
+  return "?";
 }
 
 extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stream, csm_engine_t** out) {
@@ -442,16 +508,14 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     bool rr = true;
     for (int b = 0; b < 8; ++b) rr = rr && where[b] == ((where[0] + b) & 7u);
     e->pf_rot = rr ? (int)where[0] : -1;
+    if (!rr) e->pf_disabled = 3;
     // the streamer must run BESIDE the engine stream: a waiter on stream2 has to see a flag raised by a kernel
     // submitted later on the engine stream.  If the two streams share a hardware queue it times out (3 ms): streamer off.
-    unsigned seen = 0;
-    HIPCK(hipMemsetAsync(e->d_pf_misc + 32, 0, 2 * sizeof(unsigned), e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
-    LCK(launch_pf_concurrency_probe(e->stream2, e->stream, e->d_pf_misc + 32, e->d_pf_misc + 33));
-    HIPCK(hipStreamSynchronize(e->stream2));
-    HIPCK(hipStreamSynchronize(e->stream));
-    HIPCK(hipMemcpy(&seen, e->d_pf_misc + 33, sizeof(seen), hipMemcpyDeviceToHost));
-    if (!seen) e->pf_rot = -1;
+    int seen = 0;
+    if (int pr = pf_probe_concurrency(e, &seen)) return pr;
+    if (!seen && e->pf_rot >= 0) { e->pf_rot = -1; e->pf_disabled = 4; }
+    HIPCK(hipHostMalloc((void**)&e->h_pf, 40 * sizeof(unsigned), hipHostMallocDefault));
+    memset(e->h_pf, 0, 40 * sizeof(unsigned));
   }
   HIPCK(hipStreamSynchronize(e->stream));
   *out = e;
@@ -475,6 +539,7 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->stream2) hipStreamDestroy(e->stream2);
+  if (e->h_pf) hipHostFree(e->h_pf);
   for (void* p : e->allocs) hipFree(p);
   if (e->shift_kt) hipFree(e->shift_kt);
   if (e->shift_vt) hipFree(e->shift_vt);
@@ -632,6 +697,14 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
+  // streamer health: launch parameters of the streamer, not of the captured frame-step -- the graphs stay
+  else if (!strcmp(name, "prefetch_budget_us")) { e->pf_budget_us = value < 100 ? 100 : value; return 0; }
+  else if (!strcmp(name, "prefetch_force_serial")) { e->pf_force_serial = value ? 1 : 0; return 0; }
+  else if (!strcmp(name, "prefetch_rearm")) {   // clears a run-time switch-off (1 / 2) and the strike count; the creation-time verdicts (3 / 4) stay
+    if (e->pf_disabled == 1 || e->pf_disabled == 2) e->pf_disabled = 0;
+    e->pf_strikes = 0; e->pf_clean = 0;
+    return 0;
+  }
   else if (!strcmp(name, "tile_weights")) {   // A/B: 0 drops the fragment-order copies (row-major MFMA path)
     e->tile_weights = value;
     if (e->bound) { if (int r = build_tiled(e)) return r; }
@@ -1869,7 +1942,8 @@ static int build_pf_schedule(csm_engine* e, const std::vector<PfGeom>& geoms, Gr
       --j;
       if (steps == n - 2) all = true;
     }
-    if (all || n == 1) need = -(1 << 29);    // a whole frame-step fits the window
+    if (all || n == 1) need = -ent.n_launch;   // a whole frame-step fits the window: fetched while the PREVIOUS frame-step runs (round 6: was "at once",
+                                               // i.e. every replay of a small model was fetched before the first launch and the loaders outlived the chain)
     // a run that could only be fetched once its own consumer has started is left to the consumer; co-fetch keeps the
     // runs that become fetchable exactly when their consumer starts (the streamer then reads beside the consumer)
     if (need > segs[i].owner || (need == segs[i].owner && !e->pf_cofetch)) continue;
@@ -1938,27 +2012,31 @@ extern "C" int csm_generate(csm_engine_t* e, const csm_sampling_t* s, int n_fram
       e->graphs_captured++;
     }
     it->second.last_use = ++e->graph_tick;
-    const bool stream_weights = e->pf_enable && e->pf_rot >= 0 && it->second.n_segs > 0;
+    if (int hr = pf_harvest(e, false)) return hr;   // status of the previous streamer launch, if it has completed: may switch the streamer off
+    const bool stream_weights = e->pf_enable && !e->pf_disabled && e->pf_rot >= 0 && it->second.n_segs > 0;
     e->pf_last_frames = n_frames;
     e->pf_last[0] = it->second.n_segs; e->pf_last[1] = it->second.n_launch;
     e->pf_last[2] = (long long)it->second.sched_bytes; e->pf_last[3] = (long long)it->second.step_bytes;
     if (stream_weights) {   // the streamer runs beside the replays on stream2, paced by the launch counter
       HIPCK(hipMemsetAsync(e->d_prog, 0, sizeof(unsigned), e->stream));
       HIPCK(hipMemsetAsync(e->d_pf_misc, 0, 16 * sizeof(unsigned), e->stream));
+      hipStream_t pst = e->pf_force_serial ? e->stream : e->stream2;
       HIPCK(hipEventRecord(e->ev_fork, e->stream));
-      HIPCK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+      if (pst != e->stream) HIPCK(hipStreamWaitEvent(pst, e->ev_fork, 0));
       PfArgs pa{};
       pa.segs = it->second.d_segs; pa.n = it->second.n_segs; pa.n_launch = it->second.n_launch; pa.reps = n_frames;
-      pa.rot = e->pf_rot; pa.prog = e->d_prog; pa.ticket = e->d_pf_misc; pa.status = e->d_pf_misc + 8;
-      pa.budget_ticks = 2000000;   // 20 ms without a launch starting: give up (s_memrealtime runs at 100 MHz)
+      pa.rot = e->pf_rot; pa.prog = e->d_prog; pa.ticket = e->d_pf_misc; pa.status = e->d_pf_misc + 8; pa.lifetime = e->d_pf_misc + 40;
+      pa.budget_ticks = (long long)e->pf_budget_us * 100;   // default 20 ms without a launch starting: give up (s_memrealtime runs at 100 MHz)
       pa.skip_late = e->pf_skip_late; pa.poll_sleep = e->pf_poll_sleep; pa.depth = e->pf_depth; pa.seg_sleep = e->pf_seg_sleep; pa.stride = e->pf_stride;
-      LCK(launch_weight_prefetch(e->stream2, e->pf_grid, pa));
-      HIPCK(hipEventRecord(e->ev_join, e->stream2));
+      LCK(launch_weight_prefetch(pst, e->pf_grid, pa));
+      HIPCK(hipMemcpyAsync(e->h_pf, e->d_pf_misc + 8, 40 * sizeof(unsigned), hipMemcpyDeviceToHost, pst));
+      HIPCK(hipEventRecord(e->ev_join, pst));
+      e->pf_pending++;
     }
     for (int i = 0; i < n_frames; ++i) HIPCK(hipGraphLaunch(it->second.exec, e->stream));
     if (stream_weights) {
       HIPCK(hipEventRecord(e->ev1, e->stream));
-      HIPCK(hipStreamWaitEvent(e->stream, e->ev_join, 0));   // later work on the engine stream sees the streamer finished
+      if (!e->pf_force_serial) HIPCK(hipStreamWaitEvent(e->stream, e->ev_join, 0));   // later work on the engine stream sees the streamer finished
       e->h_len += n_frames;
       e->h_frame += n_frames;
       return 0;
@@ -2044,7 +2122,22 @@ extern "C" int csm_prefetch_stats(csm_engine_t* e, long long* out10_host) {
   out10_host[9] = e->pf_last_frames;
   unsigned dbg[4];
   HIPCK(hipMemcpy(dbg, e->d_pf_misc + 12, sizeof(dbg), hipMemcpyDeviceToHost));
-  snprintf(g_err, sizeof(g_err), "streamer stop record: segment %u want %u seen %u rep %u", dbg[0], dbg[1], dbg[2], dbg[3]);
+  if (int hr = pf_harvest(e, true)) return hr;
+  snprintf(g_err, sizeof(g_err), "streamer %s; stop record of the last give-up: segment %u want %u seen %u rep %u; retired by the end-of-chain rule %u",
+           pf_reason(e->pf_disabled), dbg[0], dbg[1], dbg[2], dbg[3], st[3]);
+  return 0;
+}
+
+// Health of the weight streamer (round 6).  out8 = {disabled reason (0 on, 1 streams share a hardware queue, 2 repeated give-ups, 3 dispatch
+// not round-robin, 4 creation-time probe failed), strikes, lifetime give-ups (workgroups), lifetime finished (workgroups), streamer
+// launches, budget in us, concurrency-probe runs, streamer launches not yet accounted for}.  Waits for the last streamer launch only.
+extern "C" int csm_prefetch_health(csm_engine_t* e, long long* out8_host) {
+  if (!e || !out8_host) return fail(CSM_ERR_ARG, "null argument");
+  if (int hr = pf_harvest(e, true)) return hr;
+  out8_host[0] = e->pf_disabled; out8_host[1] = e->pf_strikes;
+  out8_host[2] = e->h_pf ? e->h_pf[32] : 0; out8_host[3] = e->h_pf ? e->h_pf[33] : 0; out8_host[4] = e->h_pf ? e->h_pf[34] : 0;
+  out8_host[5] = e->pf_budget_us; out8_host[6] = e->pf_probe_runs; out8_host[7] = e->pf_pending;
+  snprintf(g_err, sizeof(g_err), "%s", pf_reason(e->pf_disabled));
   return 0;
 }
 

@@ -13,7 +13,13 @@
 // window (default 24 MiB of the 32 MiB aggregate L2), and is skipped when its consumer has already started.
 //
 // The streamer never writes model state, so results are bit-identical with it on or off; a late or absent streamer
-// only costs speed.  Every spin is bounded (it gives up after `budget_ticks` without progress).
+// only costs speed.  It ENDS deterministically (round 6): the poller of every workgroup sees the launch counter reach
+// `reps * n_launch` -- the last streamed launch of the last replay has started, nothing is left worth fetching -- and
+// retires the workgroup as `finished` wherever its loaders are.  "No launch started for `budget_ticks`" while the
+// counter is below that total therefore means a STALLED chain (two streams on one hardware queue, a launch that cannot
+// become resident beside the streamer): the workgroup gives up, the give-up is counted in a lifetime counter the host
+// reads before the next csm_generate (engine.hip: pf_harvest), which re-runs the stream-concurrency probe and switches
+// the streamer off for the engine instead of stalling every call.
 // No reference counterpart: the reference (modeling_csm.py) issues torch ops one by one.
 #pragma once
 #include "common.h"
@@ -51,8 +57,10 @@ struct PfArgs {
   int rot;                 // workgroup b of a dispatch runs on XCD (b + rot) % 8
   const unsigned* prog;    // launches started so far (bumped by workgroup 0 of every streamed launch)
   unsigned* ticket;        // [8] per-XCD arrival counters, zeroed before the launch
-  unsigned* status;        // [0] workgroups that gave up, [1] finished, [2] segments skipped as late (workgroup 0 of XCD 0)
-  long long budget_ticks;  // s_memrealtime ticks (100 MHz) without progress before giving up
+  unsigned* status;        // [0] workgroups that gave up, [1] finished, [2] segments skipped as late (workgroup 0 of XCD 0),
+                           // [3] workgroups retired by the end-of-chain rule, [4..7] stop record of a give-up
+  unsigned* lifetime;      // never reset: [0] give-ups, [1] finished, [2] streamer launches (workgroup 0 of XCD 0)
+  long long budget_ticks;  // s_memrealtime ticks (100 MHz) without a launch starting, counter below the total: give up
   int skip_late;           // 1: a segment whose consumer has already started is skipped
   int poll_sleep;          // s_sleep units between two polls of the launch counter
   int seg_sleep;           // s_sleep units every loader wave idles before each segment (rate limiter)
@@ -110,20 +118,30 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
     // wait would cover every prefetch load in flight) between their prefetches
     long long t_last = __builtin_amdgcn_s_memrealtime();
     int last = -1;
+    const int total = a.reps * a.n_launch;
+    if (lane == 0 && x == 0 && bl == 0) atomicAdd(a.lifetime + 2, 1u);
     while (*v_done < 3) {
       const int c = (int)__hip_atomic_load(a.prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) *v_cur = c;
+      if (c >= total) {
+        // deterministic end: the last streamed launch of the last replay has started.  Loaders that are still walking
+        // the schedule (a chain of launches shorter than the loaders' per-segment bookkeeping, a slow clock) stop at
+        // their next segment: this is `finished`, never a give-up
+        if (lane == 0) { *v_state = 3; atomicAdd(a.status + 3, 1u); }
+        break;
+      }
       const long long now = __builtin_amdgcn_s_memrealtime();
       if (c != last) { last = c; t_last = now; }
-      // before the first launch has started the chain may still be on its way through the host (first launch of a freshly
-      // instantiated graph): ten budgets; afterwards one budget without progress ends the streamer
-      if (now - t_last > (c == 0 ? 10 * a.budget_ticks : a.budget_ticks)) {
-        if (lane == 0) { *v_state = 2; atomicAdd(a.status, 1u); }
+      // one budget without a launch starting while launches are outstanding: the chain is stalled (or has not been
+      // submitted: the host submits the replays right behind the streamer).  Rounds 2-5 waited ten budgets before the
+      // first launch; a chain held up BY the streamer then lost 200 ms per call
+      if (now - t_last > a.budget_ticks) {
+        if (lane == 0) { *v_state = 2; atomicAdd(a.status, 1u); atomicAdd(a.lifetime, 1u); }
         return;
       }
       for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
     }
-    if (lane == 0) atomicAdd(a.status + 1, 1u);
+    if (lane == 0) { atomicAdd(a.status + 1, 1u); atomicAdd(a.lifetime + 1, 1u); }
     return;
   }
   const unsigned slot = bl * 3u + (unsigned)(wave - 1), nslot = nl * 3u;
@@ -140,16 +158,18 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
       const PfSeg* sp = &seg;
       const int want = base + sp->need;
       int cur = *v_cur;
-      while (cur < want) {
-        if (*v_state == 2) {
-          if (lane == 0 && wave == 1) {   // debug record of where a workgroup stopped: {segment, want, seen, rep}
-            a.status[4] = (unsigned)e; a.status[5] = (unsigned)want; a.status[6] = (unsigned)cur; a.status[7] = (unsigned)rep;
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          return;
-        }
+      int st = *v_state;
+      while (cur < want && st == 0) {
         __builtin_amdgcn_s_sleep(1);
         cur = *v_cur;
+        st = *v_state;
+      }
+      if (st != 0) {   // 3: the chain has started its last launch (poller);  2: the poller gave up
+        if (st == 2 && lane == 0 && wave == 1) {   // record of where a workgroup stopped: {segment, want, seen, rep}
+          a.status[4] = (unsigned)e; a.status[5] = (unsigned)want; a.status[6] = (unsigned)cur; a.status[7] = (unsigned)rep;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
       }
       if (a.skip_late && cur > base + sp->owner) { ++skipped; continue; }   // its consumer is already running: leave it alone
       for (int z = 0; z < a.seg_sleep; z += 8) __builtin_amdgcn_s_sleep(8);

@@ -17,7 +17,7 @@ from .configuration_csm import CSMConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_F32, DT_BF16, DT_FP8 = 0, 1, 2
 
 EXPORTS = [
@@ -26,7 +26,7 @@ EXPORTS = [
     "csm_get_state", "csm_generate", "csm_read_frames", "csm_frames_done", "csm_cur_len", "csm_set_kv_start",
     "csm_last_generate_ms", "csm_embed_sum", "csm_rmsnorm", "csm_gemv", "csm_gemm", "csm_sample_topk",
     "csm_attn_decode", "csm_rope_scatter", "csm_bench_gemv", "csm_sync", "csm_last_error", "csm_abi_version",
-    "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats",
+    "csm_rewind_frames", "csm_graph_stats", "csm_kv_copy", "csm_prefetch_stats", "csm_prefetch_health",
     "csm_set_debug_buffer", "csm_last_geoms", "csm_read_zero_counts",
     "csm_prefill_pos", "csm_kv_export", "csm_kv_import", "csm_set_length", "csm_forward_loss", "csm_prefill_slot", "csm_prefill_slots",
     "csm_mimi_create", "csm_mimi_destroy", "csm_mimi_bind_weights", "csm_mimi_decode", "csm_mimi_stream_reset",
@@ -141,6 +141,7 @@ def load_library(path: Optional[str] = None):
     lib.csm_graph_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.csm_kv_copy.argtypes = [vp, vp]
     lib.csm_prefetch_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.csm_prefetch_health.argtypes = [vp, C.POINTER(C.c_longlong)]
     lib.csm_read_zero_counts.argtypes = [vp, C.POINTER(C.c_int32), i32, i32]
     lib.csm_prefill_pos.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.csm_forward_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -732,6 +733,16 @@ class Engine:
                 "scheduled_bytes", "streamed_launch_bytes", "launches_counted", "frames")
         d = dict(zip(keys, [int(v) for v in a]))
         d["note"] = self.lib.csm_last_error().decode(errors="replace")
+        d["health"] = self.prefetch_health()
+        return d
+
+    def prefetch_health(self) -> dict:
+        """Run-time health of the weight streamer (csm_prefetch_health): whether it is still on, and why not."""
+        a = (C.c_longlong * 8)()
+        _ck(self.lib, self.lib.csm_prefetch_health(self._h, a))
+        keys = ("disabled", "strikes", "gave_up_total", "finished_total", "streamer_launches", "budget_us", "probe_runs", "pending")
+        d = dict(zip(keys, [int(v) for v in a]))
+        d["reason"] = self.lib.csm_last_error().decode(errors="replace")
         return d
 
     def set_debug_buffer(self, buf: Optional[torch.Tensor], n_launches: int = 0):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CSM_ABI_VERSION 6
+#define CSM_ABI_VERSION 7
 
 enum { CSM_DTYPE_F32 = 0, CSM_DTYPE_BF16 = 1, CSM_DTYPE_FP8 = 2 /* OCP e4m3fn + per-output-row fp32 scale (matrices only) */ };
 
@@ -141,7 +141,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                launches; -1: 16-row launches -- the forms the width tests compare against, bit for bit),
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
  *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 6: round 5), "prefetch_seg_sleep"
- *                (its pause per 4 MiB run, default 0 since the decode kernels run at s_setprio 3), "kernel_prio" (bit mask of the
+ *                (its pause per 4 MiB run, default 0 since the decode kernels run at s_setprio 3), "prefetch_budget_us" / "prefetch_rearm" /
+ *                "prefetch_force_serial" (streamer health: see csm_prefetch_health), "kernel_prio" (bit mask of the
  *                launch families that raise their issue priority: 1 decoder attention + o_proj, 2 GEMV / skinny GEMM, 4 backbone
  *                attention + samplers; default 7), "attn_oproj_gqa" (B = 1 decoder attention + o_proj with the K/V tiles shared by
  *                the query heads of a kv-head), "oproj_combine" / "combine_splits" (B = 1 backbone: split-KV merge inside the o_proj
@@ -333,6 +334,16 @@ int csm_graph_stats(csm_engine_t* e, int* captured_total_host, int* cached_host)
  * frame-step, scheduled bytes, bytes of all streamed launches, launches counted, frames} for the last csm_generate;
  * syncs both streams */
 int csm_prefetch_stats(csm_engine_t* e, long long* out10_host);
+/* health of the weight streamer (ABI 7).  The streamer ends when the launch counter reaches the total of the call; "no launch started
+ * for `prefetch_budget_us` (default 20 000) while launches are outstanding" is a stalled chain: the workgroups give up, and the NEXT
+ * csm_generate (which reads a pinned status mirror -- no synchronisation) re-runs the stream-concurrency probe and switches the
+ * streamer off for this engine: the reference loop it feeds (modeling_csm.py:644-690) must never stall behind an optimisation.
+ * out8 = {disabled reason: 0 on / 1 the two streams share a hardware queue / 2 two give-ups within 64 calls with the probe passing /
+ * 3 workgroups not dispatched round-robin over the XCDs / 4 probe failed at engine creation, strikes, lifetime give-ups
+ * (workgroups), lifetime finished (workgroups), streamer launches, budget (us), probe runs, launches not yet accounted for};
+ * the reason as text in csm_last_error().  Waits for the last streamer launch only.  Options: "prefetch_budget_us",
+ * "prefetch_rearm" (clears reasons 1 / 2), "prefetch_force_serial" (TEST HOOK: streamer and probe on the engine stream) */
+int csm_prefetch_health(csm_engine_t* e, long long* out8_host);
 /* debug probes of the weight streamer (tools/streamer_probe.py): per-workgroup {XCD id, clocks until the weights were
  * consumed} of the first n streamed launches of the next captured frame-step -> buf[n][2048][2] uint32 (device);
  * geometry {N, K, grid, tasks per workgroup, kind} of the streamed launches of the last captured frame-step */

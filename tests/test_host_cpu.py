@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in csm_hip.h but not exported"
     assert declared == set(EXPORTS)
     from csm_hf_amd.engine import ABI_VERSION
-    assert lib.csm_abi_version() == ABI_VERSION == 6
+    assert lib.csm_abi_version() == ABI_VERSION == 7
 
 
 def test_no_gpu_fails_loudly():
