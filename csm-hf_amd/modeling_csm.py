@@ -189,7 +189,7 @@ class CSMModel(nn.Module):
 
     config_class = CSMConfig
     base_model_prefix = "csm"
-    DEFAULT_KV_DTYPE = "auto"   # instances start with kv_dtype = this (tests/conftest.py pins the suites written against the exact mode to torch.float32)
+    DEFAULT_KV_DTYPE = "auto"   # instances start with kv_dtype = this (tests that assert bit-exactness against the fp32-arithmetic fixtures set torch.float32 themselves)
 
     def __init__(self, config: CSMConfig):
         super().__init__()

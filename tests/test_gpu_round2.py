@@ -13,6 +13,7 @@ import torch
 from csm_hf_amd import CSMConfig, CSMModel, sample_topk
 from csm_hf_amd.synth import synth_state_dict, synth_context
 from oracle import csm_oracle as O
+from _util import EXACT_KV
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -391,6 +392,7 @@ def test_training_forward_loss_vs_reference(name):
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
+    m.kv_dtype = EXACT_KV      # this test asserts the exact mode (fp32 KV cache) against fp32-arithmetic values
     ids, mask, labels = (torch.from_numpy(g[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
     out = m.forward(ids, mask, labels=labels, return_dict=True)
     for k in ("loss", "backbone_loss", "decoder_loss"):
@@ -516,6 +518,7 @@ def test_other_model_shapes_vs_oracle(wdtype):
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
+    m.kv_dtype = EXACT_KV      # this test asserts the exact mode (fp32 KV cache) against fp32-arithmetic values
     ids, mask = synth_context(cfg, 3, 4, 9, seed=8)
     tr = {}
     want1 = O.generate(sd32, cfg, ids[:1], mask[:1], max_new_frames=5, topk=1, stop_on_all_zeros=False, trace=tr)
@@ -572,6 +575,7 @@ def test_bench_two_ranks_through_the_real_engine():
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     del sd
+    m.kv_dtype = EXACT_KV      # bench.py's headline leg and its config-4 legs checked here run `--kv-dtype f32`
     ids, mask = synth_context(cfg, 2, 16, 48, seed=2)
     for r in range(2):
         out = m.generate(ids[r:r + 1].to(DEV), mask[r:r + 1].to(DEV), max_new_frames=6, topk=1, stop_on_all_zeros=False)

@@ -15,6 +15,7 @@ import torch
 from csm_hf_amd import CSMConfig, CSMModel
 from csm_hf_amd.synth import synth_state_dict, synth_context
 from oracle import csm_oracle as O
+from _util import EXACT_KV
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -612,6 +613,7 @@ def test_sampling_from_torchs_global_generator_csm1b(gold):
     model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()})
     del sd
     model = model.to(DEV).eval()
+    model.kv_dtype = EXACT_KV      # draw-for-draw equality with the reference's fp32-arithmetic run needs the exact mode
     ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
     want = torch.from_numpy(g["tokens"])
     n = want.shape[1]
@@ -779,6 +781,7 @@ def test_split_k_gate_up_of_a_short_prefill():
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     del sd
+    m.kv_dtype = EXACT_KV      # this test asserts the exact mode (fp32 KV cache) against fp32-arithmetic values
     ids, mask = synth_context(cfg, 1, 16, 48, seed=2)               # 64 rows
 
     def run(precision, opts):
@@ -814,6 +817,7 @@ def test_skinny_tiles_of_the_lds_dma_gemm_for_short_prefills():
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     del sd
+    m.kv_dtype = EXACT_KV      # this test asserts the exact mode (fp32 KV cache) against fp32-arithmetic values
 
     def run(precision, n_ctx, opts):
         ids, mask = synth_context(cfg, 1, n_ctx // 4, n_ctx - n_ctx // 4, seed=2)

@@ -9,6 +9,7 @@ import torch
 from csm_hf_amd import CSMConfig, CSMModel
 from csm_hf_amd.synth import synth_state_dict, synth_context
 from oracle import csm_oracle as O
+from _util import EXACT_KV
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -183,6 +184,7 @@ def test_bench_eight_ranks_on_one_device_slices_like_one_process():
     m = CSMModel(cfg)
     m.load_state_dict(sd)
     del sd
+    m.kv_dtype = EXACT_KV      # the bench legs checked here run `--kv-dtype f32`
     ids, mask = synth_context(cfg, 8, 8, 24, seed=2)
     for r in (0, 3, 7):
         out = m.generate(ids[r:r + 1].to(DEV), mask[r:r + 1].to(DEV), max_new_frames=4, topk=1, stop_on_all_zeros=False)
