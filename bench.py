@@ -209,6 +209,43 @@ def run_config4(model, cfg, rank, world, dist, dev, ctx: int, frames: int):
     return out
 
 
+def run_b1_default_kv(model, cfg, ids, mask, ctx: int, W: int, K: int, topk: int, temperature: float):
+    """The headline workload (B = 1 per GPU, `ctx`-frame context, K timed frame-steps after W) in the SHIPPED DEFAULT of a bf16 checkpoint:
+    bf16 KV cache (`CSMModel.kv_dtype = "auto"`), exact fp32 activations.  The headline itself stays on the fp32 cache because that mode
+    reproduces the reference's token stream bit for bit (`parity.equal_all`); this record is what `from_pretrained(..., torch.bfloat16)`
+    users get, priced against the bytes of ITS cache width.  Parity of this mode: tests/test_gpu_default_mode.py (tolerance protocol)."""
+    B = ids.shape[0]
+    model.kv_dtype = "auto"
+    try:
+        eng = model._ensure_engine(B, ctx + W + K + 2, W + K + 1, B * ctx)
+        assert eng.kv_dtype == torch.bfloat16
+        eng.reset()
+        eng.set_kv_start([0] * B)
+        eng.prefill(ids, mask, want_outputs=False)
+        s = eng.sampling(temperature=temperature, topk=topk, seed=1234)
+        eng.generate(s, W, True)
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.generate(s, K, True)
+        eng.sync()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        hip_ms = eng.last_generate_ms()
+        by = bytes_step(cfg, B, ctx + W + (K - 1) / 2.0 + 1, kvbytes=2)
+        st = eng.prefetch_stats()
+        toks = eng.read_frames(0, W + K)
+        return {"kv_dtype": "bf16", "ms_per_step": round(wall / K * 1e3, 4), "hip_event_ms_per_step": round(hip_ms / K, 4),
+                "frames_per_s": round(B * K / wall, 2), "algorithmic_bytes_per_step": int(by),
+                "roofline_frac_of_8TBs": round(by / (hip_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "weight_streamer": {"gave_up": st["gave_up"], "finished": st["finished"], "disabled": st["health"]["disabled"]},
+                "tokens_checksum": int(toks.to(torch.int64).sum().item()),
+                "parity": "tolerance protocol of SURVEY 8-c against the reference fixtures: tests/test_gpu_default_mode.py"}
+    finally:
+        model._drop_engine()
+        model.kv_dtype = torch.float32
+
+
 def run_configs_235(model, cfg, dev):
     """End-to-end records of BASELINE configs[1], [2] and [4] through the public API (`CSMModel.generate`: prefill + frame loop +
     the host-side bookkeeping of the call), each timed on its second call (the first sizes the engine and captures the graph).
@@ -268,6 +305,10 @@ def run_configs_235(model, cfg, dev):
             rec[f"prefill_{prec}"] = {"wall_s": round(wall, 4), "decode_ms": round(dec_ms, 2), "ms_per_step_decode": round(dec_ms / 500, 4),
                                       "prefill_and_host_ms": round(wall * 1e3 - dec_ms, 2), "frames_per_s_end_to_end": round(500 / wall, 1),
                                       "tokens_checksum": ck}
+            by5 = bytes_step(cfg, 1, 2048 + (500 - 1) / 2.0 + 1, wbytes=1, kvbytes=4)
+            rec[f"prefill_{prec}"]["roofline"] = {"bound": "hbm", "kernel": "frame-step hipGraph, fp8-e4m3 linear weights", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                  "algorithmic_bytes_per_step": int(by5), "achieved": round(by5 / (dec_ms / 500 * 1e-3) / 1e9, 1),
+                                                  "frac": round(by5 / (dec_ms / 500 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         rec["workload"] = "csm-1b fp8-e4m3 linear weights, B=1, 2048-frame context prefilled inside the timed call + 500 frames greedy, CSMModel.generate"
         out["config5"] = rec
     except Exception as ex:      # informative sub-records: never break the bench line
@@ -531,6 +572,17 @@ def main():
     assert live_engines() == 1, f"rank {rank}: {live_engines()} engines alive in the timed process (one engine per process and GPU)"
 
     pf_stats = eng.prefetch_stats()
+    pf_stats["disabled_reason"] = None if pf_stats["health"]["disabled"] == 0 else pf_stats["health"]["reason"]
+    # per-rank step times: when a multi-GPU node runs this, the line shows that the process group saw N ranks
+    # and which rank was the slowest
+    per_rank_ms = [wall / K * 1e3]
+    ranks_seen = 1
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([wall / K * 1e3], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        per_rank_ms = [float(g[0]) for g in got]
     toks = eng.read_frames(0, W + K)
     all_toks = toks
     if dist is not None:      # the only RCCL traffic: gather finished frames, off the timed path
@@ -569,6 +621,8 @@ def main():
                        "batch_per_gpu": B, "context_frames": a.ctx, "parallelism": f"batch-split x{world}"},
             "tokens_checksum_per_rank": checks,
             "dist_backend": dist_backend,      # null: single process without a launcher (no process group)
+            "ranks_seen": ranks_seen, "ms_per_step_per_rank": [round(x, 4) for x in per_rank_ms],
+            "slowest_rank": int(max(range(len(per_rank_ms)), key=lambda i: per_rank_ms[i])),
             "weight_streamer": pf_stats,
             "prefill_ms": round(prefill_ms, 2),
             "prefill_ms_statistic": f"median of {PREFILL_SAMPLES} calls after {PREFILL_WARM} untimed",
@@ -638,6 +692,11 @@ def main():
     want4 = a.config4 != 0 and B == 1 and a.ctx == 512 or a.config4 == 1   # default: on (the B = 16 per-GPU shape is the
     # one an 8-GPU curve multiplies -- it belongs in every driver-timed line); --config4 0 switches it off
     c4 = None
+    b1_default = None
+    if want4 and not a.lean and a.weights == "bf16" and a.kv_dtype == "f32" and use_graph:
+        del eng
+        eng = None
+        b1_default = run_b1_default_kv(model, cfg, ids, mask, a.ctx, W, K, a.topk, a.temperature)
     if want4 and not a.lean and a.weights == "bf16":
         del eng
         c4 = run_config4(model, cfg, rank, world, dist, dev, a.ctx, a.config4_frames)
@@ -645,6 +704,8 @@ def main():
     if want4 and not a.lean and a.weights == "bf16" and world == 1 and os.environ.get("CSM_BENCH_NO_E2E") != "1":
         e2e = run_configs_235(model, cfg, dev)
     if rank == 0:
+        if b1_default is not None:
+            out["default_bf16_kv"] = b1_default
         if e2e is not None:
             out.update(e2e)
         if c4 is not None:

@@ -17,7 +17,9 @@ UNITS = ["gemv", "gemv_w0_k1", "gemv_w0_k2", "gemv_w0_k4", "gemv_w1_k1", "gemv_w
 # several template instantiations of the same epilogues) must round alike, bit for bit (tests: logits of wide launches against
 # 16-row launches); the few fused operations these epilogues want are spelled out (__fmaf_rn)
 UNIT_FLAGS = {"attn_prefill": ["-mllvm", "--amdgpu-mfma-vgpr-form"], "gemm16": ["-ffp-contract=off"], "gemm32": ["-ffp-contract=off"], "gemm128": ["-ffp-contract=off", "-mllvm", "--amdgpu-mfma-vgpr-form"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+# -amdgpu-kernarg-preload-count: leading scalar kernel parameters (up to 14 dwords) arrive in SGPRs, initialised by the dispatcher, instead of
+# being s_loaded by every wave at its first instruction (gemv.h GEMV_HOT_PARAMS; round 6)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

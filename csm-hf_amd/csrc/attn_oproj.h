@@ -15,6 +15,7 @@
 // B = 1 frame-step 3.28 -> 3.16 ms.  The launch is left out of the weight streamer's schedule (prefetch.h): with its
 // 2 MB streamed like the o_proj GEMV's were, the step measured 3.19 ms.
 #pragma once
+#include <type_traits>
 #include "attn_tile.h"
 
 struct AttnOprojArgs {
@@ -38,13 +39,25 @@ struct AttnOprojArgs {
 //  attention + matrix-core o_proj pair at B = 16 (5.58 vs 5.09 ms per step: every workgroup pulls its row's K/V tiles once per
 //  head) and removed in round 4; numbers in profiles/r03_b16_step_timeline.md and DESIGN.md's appendix.)
 
+// kernel-argument preload (gemv.h GEMV_HOT_PARAMS has the why): the 14 leading dwords are everything the kernels need to request
+// their weights, the residual, q and the K / V tiles -- 6 pointers, the cache pitch and a packed word (bit 0 prio, bits 8.. pos_const)
+#define AO_HOT_PARAMS const void* hW, float* hout, const int* hpos_ptr, const void* hk, const void* hv, const float* hq, int hlmax, uint32_t hpk
+#define AO_HOT_ARGS(a) (a).W, (a).out, (a).pos_ptr, (a).kcache, (a).vcache, (a).q, (a).lmax, (uint32_t)(((a).prio ? 1u : 0u) | ((a).pos_ptr ? 0u : ((uint32_t)(a).pos_const << 8)))
+#define AO_HOT_TAKE(a)                                                                                              \
+  do {                                                                                                              \
+    (a).W = hW; (a).out = hout; (a).pos_ptr = hpos_ptr; (a).kcache = hk; (a).vcache = hv; (a).q = hq; (a).lmax = hlmax; \
+    (a).prio = (int)(hpk & 1u); (a).pos_const = (int)(hpk >> 8);                                                    \
+  } while (0)
+
 #ifdef CSM_ATTN_OPROJ_KERNEL
 // blockDim = 64 n_q (n_q in {2, 4, 8}: the K/V tile alone is 128 registers).  A thread multiplies KPT = max(8, K / 64)
 // consecutive k of one output row, so a row takes K / KPT lanes (a whole wave for csm-1b's decoder: 8 rows per
 // workgroup, grid = N / 8 = 128 workgroups -- the 2 MB of weights must be pulled by many CUs at once: a CU draws only
 // ~11 B/clk from HBM, and the 32-rows-per-workgroup form of this kernel, 64 KB on each of 32 CUs, took 12 us).
 template <typename KT, typename WT, int HD>
-__global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
+__global__ __launch_bounds__(512) void attn_oproj_kernel(AO_HOT_PARAMS, AttnOprojArgs a) {
+  AO_HOT_TAKE(a);
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   using Tile = AttnTile32<KT, HD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[n_q][HD] | att[n_q][HD] | p[n_q][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,7 +135,9 @@ __global__ __launch_bounds__(512) void attn_oproj_kernel(AttnOprojArgs a) {
 // instructions), the same multiply-adds per wave, per-wave online-softmax partials (acc, m, l) merged through LDS by one wave
 // per head.  Shape: head_dim 128, n_q = 8, n_kv = 2, cache <= 32 positions (csm-1b's decoder); other shapes keep the kernel above.
 template <typename KT, typename WT>
-__global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AttnOprojArgs a) {
+__global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AO_HOT_PARAMS, AttnOprojArgs a) {
+  AO_HOT_TAKE(a);
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   constexpr int HD = 128, NQ = 8, G = 4, K = NQ * HD, KPW = 8;   // KPW = keys per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];   // q[8 waves][G * HD] | part[8 waves][G][HD] | att[NQ][HD] | stat[8][G][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

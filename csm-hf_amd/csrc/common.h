@@ -295,9 +295,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // branches around VOLATILE loads on purpose: from `p ? *p : (q ? *q : c)` the compiler built ONE load through a selected
 // pointer and parked the constant in scratch memory to have something to point at -- a dependent scratch round trip
 // (~1 500 clocks) ahead of every load of the QKV launches, constant-position decoder passes included.
+// (relaxed agent-scope atomic loads: a vector load that bypasses the non-coherent caches like the `volatile` loads of rounds 1-5 did, but
+//  without the s_waitcnt vmcnt(0) the compiler puts directly behind a volatile access -- that wait stood in front of every weight load of
+//  the backbone's QKV launches.  The counters are written by earlier launches of the same stream.)
 __device__ __forceinline__ int row_position(const int* row_pos, int m, const int* pos_ptr, int pos_const) {
-  if (row_pos) return *reinterpret_cast<const volatile int*>(row_pos + m);
-  if (pos_ptr) return *reinterpret_cast<const volatile int*>(pos_ptr);
+  if (row_pos) return __hip_atomic_load(row_pos + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (pos_ptr) return __hip_atomic_load(pos_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return pos_const;
 }
 

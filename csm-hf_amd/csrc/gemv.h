@@ -16,6 +16,7 @@
 // (SDPA as the prologue of the o_proj launch -- PRO_ATTN, round 1 -- measured 4 % slower per frame than the separate
 // launch and was removed in round 4; the B = 1 decoder runs attention + o_proj as attn_oproj_kernel.)
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "prefetch.h"
 #include "sample_wave.h"
@@ -113,6 +114,39 @@ struct GemvArgs {
   // consumed} of this launch, [grid][2] uint32; nullable
   uint32_t* dbg;
 };
+
+// ---- kernel-argument preload (round 6) --------------------------------------------------------------------------------------
+// A kernel whose arguments are ONE struct by value starts every wave with an s_load of the kernarg segment: a scalar-cache miss
+// to memory (each launch of a replayed graph has its own kernarg block) that stands in front of the first weight load of every
+// launch of the chain.  gfx950's dispatcher can instead initialise up to 14 SGPRs from the first 14 dwords of the kernarg segment
+// ("kernarg preload", -mllvm -amdgpu-kernarg-preload-count: build.py) -- but only for leading SCALAR parameters, not for struct
+// members.  The hot kernels of the decode chain therefore take what they need to issue their first loads as 14 leading dwords
+// (5 pointers + 4 ints) in front of the struct and overwrite the struct's copies with them; everything else is still read from the
+// struct, behind the loads.  tools/ubench/kernarg_preload.hip: 3.32 -> 3.15 us per dependent 4 MB launch (-0.16 us, x 614 launches
+// of the B = 1 frame-step); profiles/r06_kernarg_preload.md.
+//   p4 = out (the residual is prefetched first of all) -- EPI_QKV: row_pos if there is one, else pos_ptr (the position load is the first
+//        of the launch; a select on a flag would not do: the compiler turns `flag ? a.row_pos : nullptr` into an s_load + s_cselect)
+//   flags: bit 0 nt, 1 prio, 3 p4 is row_pos; bits 8-15 hd, 16-23 n_q, 24-31 n_kv
+#define GEMV_HOT_PARAMS const void* hW, const float* hx, const float* hln, unsigned* hprog, void* hp4, int hN, int hK, uint32_t hflags, int hi3
+#define GEMV_HOT_ARGS(a, EPI_)                                                                                                        \
+  (a).W, (a).x, (a).ln, (a).prog, ((EPI_) == EPI_QKV ? (void*)((a).row_pos ? (a).row_pos : (a).pos_ptr) : (void*)(a).out), (a).N, (a).K, \
+  (uint32_t)(((a).nt ? 1u : 0u) | ((a).prio ? 2u : 0u) | ((a).row_pos ? 8u : 0u) |                                                    \
+             (((uint32_t)(a).hd & 255u) << 8) | (((uint32_t)(a).n_q & 255u) << 16) | (((uint32_t)(a).n_kv & 255u) << 24)),             \
+  (a).pos_const
+// (hd, n_q, n_kv <= 255 is checked by the launchers)
+#define GEMV_HOT_TAKE(a, EPI_)                                                                    \
+  do {                                                                                            \
+    (a).W = hW; (a).x = hx; (a).ln = hln; (a).prog = hprog; (a).N = hN; (a).K = hK;               \
+    (a).nt = (int)(hflags & 1u); (a).prio = (int)((hflags >> 1) & 1u);                            \
+    if ((EPI_) == EPI_QKV) {                                                                      \
+      (a).pos_const = hi3;                                                                        \
+      if (hflags & 8u) { (a).row_pos = (const int*)hp4; (a).pos_ptr = nullptr; }                  \
+      else { (a).row_pos = nullptr; (a).pos_ptr = (const int*)hp4; }                              \
+      (a).hd = (int)((hflags >> 8) & 255u); (a).n_q = (int)((hflags >> 16) & 255u); (a).n_kv = (int)(hflags >> 24); \
+    } else {                                                                                      \
+      (a).out = (float*)hp4;                                                                      \
+    }                                                                                             \
+  } while (0)
 
 #ifndef CSM_ARGS_ONLY
 template <typename KT>
@@ -253,7 +287,9 @@ struct GemvEpi {
 // M = rows per launch: 1 (every single-sequence launch) or 2 (the two-token first decoder pass: both rows share every
 // weight register; a row's arithmetic -- pair accumulators, ascending chunks, wave_sum2 -- is exactly the M = 1 form's).
 template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T, int M = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
+  GEMV_HOT_TAKE(a, EPI);
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;   // only fp8 weights carry row scales: no kernarg read in front of the loads
   static_assert(M == 1 || (PRO != PRO_TOKNORM && PRO != PRO_SAMPLE && EPI != EPI_ARGMAX), "fused sampling is single-row");
   constexpr bool TOK = PRO == PRO_TOKNORM || PRO == PRO_SAMPLE;   // the input row comes from the projected-embedding table
   __shared__ float part[4][2 * T * M];
@@ -492,7 +528,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // its row pair exactly like gemv1_kernel<PRO_PLAIN, EPI_RESID, U = 4> (pair accumulators, ascending chunks, wave_sum2).
 // ---------------------------------------------------------------------------------------------------
 template <typename WT, int SMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemv1_combine_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemv1_combine_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
+  GEMV_HOT_TAKE(a, EPI_RESID);
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   constexpr int U = 4, HD = 64, K = 2048;
   __shared__ __attribute__((aligned(16))) float xs[K];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,7 +603,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 template <typename WT, typename KT, int M, int PRO, int EPI, int KS>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
+  GEMV_HOT_TAKE(a, EPI);
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] | red[M][4] | part[4][2M]
   constexpr int U = 4;
   constexpr int TPB = 4 / KS;

@@ -215,15 +215,16 @@ static int launch_attn_oproj_t(hipStream_t st, const AttnOprojArgs& a) {
   }
   if (gqa) {
     const size_t lds2 = ((size_t)8 * 4 * 128 * 2 + 8 * 128 + 8 * 4 * 2) * sizeof(float);
-    hipLaunchKernelGGL((attn_oproj_gqa_kernel<KT, WT>), dim3(a.N / 8), dim3(512), lds2, st, a);
+    hipLaunchKernelGGL((attn_oproj_gqa_kernel<KT, WT>), dim3(a.N / 8), dim3(512), lds2, st, AO_HOT_ARGS(a), a);
     return (int)hipGetLastError();
   }
-  if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 64>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 128>), grid, block, lds, st, a);
+  if (a.hd == 64) hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 64>), grid, block, lds, st, AO_HOT_ARGS(a), a);
+  else hipLaunchKernelGGL((attn_oproj_kernel<KT, WT, 128>), grid, block, lds, st, AO_HOT_ARGS(a), a);
   return (int)hipGetLastError();
 }
 int launch_attn_oproj(hipStream_t st, int wdtype, int kvdtype, const AttnOprojArgs& a) {
   if ((a.hd != 64 && a.hd != 128) || a.lmax > 32 || a.n_q % a.n_kv) return -2;
+  if (!a.pos_ptr && (a.pos_const < 0 || a.pos_const >= (1 << 23))) return -2;   // packed beside the priority bit in the preloaded word (attn_oproj.h AO_HOT_ARGS)
   if (a.n_q != 2 && a.n_q != 4 && a.n_q != 8) return -2;
   {
     const int K = a.n_q * a.hd, tpr = K / (K >= 1024 ? 16 : 8);   // lanes per output row: half a wave or a wave
