@@ -42,13 +42,32 @@ struct AttnArgs {
   uint32_t* dbg;      // timeline probe slots (common.h TL_BEGIN) of the attention launch and, 4096 words on, of the combine launch; nullable
 };
 
+// kernel-argument preload (gemv.h GEMV_HOT_PARAMS has the why): 6 pointers + the cache pitch + a packed word = the 14 dwords the
+// kernels need to request their first K / V tile.  p_pos = row_pos if there is one, else pos_ptr.
+//   packed: bit 0 prio, 1 p_pos is row_pos, 2 one_wave; bits 3-9 pos_const (0..127), 10-17 nsplit, 18-25 n_q, 26-31 n_kv
+//   hlmax: bits 0-23 the cache pitch, bits 24-31 the rows of the launch (the one-wave form derives its grid from it: gridDim is a
+//          hidden kernel argument, i.e. another s_load)
+#define ATTN_HOT_PARAMS const float* hq, const void* hk, const void* hv, const int* hpos, const int* hkvs, const int* hseq, int hlmax, uint32_t hpk
+#define ATTN_HOT_ARGS(a, rows_)                                                                                                           \
+  (a).q, (a).kcache, (a).vcache, ((a).row_pos ? (a).row_pos : (a).pos_ptr), (a).kv_start, (a).row_seq, (int)((uint32_t)(a).lmax | ((uint32_t)((rows_) <= 255 ? (rows_) : 0) << 24)), \
+  (uint32_t)(((a).prio ? 1u : 0u) | ((a).row_pos ? 2u : 0u) | ((a).one_wave ? 4u : 0u) |                                             \
+             ((((a).row_pos || (a).pos_ptr) ? 0u : (uint32_t)(a).pos_const) << 3) | ((uint32_t)(a).nsplit << 10) | ((uint32_t)(a).n_q << 18) | ((uint32_t)(a).n_kv << 26))
+#define ATTN_HOT_TAKE(a)                                                                                   \
+  do {                                                                                                     \
+    (a).q = hq; (a).kcache = hk; (a).vcache = hv; (a).kv_start = hkvs; (a).row_seq = hseq; (a).lmax = (int)((uint32_t)hlmax & 0xffffffu); \
+    if (hpk & 2u) { (a).row_pos = hpos; (a).pos_ptr = nullptr; } else { (a).row_pos = nullptr; (a).pos_ptr = hpos; } \
+    (a).prio = (int)(hpk & 1u); (a).one_wave = (int)((hpk >> 2) & 1u); (a).pos_const = (int)((hpk >> 3) & 127u);   \
+    (a).nsplit = (int)((hpk >> 10) & 255u); (a).n_q = (int)((hpk >> 18) & 255u); (a).n_kv = (int)(hpk >> 26);      \
+  } while (0)
+
 #ifndef CSM_ARGS_ONLY
 #include "attn_tile.h"
 
 // HD = head_dim (64 or 128).  One workgroup = (row, kv-head, split); wave g handles query head j*G+g.
 // PF = second register set: the next tile is in flight while the current one is consumed.
 template <typename KT, int HD, bool PF = false>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(ATTN_HOT_PARAMS, AttnArgs a) {
+  ATTN_HOT_TAKE(a);
   using Tile = AttnTile32<KT, HD>;
   __shared__ __attribute__((aligned(16))) float qs[16 * HD];  // up to 16 q-heads per kv-head
   __shared__ float pb[4][32];
@@ -62,7 +81,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     // the G one-wave workgroups of a (row, kv-head) read the same K / V tile: `per` workgroups apart in the grid, i.e. on ONE XCD when
     // rows x kv-heads is a multiple of 8 (workgroup id mod 8), so that three of the four reads hit that XCD's L2.  As the fastest index
     // (round 4) they sat on four XCDs: 19 MB fetched per decoder attention launch of a 128-row step for 4-8 MB of K / V
-    const int per = (int)gridDim.x / G;
+    const int r8 = (int)((uint32_t)hlmax >> 24);
+    const int per = r8 ? r8 * a.n_kv * a.nsplit : (int)gridDim.x / G;   // = gridDim.x / G; launches of more than 255 rows (context rows) read the hidden argument
     g0 = blk / per;
     blk -= g0 * per;
     gstep = G;
@@ -205,7 +225,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 // workgroups) at a 512-frame context instead of 32, which in turn lets the o_proj launch merge the split partials in its own
 // prologue (gemv.h gemv1_combine_kernel) -- the attn_combine launch of the B = 1 backbone layer is gone.  head_dim 64, G = 4.
 template <typename KT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_decode_gqa_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_decode_gqa_kernel(ATTN_HOT_PARAMS, AttnArgs a) {
+  ATTN_HOT_TAKE(a);
   constexpr int HD = 64, G = 4;
   using Tile = AttnTile32<KT, HD>;
   __shared__ __attribute__((aligned(16))) float qs[4][G * HD];   // wave-private copies of the G query heads

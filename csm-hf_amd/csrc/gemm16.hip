@@ -10,6 +10,7 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16 + NW * 16) * sizeof(float);
   if (a.xplanes && !a.Wt) return -2;   // planes are laid out for the fragment-order k order
+  if (KB > 31 || M > 31 || (EPI == EPI_QKV && (a.hd > 255 || a.n_q > 63 || a.n_kv > 15))) return -2;   // packed into the preloaded word (gemm16.h G16_HOT_ARGS)
   if (a.geom_out && a.Wt) {            // weight streamer (prefetch.h, kind 2): workgroup (bx, by) -> fragment blocks
     PfGeom& g = *a.geom_out;
     g.W = a.Wt; g.N = a.N; g.K = a.K; g.esz = (int)sizeof(WT); g.kind = 2;
@@ -27,10 +28,10 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
     }
   }
   if (a.pl1 && !a.xplanes && a.oplanes) return -1;   // one-plane mode exists on the planes path only (every producer of planes is itself fed planes)
-  if (a.xplanes && a.pl1) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
-  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  if (a.xplanes && a.pl1) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, G16_HOT_ARGS(a, M, KB, true, true, EPI), a, slabs, tickets);
+  else if (a.xplanes) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, true>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, G16_HOT_ARGS(a, M, KB, true, true, EPI), a, slabs, tickets);
+  else if (a.Wt) hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, true, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, G16_HOT_ARGS(a, M, KB, true, false, EPI), a, slabs, tickets);
+  else hipLaunchKernelGGL((gemm16_kernel<WT, KT, PRO, EPI, NW, PT, false, false>), (KB > 1 && a.kfast) ? dim3(KB, gx) : dim3(gx, KB), dim3(64 * NW), lds, st, G16_HOT_ARGS(a, M, KB, false, false, EPI), a, slabs, tickets);
   return (int)hipGetLastError();
 }
 

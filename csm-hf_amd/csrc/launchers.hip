@@ -11,12 +11,13 @@
 int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   if (a.n_q % a.n_kv != 0 || a.n_q / a.n_kv > 16) return -1;
   if (a.nsplit < 1 || a.nsplit > 64) return -1;
+  if (a.lmax >= (1 << 24) || a.n_q > 255 || a.n_kv > 63 || (!a.row_pos && !a.pos_ptr && (a.pos_const < 0 || a.pos_const > 127))) return -1;   // packed into the preloaded word (attn.h ATTN_HOT_ARGS)
   if (a.oplanes && rows > 128) return -1;
   const int G = a.n_q / a.n_kv;
   if (a.gqa && a.hd == 64 && G == 4 && !a.tickets && (!a.oplanes || rows <= 128)) {
     const int g2 = rows * a.n_kv * a.nsplit;
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_gqa_kernel<bf16_t>), dim3(g2), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_gqa_kernel<float>), dim3(g2), dim3(256), 0, st, a);
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_gqa_kernel<bf16_t>), dim3(g2), dim3(256), 0, st, ATTN_HOT_ARGS(a, rows), a);
+    else hipLaunchKernelGGL((attn_decode_gqa_kernel<float>), dim3(g2), dim3(256), 0, st, ATTN_HOT_ARGS(a, rows), a);
     int e = (int)hipGetLastError();
     if (e || a.nsplit == 1 || a.no_combine) return e;
     hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(rows * a.n_q), dim3(64), 0, st, a.part, a.n_q, a.nsplit, a.out, a.oplanes, a.pl1, a.dbg ? a.dbg + 4096 : nullptr);
@@ -26,13 +27,13 @@ int launch_attn(hipStream_t st, int kvdtype, int rows, const AttnArgs& a) {
   const int bd = a.one_wave ? 64 : 256;
   if (a.hd == 64) {
     if (a.tile_prefetch) {
-      if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64, true>), dim3(grid), dim3(bd), 0, st, a);
-      else hipLaunchKernelGGL((attn_decode_kernel<float, 64, true>), dim3(grid), dim3(bd), 0, st, a);
-    } else if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(bd), 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(bd), 0, st, a);
+      if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64, true>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
+      else hipLaunchKernelGGL((attn_decode_kernel<float, 64, true>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
+    } else if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 64>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 64>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
   } else if (a.hd == 128) {
-    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(bd), 0, st, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<float, 128>), dim3(grid), dim3(bd), 0, st, a);
+    if (kvdtype == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
+    else hipLaunchKernelGGL((attn_decode_kernel<float, 128>), dim3(grid), dim3(bd), 0, st, ATTN_HOT_ARGS(a, rows), a);
   } else {
     return -1;
   }
