@@ -128,23 +128,41 @@ struct GemvArgs {
 //        of the launch; a select on a flag would not do: the compiler turns `flag ? a.row_pos : nullptr` into an s_load + s_cselect)
 //   flags: bit 0 nt, 1 prio, 3 p4 is row_pos; bits 8-15 hd, 16-23 n_q, 24-31 n_kv
 #define GEMV_HOT_PARAMS const void* hW, const float* hx, const float* hln, unsigned* hprog, void* hp4, int hN, int hK, uint32_t hflags, int hi3
-#define GEMV_HOT_ARGS(a, EPI_)                                                                                                        \
-  (a).W, (a).x, (a).ln, (a).prog, ((EPI_) == EPI_QKV ? (void*)((a).row_pos ? (a).row_pos : (a).pos_ptr) : (void*)(a).out), (a).N, (a).K, \
+#define GEMV_HOT_ARGS(a, PRO_, EPI_)                                                                                                  \
+  (a).W,                                                                                                                              \
+  ((PRO_) == PRO_TOKNORM ? reinterpret_cast<const float*>((a).am_in) : ((PRO_) == PRO_COMBINE ? (a).cmb_part : (a).x)),              \
+  (a).ln, (a).prog,                                                                                                                   \
+  ((PRO_) == PRO_TOKNORM ? (void*)const_cast<float*>((a).tok_table + (size_t)(a).tok_row_base * (size_t)(a).K)                       \
+                         : ((EPI_) == EPI_QKV ? (void*)((a).row_pos ? (a).row_pos : (a).pos_ptr) : (void*)(a).out)),                  \
+  (a).N, (a).K,                                                                                                                       \
   (uint32_t)(((a).nt ? 1u : 0u) | ((a).prio ? 2u : 0u) | ((a).row_pos ? 8u : 0u) |                                                    \
              (((uint32_t)(a).hd & 255u) << 8) | (((uint32_t)(a).n_q & 255u) << 16) | (((uint32_t)(a).n_kv & 255u) << 24)),             \
-  (a).pos_const
+  ((PRO_) == PRO_TOKNORM ? (a).am_n : ((PRO_) == PRO_COMBINE ? (a).cmb_ns : (a).pos_const))
 // (hd, n_q, n_kv <= 255 is checked by the launchers)
-#define GEMV_HOT_TAKE(a, EPI_)                                                                    \
+// PRO_TOKNORM (the decoder's token-indirect QKV launch; its position is a constant, pos_ptr / row_pos are null): the launch's critical path
+// is pairs -> token -> table row, so the pair array travels in the x slot, the table (already offset to the codebook's rows) in the p4
+// slot and the pair count in the last int; pos_const stays in the struct (used behind the weight loads).  PRO_COMBINE: the split-KV
+// partials in the x slot, their count in the last int.
+#define GEMV_HOT_TAKE(a, PRO_, EPI_)                                                              \
   do {                                                                                            \
-    (a).W = hW; (a).x = hx; (a).ln = hln; (a).prog = hprog; (a).N = hN; (a).K = hK;               \
+    (a).W = hW; (a).ln = hln; (a).prog = hprog; (a).N = hN; (a).K = hK;                           \
     (a).nt = (int)(hflags & 1u); (a).prio = (int)((hflags >> 1) & 1u);                            \
-    if ((EPI_) == EPI_QKV) {                                                                      \
-      (a).pos_const = hi3;                                                                        \
-      if (hflags & 8u) { (a).row_pos = (const int*)hp4; (a).pos_ptr = nullptr; }                  \
-      else { (a).row_pos = nullptr; (a).pos_ptr = (const int*)hp4; }                              \
-      (a).hd = (int)((hflags >> 8) & 255u); (a).n_q = (int)((hflags >> 16) & 255u); (a).n_kv = (int)(hflags >> 24); \
+    if ((PRO_) == PRO_TOKNORM) {                                                                  \
+      (a).am_in = reinterpret_cast<const float2*>(hx); (a).am_n = hi3;                            \
+      (a).tok_table = reinterpret_cast<const float*>(hp4); (a).tok_row_base = 0;                  \
+      (a).row_pos = nullptr; (a).pos_ptr = nullptr;                                               \
     } else {                                                                                      \
-      (a).out = (float*)hp4;                                                                      \
+      if ((PRO_) == PRO_COMBINE) { (a).cmb_part = hx; (a).cmb_ns = hi3; } else (a).x = hx;        \
+      if ((EPI_) == EPI_QKV) {                                                                    \
+        (a).pos_const = hi3;                                                                      \
+        if (hflags & 8u) { (a).row_pos = (const int*)hp4; (a).pos_ptr = nullptr; }                \
+        else { (a).row_pos = nullptr; (a).pos_ptr = (const int*)hp4; }                            \
+      } else {                                                                                    \
+        (a).out = (float*)hp4;                                                                    \
+      }                                                                                           \
+    }                                                                                             \
+    if ((EPI_) == EPI_QKV) {                                                                      \
+      (a).hd = (int)((hflags >> 8) & 255u); (a).n_q = (int)((hflags >> 16) & 255u); (a).n_kv = (int)(hflags >> 24); \
     }                                                                                             \
   } while (0)
 
@@ -288,7 +306,7 @@ struct GemvEpi {
 // weight register; a row's arithmetic -- pair accumulators, ascending chunks, wave_sum2 -- is exactly the M = 1 form's).
 template <typename WT, typename KT, int PRO, int EPI, int U, int KS, int T, int M = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) void gemv1_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
-  GEMV_HOT_TAKE(a, EPI);
+  GEMV_HOT_TAKE(a, PRO, EPI);
   if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;   // only fp8 weights carry row scales: no kernarg read in front of the loads
   static_assert(M == 1 || (PRO != PRO_TOKNORM && PRO != PRO_SAMPLE && EPI != EPI_ARGMAX), "fused sampling is single-row");
   constexpr bool TOK = PRO == PRO_TOKNORM || PRO == PRO_SAMPLE;   // the input row comes from the projected-embedding table
@@ -320,6 +338,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   for (int t = 0; t < T; ++t) {
     k[t] = gemv_map_task<EPI>(a, (blockIdx.x * TPB + tw) * T + t, ntask);
     if (kw == 0) epi[t].prefetch(a, k[t]);
+  }
+  // PRO_TOKNORM: the head launch's per-task (value, index) pairs are requested FIRST of all (round 6): vmcnt retires in issue order, so
+  // pairs requested behind the weights (rounds 2-5) could only be consumed once every weight of the wave had landed -- the launch's
+  // critical chain pairs -> token -> table row started a whole weight flight late.  The pair array's address is a preloaded argument.
+  constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
+  float2 pv[PRO == PRO_TOKNORM ? NP : 1];
+  if (PRO == PRO_TOKNORM) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {   // unconditional loads (a slot beyond am_n re-reads the last pair and is masked below): no branch per load
+      const int idx = lane + 64 * j;
+      pv[j] = a.am_in[idx < a.am_n ? idx : a.am_n - 1];
+    }
   }
   if (!TOK) {
 #pragma unroll
@@ -356,18 +386,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
   // every wave of the launch resident at once the other waves cover.)
   int tok_bi = 0;
   if (PRO == PRO_TOKNORM) {
-    // greedy token of the previous codebook = argmax over the head launch's per-task (value, index) pairs
-    constexpr int NP = 17;  // up to 1088 pairs (V = 2051 -> 1026)
-    float2 pv[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int idx = lane + 64 * j;
-      pv[j] = idx < a.am_n ? a.am_in[idx] : make_float2(-INFINITY, __int_as_float(0x7fffffff));
-    }
     float bv = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
+      if (lane + 64 * j >= a.am_n) pv[j] = make_float2(-INFINITY, __int_as_float(0x7fffffff));
       const int ci = __float_as_int(pv[j].y);
       if (pv[j].x > bv || (pv[j].x == bv && ci < bi)) { bv = pv[j].x; bi = ci; }
     }
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
 // ---------------------------------------------------------------------------------------------------
 template <typename WT, int SMAX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemv1_combine_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
-  GEMV_HOT_TAKE(a, EPI_RESID);
+  GEMV_HOT_TAKE(a, PRO_COMBINE, EPI_RESID);
   if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   constexpr int U = 4, HD = 64, K = 2048;
   __shared__ __attribute__((aligned(16))) float xs[K];
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 template <typename WT, typename KT, int M, int PRO, int EPI, int KS>
 __global__ __launch_bounds__(256) void gemv_kernel(GEMV_HOT_PARAMS, GemvArgs a) {
-  GEMV_HOT_TAKE(a, EPI);
+  GEMV_HOT_TAKE(a, PRO, EPI);
   if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [M][K] | red[M][4] | part[4][2M]
   constexpr int U = 4;
