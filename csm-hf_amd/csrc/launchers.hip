@@ -325,7 +325,7 @@ int launch_sample(hipStream_t st, int rows, const SampleArgs& a) {
   // top-k: scaled logits | survivor values | survivor indices in LDS; greedy streams the row from memory
   const size_t lds = greedy ? 0 : (size_t)3 * a.V * sizeof(float);
   if (lds > 160 * 1024 - 4096) return -3;   // V > 13 300: the reference's sampler has no such limit (documented)
-  hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), lds, st, SMP_HOT_ARGS(a), a);
   return (int)hipGetLastError();
 }
 __global__ void set_rng_kernel(uint64_t* p, uint64_t seed, uint64_t row_offset) { p[0] = seed; p[1] = row_offset; }

@@ -515,7 +515,15 @@ __device__ __forceinline__ float block_max(float v, float* s_val) {
   return fmaxf(fmaxf(s_val[0], s_val[1]), fmaxf(s_val[2], s_val[3]));
 }
 
-__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+// kernel-argument preload (gemv.h GEMV_HOT_PARAMS has the why): logits, frame counter, table, trace and copy destination pointers,
+// the row pitch, V, a packed word (bit 0 prio, bit 1 spin_ticks > 0, bits 8.. topk) and the temperature
+#define SMP_HOT_PARAMS const float* hlogits, const int* hframe, const float* htable, float* htrace, float* hcopy, int hldl, int hV, uint32_t hpk, float htemp
+#define SMP_HOT_ARGS(a) (a).logits, (a).frame_ptr, (a).proj_table, (a).logits_trace, (a).copy_dst, (a).ldl, (a).V,                     \
+  (uint32_t)(((a).prio ? 1u : 0u) | ((a).spin_ticks > 0 ? 2u : 0u) | ((uint32_t)((a).topk > 0xffffff ? 0xffffff : ((a).topk < 0 ? 0 : (a).topk)) << 8)), (a).temperature
+__global__ __launch_bounds__(256) void sample_kernel(SMP_HOT_PARAMS, SampleArgs a) {
+  a.logits = hlogits; a.frame_ptr = hframe; a.proj_table = htable; a.logits_trace = htrace; a.copy_dst = hcopy; a.ldl = hldl; a.V = hV;
+  a.prio = (int)(hpk & 1u); a.topk = (int)(hpk >> 8); a.temperature = htemp;
+  if (!(hpk & 2u)) a.spin_ticks = 0;
   extern __shared__ __attribute__((aligned(16))) float sx[];  // [V] scaled logits
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
@@ -554,9 +562,19 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
   } else if (greedy) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-      const float v = lg[i];
-      if (v > bv) { bv = v; bi = i; }
+    if (V <= 256 * 9) {
+      // round 6: the thread's <= 9 logits are requested at once (a slot beyond V re-reads the last logit and is masked); the loop form
+      // below issued one load per iteration behind the previous compare -- nine dependent round trips, most of the launch's 5.2 us
+      float v[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { const int i = tid + 256 * j; v[j] = lg[i < V ? i : V - 1]; }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { const int i = tid + 256 * j; if (i < V && v[j] > bv) { bv = v[j]; bi = i; } }   // ascending i: the lowest index of a tie wins, as below
+    } else {
+      for (int i = tid; i < V; i += 256) {
+        const float v = lg[i];
+        if (v > bv) { bv = v; bi = i; }
+      }
     }
     choice = block_argmax(bv, bi, s_val, s_idx);
   } else {
