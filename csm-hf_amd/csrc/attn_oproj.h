@@ -154,7 +154,6 @@ __global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AO_HOT_PARAMS, Attn
   W8<WT> w0, w1;
   w0.load(wp);
   w1.load(wp + 8);
-  const float ws = a.wscale ? a.wscale[n] : 1.f;
   float resid = 0.f;
   if (lane == 0) resid = a.out[n];
   const int pos = row_position(nullptr, 0, a.pos_ptr, a.pos_const);
@@ -183,6 +182,7 @@ __global__ __launch_bounds__(512) void attn_oproj_gqa_kernel(AO_HOT_PARAMS, Attn
     *reinterpret_cast<f32x4*>(qs + lane * 8) = qa;
     *reinterpret_cast<f32x4*>(qs + lane * 8 + 4) = qb;
   }
+  const float ws = a.wscale ? a.wscale[n] : 1.f;   // fp8 row scale: behind every other request (its pointer is not among the preloaded arguments)
   __builtin_amdgcn_wave_barrier();
   float* const mypart = partb + wave * (G * HD);
   if (my > 0) {

@@ -209,12 +209,16 @@ struct GemvEpi {
   float a0[M], a1[M];
   float sc0, sc1;  // row scales of the two outputs (fp8 weights), 1 otherwise
   int pos[M];
-  __device__ __forceinline__ void prefetch(const GemvArgs& a, const GemvTask& k) {
-    sc0 = sc1 = 1.f;
+  // row scales of fp8 weights: requested BEHIND the weight loads (round 6) -- they are consumed last, and their pointer is the one early
+  // argument that does not fit the 14 preloaded dwords: in front of the weights it put the kernarg read back on the launch's critical path
+  __device__ __forceinline__ void prefetch_scale(const GemvArgs& a, const GemvTask& k) {
     if (a.wscale && k.live) {
       sc0 = a.wscale[k.r0];
       if (k.has1) sc1 = a.wscale[k.r1];
     }
+  }
+  __device__ __forceinline__ void prefetch(const GemvArgs& a, const GemvTask& k) {
+    sc0 = sc1 = 1.f;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       a0[m] = a1[m] = 0.f;
@@ -376,6 +380,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) voi
       if (a.nt) { w0[t][u].load_nt(w0p + u * 512); w1[t][u].load_nt(w1p + u * 512); }
       else { w0[t][u].load(w0p + u * 512); w1[t][u].load(w1p + u * 512); }
     }
+  }
+  if (kw == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) epi[t].prefetch_scale(a, k[t]);
   }
   if (EPI == EPI_QKV && kw == 0) {
 #pragma unroll
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       else { w0[u].load(w0p + u * 512); w1[u].load(w1p + u * 512); }
     }
   }
+  epi.prefetch_scale(a, k);
   {
     float Mx = st[0][0];
 #pragma unroll
@@ -679,7 +688,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GEMV_HOT_PARAMS, GemvArgs a) 
   // weight register sets, which stay in flight across the prologue's LDS-only barriers.
   if (kw == 0) {
     ea.prefetch(a, ta);
-    if (iters > 1) eb.prefetch(a, tb);
+    ea.prefetch_scale(a, ta);
+    if (iters > 1) { eb.prefetch(a, tb); eb.prefetch_scale(a, tb); }
   }
   constexpr int XR = 2;  // x column blocks of 1024 held in registers (K <= 2048: every normed input of the model)
   f32x4 xv[M][XR], lnw[XR];
@@ -820,7 +830,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GEMV_HOT_PARAMS, GemvArgs a) 
     t = gemv_map_task<EPI>(a, cur.task + 2 * stride, ntask);
     if (more) {
       issue(t, w0, w1, 0);
-      if (kw == 0) { ep.prefetch(a, t); ep.prefetch_late(a, t); }
+      if (kw == 0) { ep.prefetch(a, t); ep.prefetch_scale(a, t); ep.prefetch_late(a, t); }
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) wave_sum2(acc0[m], acc1[m]);
