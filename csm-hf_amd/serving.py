@@ -66,6 +66,7 @@ class ContinuousBatcher:
         self.skip_ahead = 4                 # requests that may overtake a head deferred to the next batch (in total, per deferred head)
         self.overtakes = 0
         self._overtaken: Dict[int, int] = {}
+        self._refused = None                # why the last _join refused the head of the queue: None | "growth" | "budget"
         self.frame_seconds = float(frame_seconds)
         import time as _time
         self._clock = clock or _time.perf_counter
@@ -169,12 +170,32 @@ class ContinuousBatcher:
             eng.generate(s, k, m.use_graph)
             toks_dev = eng.read_frames(f0, k)
             toks = toks_dev.cpu()
+            # pass 1 (host, before anything reaches the codec): how many of the chunk's frames every live row takes, and whether the
+            # delivered ids fit the codec's codebook.  A request whose ids do not fails alone -- its tokens are returned,
+            # its audio is not -- and the check comes BEFORE the decode: nothing out of range is clamped into the stateful codec on behalf
+            # of a request that is about to be failed
+            took_of, done_of = {}, {}
+            for b, r in enumerate(rows):
+                if r is None:
+                    continue
+                took, done = 0, False
+                for i in range(k):
+                    if bool((toks[b, i] == 0).all()) or len(r[2]) + took >= r[1]:
+                        done = True
+                        break
+                    took += 1
+                if dec is not None and took and not self.clamp_audio_ids and int(toks[b, :took].max()) >= dec.cfg.codebook_size:
+                    self.errors[r[0]] = (f"generated token id {int(toks[b, :took].max())} is outside the codec's codebook "
+                                         f"({dec.cfg.codebook_size}); no audio for this request")
+                    done = True
+                    waves[b] = []
+                took_of[b], done_of[b] = took, done
             wav = None
             if dec is not None:
-                # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of
-                # idle / finished rows are decoded too and dropped; ids beyond the codec's codebook cannot come from a real model)
-                live = [b for b, r in enumerate(rows) if r is not None]
-                codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k] (the clamp only touches idle rows)
+                # the chunk's frames of EVERY row through the codec, max_frames // B frames per stream-group call (frames of idle / finished /
+                # failed rows are decoded too and dropped: their streams are reset when the row is taken over; the clamp only touches those)
+                live = [b for b, r in enumerate(rows) if r is not None and r[0] not in self.errors]
+                codes = toks_dev.clamp(max=dec.cfg.codebook_size - 1).permute(0, 2, 1).contiguous()      # [B, 32, k]
                 step = max(1, dec.max_frames // B)
                 wav_dev = torch.cat([dec.streams_decode(codes[:, :, a:a + step]) for a in range(0, k, step)], dim=-1)   # [B, 1, k * spf]
                 # only the live rows' samples cross to the host (one copy), indexed back by row below
@@ -184,23 +205,9 @@ class ContinuousBatcher:
             for b, r in enumerate(rows):
                 if r is None:
                     continue
-                done = False
-                took = 0
-                for i in range(k):
-                    if bool((toks[b, i] == 0).all()) or len(r[2]) >= r[1]:
-                        done = True
-                        break
+                took, done = took_of[b], done_of[b]
+                for i in range(took):
                     r[2].append(toks[b, i])
-                    took += 1
-                if dec is not None and took and not self.clamp_audio_ids and int(toks[b, :took].max()) >= dec.cfg.codebook_size:
-                    # only the frames actually DELIVERED are checked (frames behind a row's stop or budget are never decoded for anyone),
-                    # and only this request fails: its tokens are returned, its audio is not, the batch goes on
-                    self.errors[r[0]] = (f"generated token id {int(toks[b, :took].max())} is outside the codec's codebook "
-                                         f"({dec.cfg.codebook_size}); no audio for this request")
-                    done = True
-                    waves[b] = []
-                elif wav is not None and took:
-                    pass
                 if wav is not None and took and r[0] not in self.errors:
                     waves[b].append(wav[wav_row[b], 0, :took * spf])
                 if took:
@@ -222,10 +229,13 @@ class ContinuousBatcher:
             for b in idle:
                 if not self._queue:
                     break
-                st, eng = self._join(eng, b, k, any(r is not None for r in rows))
-                if st is None and getattr(self, "_deferred_rid", None) == self._queue[0][0]:
-                    # the head waits for the NEXT batch (growth cap): up to `skip_ahead` shorter requests behind it may take idle rows
-                    # meanwhile -- a bounded overtake, so the deferred head cannot starve (rows sat idle behind it)
+                others_live = any(r is not None for r in rows)
+                st, eng = self._join(eng, b, k, others_live)
+                if st is None and self._refused == "growth" and others_live:
+                    # the head was refused IN THIS CALL for the growth / shift cap and waits for the NEXT batch: up to `skip_ahead` shorter
+                    # requests behind it may take idle rows meanwhile -- a bounded overtake, so the deferred head cannot starve.  Not when it
+                    # was refused for the chunk's prefill budget (it joins after the next chunk), and not when no row is live: then the
+                    # batch ends and the head opens the next one -- an overtaker would keep this batch alive at occupancy 1
                     head = self._queue[0][0]
                     if self._overtaken.get(head, 0) >= self.skip_ahead:
                         break
@@ -237,7 +247,7 @@ class ContinuousBatcher:
                             self._queue.rotate(pos)
                             self._queue.appendleft(item)
                             self.overtakes += 1
-                            st, eng = self._join(eng, b, k, any(r is not None for r in rows))
+                            st, eng = self._join(eng, b, k, True)
                             break
                 if st is None:                      # the head of the queue waits (budget spent / growth cap)
                     break
@@ -295,10 +305,14 @@ class ContinuousBatcher:
             if getattr(self, "_deferred_rid", None) != rid:
                 self.deferred_to_next_batch += 1
                 self._deferred_rid = rid
+            self._refused = "growth"
             return None, eng
         if S > self._budget_left and self._budget_left < self.join_budget_rows and others_live:
             self.joins_deferred_by_budget += 1      # not the first join of this chunk and it does not fit what is left
+            self._refused = "budget"
             return None, eng
+        self._refused = None
+        self._overtaken.pop(rid, None)              # admitted: its overtake count is history
         self._queue.popleft()
         self._budget_left -= S
         need = max(eng.length, S) + k + 1

@@ -315,3 +315,75 @@ def test_round5_serving_limits_and_param_signature():
     sig0 = m2._param_signature()
     m2.projection.weight = torch.nn.Parameter(torch.zeros_like(m2.projection.weight), requires_grad=False)
     assert m2._param_signature() != sig0
+
+
+def test_overtake_only_for_a_growth_refusal_with_a_live_row_and_bookkeeping_is_pruned():
+    """ADVICE r5 (medium).  (i) When the LAST live row of a batch finishes while the head of the queue is deferred for the growth cap, nothing
+    overtakes: the batch ends and the head opens the next one (an overtaker used to keep the batch alive at occupancy 1 and make the head
+    wait for whole generations).  (ii) A head refused only for the chunk's prefill BUDGET is not overtaken (it joins after the next
+    chunk).  (iii) The overtake count of an admitted head is dropped.  (iv) A request whose delivered ids do not fit the codec fails
+    alone, before anything of it reaches the codec."""
+    # (i) both rows end in the same chunk; c (too long for this batch) is deferred; d is short and could have overtaken
+    m = StubModel(max_frames=64)
+    cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=4, max_shift=100)
+    a = cb.submit(*utterance(1, 3), max_new_frames=4)
+    b = cb.submit(*utterance(2, 3), max_new_frames=4)
+    c = cb.submit(*utterance(3, 900), max_new_frames=2)
+    d = cb.submit(*utterance(4, 3), max_new_frames=2)
+    out = cb.run()
+    assert [out[x].shape[0] for x in (a, b, c, d)] == [4, 4, 2, 2]
+    assert cb.overtakes == 0 and len(m.engines) == 2
+    assert not any(x[0] == "join" for x in m.engines[0].log), m.engines[0].log     # nobody joined the dying batch
+    assert m.engines[1].log[0] == ("prefill", 2, 900)                              # c and d opened the next batch together
+    assert cb._overtaken == {}
+    # (ii) budget refusal: the head (60 frames) does not fit what is left of the chunk's budget after the first join; the short request
+    # behind it must NOT slip past it
+    m2 = StubModel(max_frames=64)
+    cb2 = ContinuousBatcher(m2, batch_size=3, topk=1, check_every=2, join_budget_rows=64)
+    r0 = cb2.submit(*utterance(1, 80), max_new_frames=2)
+    r1 = cb2.submit(*utterance(2, 80), max_new_frames=2)
+    r2 = cb2.submit(*utterance(6, 80), max_new_frames=30)
+    r3 = cb2.submit(*utterance(3, 40), max_new_frames=2)        # first join of the chunk: admitted (40 of 64)
+    r4 = cb2.submit(*utterance(4, 60), max_new_frames=2)        # 60 > 24 left: waits for the next chunk
+    r5 = cb2.submit(*utterance(7, 5), max_new_frames=2)         # would fit the 24 left -- but FIFO holds for a budget refusal
+    out2 = cb2.run()
+    assert len(out2) == 6 and cb2.overtakes == 0 and cb2.joins_deferred_by_budget >= 1
+    joins = [x for x in m2.engines[0].log if x[0] == "join"]
+    assert [j[2] for j in joins][:3] == [40, 60, 5], joins      # context lengths in FIFO order
+    # (iii) a deferred head that was overtaken and then admitted leaves no entry behind
+    m3 = StubModel(max_frames=64)
+    cb3 = ContinuousBatcher(m3, batch_size=2, topk=1, check_every=4, max_shift=100)
+    cb3.submit(*utterance(1, 3), max_new_frames=2)
+    cb3.submit(*utterance(2, 3), max_new_frames=14)
+    cb3.submit(*utterance(3, 900), max_new_frames=2)
+    cb3.submit(*utterance(4, 3), max_new_frames=2)
+    cb3.run()
+    assert cb3.overtakes == 1 and cb3._overtaken == {}
+
+
+def test_out_of_range_ids_fail_the_request_before_the_codec_sees_them():
+    class StubCodec:
+        def __init__(self):
+            self.cfg = types.SimpleNamespace(codebook_size=250, samples_per_frame=4)
+            self.max_frames = 8
+            self.seen = []
+
+        def streams_open(self, n):
+            self.n = n
+
+        def streams_reset(self, b):
+            pass
+
+        def streams_decode(self, codes):
+            self.seen.append(codes.clone())
+            return torch.zeros(codes.shape[0], 1, codes.shape[2] * 4)
+
+    m = StubModel(max_frames=64)
+    dec = StubCodec()
+    cb = ContinuousBatcher(m, batch_size=2, topk=1, check_every=2, audio_decoder=dec)
+    ok = cb.submit(*utterance(1, 3), max_new_frames=4)          # ids 101.. : inside the codebook
+    bad = cb.submit(*utterance(3, 3), max_new_frames=4)         # ids 301.. : outside
+    out = cb.run()
+    assert out[ok].shape[0] == 4 and bad in cb.errors and ok not in cb.errors
+    assert cb.audio[ok].numel() == 4 * 4 and cb.audio[bad].numel() == 0
+    assert out[bad].shape[0] == 2                               # the tokens of the chunk that failed are still returned
