@@ -131,6 +131,8 @@ class ContinuousBatcher:
         m, B = self.model, self.B
         C = m.config.audio_num_codebooks
         first = [self._queue.popleft() for _ in range(min(B, len(self._queue)))]
+        for item in first:
+            self._overtaken.pop(item[0], None)      # admitted (it opens this batch): its overtake count is history
         T0 = max(r[1].shape[0] for r in first)
         ids = torch.zeros(B, T0, C + 1, dtype=torch.long)
         mask = torch.zeros(B, T0, C + 1, dtype=first[0][2].dtype)
