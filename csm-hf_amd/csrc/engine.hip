@@ -250,6 +250,7 @@ struct csm_engine {
   int pf_disabled = 0;             // 0 on;  1 the two streams share a hardware queue (probe);  2 repeated give-ups with the probe passing;
                                    // 3 dispatch not round-robin over the XCDs;  4 the probe at engine creation failed
   int pf_budget_us = 20000;        // no launch starting for this long while launches are outstanding = a stalled chain
+  int sample_legacy = 0;           // test hook: csm_sample_topk's top-k on sample_kernel's histogram / radix selection of rounds 1-4
   int pf_force_serial = 0;         // test hook: streamer (and probe) on the ENGINE stream -- the failure mode of two streams on one hardware queue
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
   int pf_enable = 1, pf_window_mb = 6; static constexpr int pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
@@ -694,6 +695,7 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "prefill_fuse_quant")) e->prefill_fuse_quant = value ? 1 : 0;
   else if (!strcmp(name, "dbg_skip")) { e->dbg_skip = value & 0xffff; e->g16_slab = (value >> 16) << 4; }   // bits 16-19: in-kernel knock-outs of the CSM_G16_KO build
   else if (!strcmp(name, "rows64")) e->rows64 = value < 0 ? -1 : (value ? 1 : 0);   // -1: 16-row launches only (tests: every wider form against gemm16_kernel)
+  else if (!strcmp(name, "sample_legacy")) { e->sample_legacy = value ? 1 : 0; return 0; }   // test hook: the stand-alone sampler's old selection path
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
@@ -2304,6 +2306,7 @@ extern "C" int csm_sample_topk(csm_engine_t* e, const float* logits, int rows, i
   SampleArgs a{};
   a.logits = logits; a.ldl = V; a.V = V; a.temperature = temperature; a.topk = topk; a.seed = seed; a.noise = noise;
   a.noise_ld = V; a.cb = 0; a.C = 1; a.B = rows; a.max_frames = 1; a.idx_out = out_idx;
+  a.legacy = e ? e->sample_legacy : 0;
   LCK(launch_sample(st, rows, a));
   if (!e) HIPCK(hipStreamSynchronize(st));
   return 0;

@@ -479,6 +479,7 @@ struct SampleArgs {
   uint32_t* dbg;        // timeline probe slot (common.h TL_BEGIN), nullable
   int prio;             // 1 = s_setprio 3 at kernel entry
   int spin_ticks;       // TIMING ONLY: the launch idles this many 10 ns ticks before it starts (how a long launch in the chain affects the weight streamer)
+  int legacy;           // TEST HOOK (engine option "sample_legacy"): top-k on the histogram / radix path of rounds 1-4 instead of sample_wave.h's selection
 };
 
 #ifndef CSM_ARGS_ONLY
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SMP_HOT_PARAMS, SampleArgs 
     for (int i = tid; i < a.copy_n; i += 256) a.copy_dst[i] = a.copy_src[i];
 
   int choice;
-  if (!greedy && V >= WS_VMIN && V <= WS_VMAX && a.temperature > 0.f) {
+  if (!greedy && V >= WS_VMIN && V <= WS_VMAX && a.temperature > 0.f && !a.legacy) {
     // round 5: the barrier-light selection of sample_wave.h (values in registers, one histogram pass, LDS-only barriers): 9.8 -> ~5 us
     // per launch at top-k 50; term for term the arithmetic of the path below (tests: the two agree token for token)
     WaveSampleArgs w{};

@@ -91,7 +91,7 @@ __device__ __forceinline__ int wg_sample_topk(const WaveSampleArgs& a, float* ld
   }
   const int ktop = a.topk < V ? a.topk : V;
   int krem = ktop;
-  uint32_t kth_key = 0;
+  uint32_t kth_key = 0;   // (if 64 rounds ever ended without a decision, key 0 keeps every value: a superset, never a dropped member)
   float lo = -3.402823466e38f, hi = 3.402823466e38f;   // value range still holding the k-th largest (bins are monotone in the value)
   for (int round = 0; round < 64; ++round) {   // (a round narrows [lo, hi] to one of its 256 bins, or ends; every decision is workgroup-uniform)
     float mxv = -INFINITY, mnv = INFINITY;
@@ -110,7 +110,10 @@ __device__ __forceinline__ int wg_sample_topk(const WaveSampleArgs& a, float* ld
     mxv = fmaxf(fmaxf(misc[0], misc[1]), fmaxf(misc[2], misc[3]));
     mnv = fminf(fminf(misc[4], misc[5]), fminf(misc[6], misc[7]));
     const float bs = 255.99f / (mxv - mnv);
-    if (!(mxv > mnv) || !(bs < INFINITY)) { kth_key = f32_key(mxv); break; }   // every remaining candidate has the same value
+    // every remaining candidate has the same value -- or a range too narrow to bin (mxv - mnv denormal: 255.99 / range overflows).  In both
+    // cases the candidates that are left are all KEPT (key of the minimum): for equal values that is the reference's tie rule; for the
+    // unbinnable range it keeps a few values beyond the k-th instead of dropping top-k members (round 5 took the maximum's key there: ADVICE r5)
+    if (!(mxv > mnv) || !(bs < INFINITY)) { kth_key = f32_key(mnv); break; }
 #pragma unroll
     for (int j = 0; j < WS_NJ; ++j) {
       const bool ac = x[j] >= lo && x[j] <= hi;

@@ -142,7 +142,8 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
  *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 6: round 5), "prefetch_seg_sleep"
  *                (its pause per 4 MiB run, default 0 since the decode kernels run at s_setprio 3), "prefetch_budget_us" / "prefetch_rearm" /
- *                "prefetch_force_serial" (streamer health: see csm_prefetch_health), "kernel_prio" (bit mask of the
+ *                "prefetch_force_serial" (streamer health: see csm_prefetch_health), "sample_legacy" (TEST HOOK: csm_sample_topk on the histogram / radix
+ *                selection of rounds 1-4 instead of sample_wave.h's: the two are compared token for token on adversarial rows), "kernel_prio" (bit mask of the
  *                launch families that raise their issue priority: 1 decoder attention + o_proj, 2 GEMV / skinny GEMM, 4 backbone
  *                attention + samplers; default 7), "attn_oproj_gqa" (B = 1 decoder attention + o_proj with the K/V tiles shared by
  *                the query heads of a kv-head), "oproj_combine" / "combine_splits" (B = 1 backbone: split-KV merge inside the o_proj

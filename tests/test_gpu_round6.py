@@ -108,3 +108,46 @@ def test_streamer_of_a_model_that_fits_the_window_ends_with_the_chain():
     _timed_generate(m, ids, mask, 40)
     _, t_off = _timed_generate(m, ids, mask, 40)
     assert t < t_off + 10.0, (t, t_off)
+
+
+def test_wave_sampler_selection_equals_the_legacy_selection_on_adversarial_rows():
+    """since round 5 every top-k call at csm's vocabulary (2 048 <= V <= 2 304) runs sample_wave.h's selection, so the
+    round-5 test compared the new code with itself.  The engine option `sample_legacy` (test hook) sends csm_sample_topk through
+    sample_kernel's histogram / radix selection of rounds 1-4; with explicit Exp(1) noise both must give the oracle's token
+    (reference modeling_csm.py:170-189) on: random rows; 300 equal maxima (every tie is kept); 700 equal values inside the k-th bin
+    (> 256: the bin cannot be ranked in one wave); top-k = V; a row with -inf entries; rows of huge dynamic range.  A row whose range
+    is denormal (cannot be binned) keeps all its candidates instead of dropping top-k members: the token is then the arg-max of
+    p / q over ALL entries."""
+    from oracle import csm_oracle as O
+    cfg, sd, m = tiny_model()
+    ids, mask = synth_context(cfg, 1, 2, 3, seed=1)
+    m.generate(ids.to(DEV), mask.to(DEV), max_new_frames=1, topk=1, stop_on_all_zeros=False)     # an engine to hang the option on
+    eng = m._engine
+    V = 2051
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    rows.append(torch.randn(V, generator=g) * 2.0)
+    t = torch.randn(V, generator=g); t[torch.randperm(V, generator=g)[:300]] = 7.5; rows.append(t)                 # 300 tied maxima
+    t = torch.randn(V, generator=g); t[torch.randperm(V, generator=g)[:700]] = 0.125; rows.append(t)               # 700 equal values mid-range
+    t = torch.randn(V, generator=g) * 1e-3 + 3.0; rows.append(t)                                                   # narrow (but normal) range
+    t = torch.randn(V, generator=g); t[::3] = float("-inf"); rows.append(t)                                        # -inf entries
+    t = torch.randn(V, generator=g) * 30.0; rows.append(t)                                                         # wide range
+    t = torch.full((V,), 0.25); rows.append(t)                                                                     # all equal
+    logits = torch.stack(rows)
+    noise = torch.empty(len(rows), V).exponential_(1, generator=torch.Generator().manual_seed(11))
+    for topk, temp in ((50, 1.0), (5, 0.7), (300, 1.3), (V, 1.0), (1000, 0.9)):
+        want = O.sample_topk(logits, topk, temp, noise=noise).reshape(-1).to(torch.int32)
+        eng.set_option("sample_legacy", 0)
+        wave = eng.k_sample(logits, topk, temp, noise=noise).cpu()
+        eng.set_option("sample_legacy", 1)
+        legacy = eng.k_sample(logits, topk, temp, noise=noise).cpu()
+        eng.set_option("sample_legacy", 0)
+        assert torch.equal(wave, legacy), (topk, temp, wave.tolist(), legacy.tolist())
+        assert torch.equal(wave, want), (topk, temp, wave.tolist(), want.tolist())
+    # denormal range: 255.99 / (max - min) overflows -> no bins; every candidate is kept (round 5 kept only the maximum's ties)
+    den = (torch.arange(V, dtype=torch.float32) * 1e-45).reshape(1, V)
+    assert float(den.max()) > 0 and float(den.max()) < 1.2e-38
+    nz = torch.empty(1, V).exponential_(1, generator=torch.Generator().manual_seed(12))
+    got = int(eng.k_sample(den, 50, 1.0, noise=nz).cpu()[0])
+    keep_all = int(O.sample_topk(den, V, 1.0, noise=nz).reshape(-1)[0])     # p / q over all entries
+    assert got == keep_all, (got, keep_all)
