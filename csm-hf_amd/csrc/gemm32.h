@@ -14,8 +14,32 @@
 // its launches is what counts).  With four tiles the B operands of tile mt+1 are requested while tile mt multiplies (two
 // register sets) instead of all up front.  Round 4: up to 128 rows per launch (BASELINE configs[3]'s 128-row strong leg in ONE
 // engine pass): the batch tiles beyond MT go to further workgroups of the panel (blockIdx.z), shapes in gemm32.hip.
+// Kernel-argument preload (gemv.h GEMV_HOT_PARAMS has the why; gemm16.h G16_HOT_PARAMS is the 16-row form): fragment-order weights, planes,
+// launch counter, position source (EPI_QKV: row_pos if there is one, else pos_ptr; other epilogues: out), the producer's sums of squares,
+// N, K, a packed word and a second one.
+//   packed : bit 0 nt, 1 prio, 2 kfast, 3 the position source is row_pos; bits 8-15 hd, 16-23 n_q, 24-31 n_kv
+//   packed2: bits 0-7 pos_const (0 when a pointer gives the position), 8-15 M, 16-23 KB
+#define G32_HOT_PARAMS const void* hWt, const void* hxp, unsigned* hprog, void* hp3, const float* hxss, int hN, int hK, uint32_t hpk, uint32_t hpk2
+#define G32_HOT_ARGS(a, M_, KB_, EPI_)                                                                                                       \
+  (a).Wt, (const void*)(a).xplanes, (a).prog, ((EPI_) == EPI_QKV ? (void*)((a).row_pos ? (a).row_pos : (a).pos_ptr) : (void*)(a).out), (a).xss, \
+  (a).N, (a).K,                                                                                                                              \
+  (uint32_t)(((a).nt ? 1u : 0u) | ((a).prio ? 2u : 0u) | ((a).kfast ? 4u : 0u) | ((a).row_pos ? 8u : 0u) | (((uint32_t)(a).hd & 255u) << 8) |   \
+             (((uint32_t)(a).n_q & 255u) << 16) | (((uint32_t)(a).n_kv & 255u) << 24)),                                                       \
+  (uint32_t)((((a).row_pos || (a).pos_ptr) ? 0u : ((uint32_t)(a).pos_const & 255u)) | ((uint32_t)(M_) << 8) | ((uint32_t)(KB_) << 16))
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, int MT = 2, bool ONE = false>
-__global__ __launch_bounds__(64 * NW) void gemm32_kernel(GemvArgs a, int M, int KB, float* slabs, int* tickets) {
+__global__ __launch_bounds__(64 * NW) void gemm32_kernel(G32_HOT_PARAMS, GemvArgs a, float* slabs, int* tickets) {
+  a.Wt = hWt; a.xplanes = reinterpret_cast<const bf16_t*>(hxp); a.prog = hprog; a.xss = hxss; a.N = hN; a.K = hK;
+  a.nt = (int)(hpk & 1u); a.prio = (int)((hpk >> 1) & 1u); a.kfast = (int)((hpk >> 2) & 1u);
+  const int M = (int)((hpk2 >> 8) & 255u), KB = (int)((hpk2 >> 16) & 255u);
+  if (EPI == EPI_QKV) {
+    a.pos_const = (int)(hpk2 & 255u);
+    if (hpk & 8u) { a.row_pos = reinterpret_cast<const int*>(hp3); a.pos_ptr = nullptr; }
+    else { a.row_pos = nullptr; a.pos_ptr = reinterpret_cast<const int*>(hp3); }
+    a.hd = (int)((hpk >> 8) & 255u); a.n_q = (int)((hpk >> 16) & 255u); a.n_kv = (int)(hpk >> 24);
+  } else {
+    a.out = reinterpret_cast<float*>(hp3);
+  }
+  if constexpr (!std::is_same<WT, fp8_t>::value) a.wscale = nullptr;
   constexpr int U = PT * MT;   // accumulator tiles per wave: u = t * MT + mt
   extern __shared__ __attribute__((aligned(16))) float lds[];  // red[NW][U][256] | panel[U][256] | flag[16] | stat[16 MT]
   float* red = lds;

@@ -25,7 +25,8 @@ static int launch_g32(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
     }
   }
   if (a.configure_only) return 0;
-  hipLaunchKernelGGL(fn, (KB > 1 && a.kfast) ? dim3(KB, gx, Z) : dim3(gx, KB, Z), dim3(64 * NW), lds, st, a, M, KB, slabs, tickets);
+  if (M > 255 || KB > 255 || (EPI == EPI_QKV && (a.hd > 255 || a.n_q > 255 || a.n_kv > 255 || (!a.row_pos && !a.pos_ptr && (a.pos_const < 0 || a.pos_const > 255))))) return -2;   // packed into the preloaded words (gemm32.h G32_HOT_ARGS)
+  hipLaunchKernelGGL(fn, (KB > 1 && a.kfast) ? dim3(KB, gx, Z) : dim3(gx, KB, Z), dim3(64 * NW), lds, st, G32_HOT_ARGS(a, M, KB, EPI), a, slabs, tickets);
   return (int)hipGetLastError();
 }
 

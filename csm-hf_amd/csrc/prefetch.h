@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
           a.status[4] = (unsigned)e; a.status[5] = (unsigned)want; a.status[6] = (unsigned)cur; a.status[7] = (unsigned)rep;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && skipped && x == 0 && bl == 0 && wave == 1) atomicAdd(a.status + 2, skipped);   // the late-segment sample, also on this exit
         return;
       }
       if (a.skip_late && cur > base + sp->owner) { ++skipped; continue; }   // its consumer is already running: leave it alone
