@@ -253,14 +253,15 @@ struct csm_engine {
   int sample_legacy = 0;           // test hook: csm_sample_topk's top-k on sample_kernel's histogram / radix selection of rounds 1-4
   int pf_force_serial = 0;         // test hook: streamer (and probe) on the ENGINE stream -- the failure mode of two streams on one hardware queue
   int pf_rot = -1;                 // workgroup b of a dispatch runs on XCD (b + pf_rot) % 8; -1 = not round-robin: streamer off
-  int pf_enable = 1, pf_window_mb = 6; static constexpr int pf_sub_kb = 4096, pf_grid = 256;   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
+  int pf_enable = 1, pf_window_mb = 6; int pf_sub_kb = 8192; static constexpr int pf_grid = 256;   // sub: round 6 -- runs of 8 MiB (rounds 2-5: 4): B = 1 2.82 -> 2.72 ms; plateau 6-10 MiB, window 4-12 MiB alike (profiles/r06_streamer_grid.txt)
+  //   // window: round 5 -- 24 MiB (rounds 2-4) only works while the chain
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
   // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
-  static constexpr int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
+  int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
   static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
   static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
-  static constexpr int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
-  static constexpr int pf_depth = 0, pf_poll_sleep = 2;
+  int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
+  int pf_depth = 0, pf_poll_sleep = 2;   // (options again in round 6: re-swept after the kernel-argument preload shortened every launch)
   int pf_seg_sleep = 0;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
   // streamer no longer slows the chain's latency-bound launches: B = 1 3.09 -> 2.95 ms (profiles/r05_b1_budget.md)   // options again in round 5 (prefetch_depth / prefetch_seg_sleep): re-swept at the 6 MiB window
   static constexpr int pf_max_kb = 0;        // > 0: only launches whose matrix is at most this large are streamed whole
@@ -699,6 +700,13 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
+  else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_skip_late")) e->pf_skip_late = value ? 1 : 0;
+  else if (!strcmp(name, "prefetch_depth")) e->pf_depth = value;
+  else if (!strcmp(name, "prefetch_poll_sleep")) e->pf_poll_sleep = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_stride")) e->pf_stride = (value == 64 || value == 128) ? value : 0;
   // streamer health: launch parameters of the streamer, not of the captured frame-step -- the graphs stay
   else if (!strcmp(name, "prefetch_budget_us")) { e->pf_budget_us = value < 100 ? 100 : value; return 0; }
   else if (!strcmp(name, "prefetch_force_serial")) { e->pf_force_serial = value ? 1 : 0; return 0; }
