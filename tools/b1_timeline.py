@@ -145,7 +145,7 @@ for streamer in (1, 0):
                   "body_us": round(agg[k][3] / agg[k][0], 2), "us_per_step": round(agg[k][1] + agg[k][3], 1)} for k in order]
         rec = {"batch": B, "ctx": a.ctx, "topk": a.topk, "launches_per_step": n, "step_us_probe_build": round(tot_gap + tot_body, 1),
                "how": "tools/b1_timeline.py: per-workgroup s_memrealtime at entry / after the last store in the -DCSM_TIMELINE build of the SAME sources "
-                      "(5-6 % slower than the product build), streamer on; gap = previous launch's last end -> first start, body = first start -> last end",
+                      "(round 6: 15-25 % slower than the product build -- the probe's s_memrealtime at kernel entry is a scalar-memory wait in front of the first load, exactly what the kernel-argument preload removed from the product; proportions between launch kinds hold, absolute bodies are ~0.5 us long), streamer on; gap = previous launch's last end -> first start, body = first start -> last end",
                "src_sha256": __import__("csm_hf_amd.build", fromlist=["sources_sha256"]).sources_sha256(),
                "commit": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
                "kinds": kinds}
