@@ -10,7 +10,9 @@
 // its last store into this launch's slot [2048 workgroups][2] of the debug buffer (csm_set_debug_buffer); workgroup 0 tags the
 // slot with the kernel kind and grid size.  Compiled out of the product build (an s_memrealtime at entry is an SMEM wait).
 #ifdef CSM_TIMELINE
-#define TL_BEGIN(ptr) uint32_t* const tl_p_ = (ptr); const uint32_t tl_t0_ = tl_p_ ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u
+// (round 6: the time stamp is taken unconditionally and the slot pointer is only looked at in TL_END -- `ptr ? stamp : 0` made every
+//  kernel of the probe build start with a kernarg read and its wait, i.e. exactly the entry cost the product build no longer has)
+#define TL_BEGIN(ptr) const uint32_t tl_t0_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); uint32_t* const tl_p_ = (ptr)
 #define TL_END(kind)                                                                                                   \
   do {                                                                                                                 \
     if (tl_p_ && threadIdx.x == 0) {                                                                                   \

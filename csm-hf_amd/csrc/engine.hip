@@ -258,8 +258,8 @@ struct csm_engine {
   // never lets the streamer get a full window ahead: after any launch longer than ~3 us (a sampler) the data fetched first is gone again by the time it is read
   // (B = 1 top-k 50: 3.53 ms at 24 MiB, 3.36 at 6; greedy 3.096 -> 3.067); profiles/r05_streamer_window.txt
   int pf_lead = 1;   // 1: the data of the RUNNING launch counts as consumed (all its workgroups issue their loads at once)
-  static constexpr int g16_k16 = 0;      // nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
-  static constexpr int pf_batched = 0;   // 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
+  int g16_k16 = 0;      // (option "g16_k16", A/B) nw | kb << 8 for the K = 2048 (16-chunk) matrix-core launches on planes; 0 = one 16-wave workgroup per panel
+  int pf_batched = 0;   // (option "prefetch_batched", A/B) 1: also pace / stream the matrix-core launches of batched decode (they are `exclusive` for csm-1b: gemm16.h)
   int pf_cofetch = 1, pf_skip_late = 1, pf_stride = 0;
   int pf_depth = 0, pf_poll_sleep = 2;   // (options again in round 6: re-swept after the kernel-argument preload shortened every launch)
   int pf_seg_sleep = 0;   // seg_sleep: 16 until the decode kernels got issue priority (kernel_prio); with it an unthrottled
@@ -700,6 +700,8 @@ extern "C" int csm_set_option(csm_engine_t* e, const char* name, int value) {
   else if (!strcmp(name, "weight_prefetch")) e->pf_enable = value;
   else if (!strcmp(name, "prefetch_window_mb")) e->pf_window_mb = value < 1 ? 1 : value;
   else if (!strcmp(name, "prefetch_seg_sleep")) e->pf_seg_sleep = value < 0 ? 0 : value;
+  else if (!strcmp(name, "prefetch_batched")) e->pf_batched = value ? 1 : 0;
+  else if (!strcmp(name, "g16_k16")) e->g16_k16 = value < 0 ? 0 : value;
   else if (!strcmp(name, "prefetch_sub_kb")) e->pf_sub_kb = value < 64 ? 64 : value;
   else if (!strcmp(name, "prefetch_lead")) e->pf_lead = value ? 1 : 0;
   else if (!strcmp(name, "prefetch_cofetch")) e->pf_cofetch = value ? 1 : 0;

@@ -129,7 +129,7 @@ int csm_build_proj_table(csm_engine_t* e, float* proj_table_out);
 int csm_set_proj_table(csm_engine_t* e, const float* proj_table);
 int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; graphs stay */
 /* Engine options -- the COMPLETE list (ABI 6 removed 36 A/B knobs whose losing variants left the library; round 5 added six names,
- * no entry point: the ABI number is unchanged; an unknown name is CSM_ERR_ARG).  Defaults are the measured best; every call drops the captured graphs.
+ * round 6 the streamer's health / schedule names, "sample_legacy", "g16_k16"; an unknown name is CSM_ERR_ARG).  Defaults are the measured best; every call drops the captured graphs.
  *   precision:   "prefill_bf16" (context activations rounded to bf16), "prefill_mx" (context linears on the MX-fp8 matrix
  *                instruction; needs csm_bind_mx_weights), "prefill_bf16_attn" (context attention on the bf16 pipe in those
  *                modes), "decode_bf16" (batched decode on ONE nearest-even activation plane: the reference's own bf16 class)
@@ -140,8 +140,12 @@ int csm_reset(csm_engine_t* e);   /* reset_caches(): lengths, frame counter; gra
  *                (bit mask: batched activations as MFMA B-operand planes), "rows64" (1: 17-128 rows in ONE launch per linear; 0: 32-row
  *                launches; -1: 16-row launches -- the forms the width tests compare against, bit for bit),
  *                "tile_weights" (fragment-order weight copies of the matrix-core kernel; 0 frees them), "weight_prefetch"
- *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 6: round 5), "prefetch_seg_sleep"
- *                (its pause per 4 MiB run, default 0 since the decode kernels run at s_setprio 3), "prefetch_budget_us" / "prefetch_rearm" /
+ *                (weight streamer on / off), "prefetch_window_mb" (bytes it may run ahead, default 6: round 5), "prefetch_sub_kb" (size of a run of
+ *                consumer workgroups, the unit the schedule is made of: default 8192 since round 6 -- 4096 before; B = 1 2.82 -> 2.73 ms), "prefetch_seg_sleep"
+ *                (its pause per run, default 0 since the decode kernels run at s_setprio 3), "prefetch_lead" / "prefetch_cofetch" / "prefetch_skip_late" /
+ *                "prefetch_depth" / "prefetch_poll_sleep" / "prefetch_stride" (schedule and loader details, defaults 1 / 1 / 1 / 0 / 2 / 0: swept again in round 6,
+ *                profiles/r06_streamer_grid.txt), "prefetch_batched" (A/B: also stream the matrix-core launches of a 2-16-row batch; measured slower, default 0),
+ *                "g16_k16" (A/B: nw | kb << 8 of the K = 2048 matrix-core launches; 0 = one 16-wave workgroup per panel), "prefetch_budget_us" / "prefetch_rearm" /
  *                "prefetch_force_serial" (streamer health: see csm_prefetch_health), "sample_legacy" (TEST HOOK: csm_sample_topk on the histogram / radix
  *                selection of rounds 1-4 instead of sample_wave.h's: the two are compared token for token on adversarial rows), "kernel_prio" (bit mask of the
  *                launch families that raise their issue priority: 1 decoder attention + o_proj, 2 GEMV / skinny GEMM, 4 backbone
