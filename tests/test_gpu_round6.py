@@ -63,7 +63,7 @@ def test_streamer_that_holds_the_chain_up_is_detected_and_switched_off(dtype):
     out0, t0 = _timed_generate(m, ids, mask, n) # the stalled call: the chain waits behind the streamer until it gives up
     assert torch.equal(out0, ref), "a streamer that gave up changed the tokens"
     # it cost one budget, not ten (200 ms in rounds 2-5)
-    assert budget_ms * 0.9 < t0 - t_off < budget_ms + 6.0, (t0, t_off)
+    assert budget_ms * 0.9 < t0 - t_off < 4 * budget_ms, (t0, t_off)      # (ten budgets would be 80 ms; the slack is for a noisy host)
     out1, t1 = _timed_generate(m, ids, mask, n) # finds the give-ups (pinned mirror, no sync), probes (3 ms), switches the streamer off
     assert torch.equal(out1, ref)
     st = eng.prefetch_stats()
@@ -71,14 +71,14 @@ def test_streamer_that_holds_the_chain_up_is_detected_and_switched_off(dtype):
     msg = repr(st)
     assert h["gave_up_total"] > 0, msg
     assert h["disabled"] == 1 and h["probe_runs"] == probes0 + 1, msg      # one give-up, one probe, off
-    assert t1 < t_off + 3.0 + 6.0, (t1, t_off, msg)
+    assert t1 < t_off + 3.0 + 3 * budget_ms, (t1, t_off, msg)
     launches_when_off = h["streamer_launches"]
     out2, t2 = _timed_generate(m, ids, mask, n)
     out3, t3 = _timed_generate(m, ids, mask, n)
     assert torch.equal(out2, ref) and torch.equal(out3, ref)
     h = eng.prefetch_health()
     assert h["streamer_launches"] == launches_when_off, h                 # no streamer launch any more
-    assert min(t2, t3) < t_off + 3.0, (t2, t3, t_off)
+    assert min(t2, t3) < t_off + budget_ms * 0.75, (t2, t3, t_off)       # no budget is paid any more
     # back to concurrent streams: re-armed, healthy again
     eng.set_option("prefetch_force_serial", 0)
     eng.set_option("prefetch_rearm", 1)
@@ -103,7 +103,7 @@ def test_streamer_of_a_model_that_fits_the_window_ends_with_the_chain():
         assert st["gave_up"] == 0 and st["finished"] > 0, repr(st)
         assert st["launches_counted"] == st["frames"] * st["streamed_launches"], repr(st)
     # the join is prompt: the call is not held for a budget by a streamer that outlives the chain
-    _, t = _timed_generate(m, ids, mask, 40)
+    t = min(_timed_generate(m, ids, mask, 40)[1] for _ in range(2))
     m._engine.set_option("weight_prefetch", 0)
     _timed_generate(m, ids, mask, 40)
     _, t_off = _timed_generate(m, ids, mask, 40)

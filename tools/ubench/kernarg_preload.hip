@@ -7,6 +7,7 @@
 //               hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-kernarg-preload-count=14 kernarg_preload.hip -o kp_on
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void k_flat(const float* W, const float* x, fl
   if (rest.pad[7] == 12345) out[0] = rest.other[0];     // keeps the struct alive without touching it on the hot path
 }
 
-int main() {
-  const int K = 1024, NL = 200;
+int main(int argc, char** argv) {
+  const int K = 1024; const int NL = argc > 1 ? atoi(argv[1]) : 200; const int REPL = argc > 2 ? atoi(argv[2]) : 10;
   for (int grid : {256, 1024}) {
     const int rpw = 1;
     const size_t wfloats = (size_t)grid * 4 * rpw * K;
@@ -68,14 +69,14 @@ int main() {
       float best = 1e9f;
       for (int rep = 0; rep < 5; ++rep) {
         CK(hipEventRecord(e0, st));
-        for (int w = 0; w < 10; ++w) CK(hipGraphLaunch(ge, st));
+        for (int w = 0; w < REPL; ++w) CK(hipGraphLaunch(ge, st));
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
       }
-      printf("grid %4d  %s : %.3f us per launch (%d dependent launches x 10 replays, %zu KB of weights per launch)\n", grid,
-             mode == 0 ? "struct by value      " : (mode == 1 ? "flat leading scalars " : "flat + sc0 sc1 stores"), best * 1e3f / (10 * NL), NL, wfloats * 4 / 1024);
+      printf("grid %4d  %s : %.3f us per launch (%d dependent launches per graph, several replays, %zu KB of weights per launch)\n", grid,
+             mode == 0 ? "struct by value      " : (mode == 1 ? "flat leading scalars " : "flat + sc0 sc1 stores"), best * 1e3f / (REPL * NL), NL, wfloats * 4 / 1024);
       CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     CK(hipFree(W)); CK(hipFree(xa)); CK(hipFree(xb));
