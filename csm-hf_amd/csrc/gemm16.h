@@ -114,13 +114,13 @@ __device__ __forceinline__ int g16_row(const GemvArgs& a, int panel, int t, int 
 // Kernel-argument preload (gemv.h GEMV_HOT_PARAMS has the why): the 14 leading dwords carry what a wave needs to request its activation
 // planes and weight fragments -- weights (fragment-order copy if TL), activations (planes if XP), launch counter, position source
 // (EPI_QKV: row_pos if there is one, else pos_ptr; other epilogues: out), norm weights, N, K, a packed word and pos_const.
-//   packed: bit 0 nt, 1 prio, 2 kfast, 3 the position source is row_pos; bits 4-8 M, 9-13 KB, 14-21 hd, 22-27 n_q, 28-31 n_kv
+//   packed: bit 0 nt, 1 prio, 2 kfast, 3 the position source is row_pos; bits 4-8 M, 9-13 KB, 14-18 hd / 8, 19-25 n_q (<= 127), 26-31 n_kv (<= 63)
 #define G16_HOT_PARAMS const void* hW, const void* hx, unsigned* hprog, void* hp3, const float* hln, int hN, int hK, uint32_t hpk, int hi3
 #define G16_HOT_ARGS(a, M_, KB_, TL_, XP_, EPI_)                                                                                              \
   ((TL_) ? (a).Wt : (a).W), ((XP_) ? (const void*)(a).xplanes : (const void*)(a).x), (a).prog,                                                 \
   ((EPI_) == EPI_QKV ? (void*)((a).row_pos ? (a).row_pos : (a).pos_ptr) : (void*)(a).out), (a).ln, (a).N, (a).K,                               \
   (uint32_t)(((a).nt ? 1u : 0u) | ((a).prio ? 2u : 0u) | ((a).kfast ? 4u : 0u) | ((a).row_pos ? 8u : 0u) | ((uint32_t)(M_) << 4) |             \
-             ((uint32_t)(KB_) << 9) | (((uint32_t)(a).hd & 255u) << 14) | (((uint32_t)(a).n_q & 63u) << 22) | (((uint32_t)(a).n_kv & 15u) << 28)), \
+             ((uint32_t)(KB_) << 9) | ((((uint32_t)(a).hd >> 3) & 31u) << 14) | (((uint32_t)(a).n_q & 127u) << 19) | (((uint32_t)(a).n_kv & 63u) << 26)), \
   (a).pos_const
 template <typename WT, typename KT, int PRO, int EPI, int NW, int PT, bool TL, bool XP, bool ONE = false>
 __global__ __launch_bounds__(64 * NW) void gemm16_kernel(G16_HOT_PARAMS, GemvArgs a, float* slabs, int* tickets) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void gemm16_kernel(G16_HOT_PARAMS, GemvArg
     a.pos_const = hi3;
     if (hpk & 8u) { a.row_pos = reinterpret_cast<const int*>(hp3); a.pos_ptr = nullptr; }
     else { a.row_pos = nullptr; a.pos_ptr = reinterpret_cast<const int*>(hp3); }
-    a.hd = (int)((hpk >> 14) & 255u); a.n_q = (int)((hpk >> 22) & 63u); a.n_kv = (int)(hpk >> 28);
+    a.hd = (int)((hpk >> 14) & 31u) << 3; a.n_q = (int)((hpk >> 19) & 127u); a.n_kv = (int)(hpk >> 26);
   } else {
     a.out = reinterpret_cast<float*>(hp3);
   }

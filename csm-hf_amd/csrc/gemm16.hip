@@ -10,7 +10,7 @@ static int launch_g16(hipStream_t st, int M, int KB, const GemvArgs& a, float* s
   if (KB > 1 && ((size_t)gx * KB * PT * 256 > slab_floats || gx > n_tickets)) return -2;
   const size_t lds = ((size_t)NW * PT * 256 + PT * 256 + 16 + NW * 16) * sizeof(float);
   if (a.xplanes && !a.Wt) return -2;   // planes are laid out for the fragment-order k order
-  if (KB > 31 || M > 31 || (EPI == EPI_QKV && (a.hd > 255 || a.n_q > 63 || a.n_kv > 15))) return -2;   // packed into the preloaded word (gemm16.h G16_HOT_ARGS)
+  if (KB > 31 || M > 31 || (EPI == EPI_QKV && (a.hd > 248 || (a.hd & 7) || a.n_q > 127 || a.n_kv > 63))) return -2;   // packed into the preloaded word (gemm16.h G16_HOT_ARGS)
   if (a.geom_out && a.Wt) {            // weight streamer (prefetch.h, kind 2): workgroup (bx, by) -> fragment blocks
     PfGeom& g = *a.geom_out;
     g.W = a.Wt; g.N = a.N; g.K = a.K; g.esz = (int)sizeof(WT); g.kind = 2;
