@@ -401,6 +401,18 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   e->device = device;
   int prio_least = 0, prio_greatest = 0;
   HIPCK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  {
+    // The legacy null stream must own its hardware queue BEFORE the weight streamer's stream is created (round 6, measured:
+    // tools/probes/stream_alloc_probe2.py).  In a process whose first GPU work runs on a side stream (`with torch.cuda.stream(s):` around
+    // everything) the null stream gets its queue only later -- at the first synchronous hipMemcpy of this file -- and the B = 1 frame-step
+    // then runs at 3.16 ms with the streamer on against 3.03 off and 2.73 when the null stream came first; one null-stream operation
+    // here, before the streams below exist, gives 2.72-2.73 in every order.  (Why the order of queue creation matters is not established.)
+    void* z = nullptr;
+    HIPCK(hipMalloc(&z, 256));
+    HIPCK(hipMemsetAsync(z, 0, 256, nullptr));
+    HIPCK(hipStreamSynchronize(nullptr));
+    HIPCK(hipFree(z));
+  }
   if (stream) {
     e->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
