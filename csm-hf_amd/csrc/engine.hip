@@ -249,6 +249,7 @@ struct csm_engine {
   int pf_strikes = 0, pf_clean = 0, pf_probe_runs = 0;
   int pf_disabled = 0;             // 0 on;  1 the two streams share a hardware queue (probe);  2 repeated give-ups with the probe passing;
                                    // 3 dispatch not round-robin over the XCDs;  4 the probe at engine creation failed
+  float pf_rate_base_us = 0.f, pf_rate_beside_us = 0.f;   // dispatch-rate probe: us per empty launch alone / beside a resident kernel on the streamer's stream
   int pf_budget_us = 20000;        // no launch starting for this long while launches are outstanding = a stalled chain
   int sample_legacy = 0;           // test hook: csm_sample_topk's top-k on sample_kernel's histogram / radix selection of rounds 1-4
   int pf_force_serial = 0;         // test hook: streamer (and probe) on the ENGINE stream -- the failure mode of two streams on one hardware queue
@@ -345,6 +346,29 @@ static int pf_probe_concurrency(csm_engine* e, int* seen_out) {
   HIPCK(hipMemcpy(&seen, e->d_pf_misc + 33, sizeof(seen), hipMemcpyDeviceToHost));
   e->pf_probe_runs++;
   *seen_out = (int)seen;
+  if (seen && !e->pf_force_serial) {
+    // Concurrent is not enough (round 6): with the two streams on ONE hardware queue slot (a process with several other active streams:
+    // the runtime multiplexes HIP streams over a few queues) a kernel resident on the streamer's stream let the chain run -- at ~30 us per
+    // launch instead of ~3: an 18 ms frame-step with `gave_up 0`.  So the probe also measures the DISPATCH RATE of the engine stream:
+    // a hipGraph of 128 dependent empty launches alone, then beside a resident spinning kernel (one workgroup per CU) on the streamer's stream.
+    float base = 1e30f, beside = 1e30f;   // the best of three each: a host hiccup between two launches must not look like a slow queue
+    for (int rep = 0; rep < 3; ++rep)
+      for (int pass = 0; pass < 2; ++pass) {
+        HIPCK(hipMemsetAsync(e->d_pf_misc + 32, 0, 2 * sizeof(unsigned), e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        LCK(launch_pf_rate_probe(pass ? e->stream2 : nullptr, e->stream, e->d_pf_misc + 32, e->d_pf_misc + 33, 128, e->ev0, e->ev1));
+        HIPCK(hipStreamSynchronize(e->stream));
+        HIPCK(hipStreamSynchronize(e->stream2));
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        if (pass) beside = std::min(beside, ms); else base = std::min(base, ms);
+      }
+    e->pf_rate_base_us = base * 1e3f / 128.f;
+    e->pf_rate_beside_us = beside * 1e3f / 128.f;
+    // measured: 1.70 us alone, 1.80 beside (+6 %) on separate queues; > 2 x on a shared one (the real chain: 2.7 -> 18-21 ms per step).
+    // (A third state exists that this probe does not see: section 8 of DESIGN.md, the null-stream order.)
+    if (beside > 1.6f * base) *seen_out = 2;   // concurrent, but the chain's launches crawl beside the resident kernel
+  }
   return 0;
 }
 
@@ -368,6 +392,7 @@ static int pf_harvest(csm_engine* e, bool wait) {
   int seen = 0;
   if (int r = pf_probe_concurrency(e, &seen)) return r;
   if (!seen) e->pf_disabled = 1;
+  else if (seen == 2) e->pf_disabled = 5;
   else if (e->pf_strikes >= 2) e->pf_disabled = 2;
   return 0;
 }
@@ -378,6 +403,7 @@ static const char* pf_reason(int r) {
     case 2: return "off: two give-ups within 64 calls although the streams run concurrently";
     case 3: return "off: workgroups are not dispatched round-robin over the XCDs";
     case 4: return "off: the stream-concurrency probe failed at engine creation";
+    case 5: return "off: launches on the engine stream slow down > 1.6 x beside a kernel resident on the streamer's stream (shared hardware queue)";
   }
   return "?";
 }
@@ -525,9 +551,12 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     if (!rr) e->pf_disabled = 3;
     // the streamer must run BESIDE the engine stream: a waiter on stream2 has to see a flag raised by a kernel
     // submitted later on the engine stream.  If the two streams share a hardware queue it times out (3 ms): streamer off.
+    // (Creating another stream for the streamer when the probes fail -- the next one lands on the next hardware queue -- was tried: the
+    // probes then pass, but the frame-step runs at 3.15 ms with the streamer on against 3.03 off; so a failed probe switches it off.)
     int seen = 0;
     if (int pr = pf_probe_concurrency(e, &seen)) return pr;
     if (!seen && e->pf_rot >= 0) { e->pf_rot = -1; e->pf_disabled = 4; }
+    if (seen == 2 && e->pf_rot >= 0) e->pf_disabled = 5;
     HIPCK(hipHostMalloc((void**)&e->h_pf, 40 * sizeof(unsigned), hipHostMallocDefault));
     memset(e->h_pf, 0, 40 * sizeof(unsigned));
   }
@@ -2147,8 +2176,8 @@ extern "C" int csm_prefetch_stats(csm_engine_t* e, long long* out10_host) {
   unsigned dbg[4];
   HIPCK(hipMemcpy(dbg, e->d_pf_misc + 12, sizeof(dbg), hipMemcpyDeviceToHost));
   if (int hr = pf_harvest(e, true)) return hr;
-  snprintf(g_err, sizeof(g_err), "streamer %s; stop record of the last give-up: segment %u want %u seen %u rep %u; retired by the end-of-chain rule %u",
-           pf_reason(e->pf_disabled), dbg[0], dbg[1], dbg[2], dbg[3], st[3]);
+  snprintf(g_err, sizeof(g_err), "streamer %s; dispatch-rate probe %.2f us per empty launch alone, %.2f beside a resident kernel; stop record of the last give-up: segment %u want %u seen %u rep %u; retired by the end-of-chain rule %u",
+           pf_reason(e->pf_disabled), e->pf_rate_base_us, e->pf_rate_beside_us, dbg[0], dbg[1], dbg[2], dbg[3], st[3]);
   return 0;
 }
 

@@ -426,6 +426,30 @@ int launch_pf_concurrency_probe(hipStream_t waiter_stream, hipStream_t setter_st
   hipLaunchKernelGGL(pf_set_kernel, dim3(1), dim3(1), 0, setter_stream, flag);
   return (int)hipGetLastError();
 }
+int launch_pf_rate_probe(hipStream_t waiter_stream, hipStream_t chain_stream, unsigned* flag, unsigned* out, int n, hipEvent_t ev0, hipEvent_t ev1) {
+  // the chain is a hipGraph of dependent launches (dispatched by the command processor at its own rate, like the frame-step: eager
+  // launches are host-bound at ~2 us each and hide what happens between two packets)
+  static thread_local hipGraphExec_t ge = nullptr;
+  static thread_local int ge_n = 0;
+  if (!ge || ge_n != n) {
+    if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(chain_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(pf_nop_kernel, dim3(256), dim3(256), 0, chain_stream, (unsigned*)nullptr);
+    if (hipStreamEndCapture(chain_stream, &g) != hipSuccess || !g) return -1;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); return -1; }
+    hipGraphDestroy(g);
+    ge_n = n;
+    hipGraphLaunch(ge, chain_stream);            // first launch: uploads
+    hipStreamSynchronize(chain_stream);
+  }
+  if (waiter_stream) hipLaunchKernelGGL(pf_wait_kernel, dim3(256), dim3(256), 0, waiter_stream, flag, out, (long long)500000);   // 5 ms; one workgroup per CU like the streamer
+  if (hipEventRecord(ev0, chain_stream) != hipSuccess) return -1;
+  if (hipGraphLaunch(ge, chain_stream) != hipSuccess) return -1;
+  if (hipEventRecord(ev1, chain_stream) != hipSuccess) return -1;
+  hipLaunchKernelGGL(pf_set_kernel, dim3(1), dim3(1), 0, chain_stream, flag);
+  return (int)hipGetLastError();
+}
 int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a) {
   hipLaunchKernelGGL(weight_prefetch_kernel, dim3(grid), dim3(256), 0, st, a);
   return (int)hipGetLastError();

@@ -95,6 +95,7 @@ __global__ void pf_wait_kernel(const unsigned* flag, unsigned* out, long long bu
   *out = seen;
 }
 __global__ void pf_set_kernel(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void pf_nop_kernel(unsigned* sink) { if (sink && threadIdx.x == 1024) *sink = 1u; }
 
 // one poller wave + three loader waves per workgroup
 __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
@@ -279,4 +280,7 @@ __global__ __launch_bounds__(256) void weight_prefetch_kernel(PfArgs a) {
 
 int launch_pf_where(hipStream_t st, unsigned* out8);
 int launch_pf_concurrency_probe(hipStream_t waiter_stream, hipStream_t setter_stream, unsigned* flag, unsigned* out);
+// dispatch-rate probe: `n` dependent empty launches on the chain's stream between two events, with (waiter_stream != nullptr) or without a
+// kernel resident on the streamer's stream (it spins until the flag the chain raises behind the launches, or for 5 ms)
+int launch_pf_rate_probe(hipStream_t waiter_stream, hipStream_t chain_stream, unsigned* flag, unsigned* out, int n, hipEvent_t ev0, hipEvent_t ev1);
 int launch_weight_prefetch(hipStream_t st, int grid, const PfArgs& a);

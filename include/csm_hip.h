@@ -344,7 +344,8 @@ int csm_prefetch_stats(csm_engine_t* e, long long* out10_host);
  * csm_generate (which reads a pinned status mirror -- no synchronisation) re-runs the stream-concurrency probe and switches the
  * streamer off for this engine: the reference loop it feeds (modeling_csm.py:644-690) must never stall behind an optimisation.
  * out8 = {disabled reason: 0 on / 1 the two streams share a hardware queue / 2 two give-ups within 64 calls with the probe passing /
- * 3 workgroups not dispatched round-robin over the XCDs / 4 probe failed at engine creation, strikes, lifetime give-ups
+ * 3 workgroups not dispatched round-robin over the XCDs / 4 probe failed at engine creation / 5 the engine stream's launches slow down
+ * > 1.6 x beside a kernel resident on the streamer's stream (the two share a hardware queue slot: an 18 ms frame-step otherwise), strikes, lifetime give-ups
  * (workgroups), lifetime finished (workgroups), streamer launches, budget (us), probe runs, launches not yet accounted for};
  * the reason as text in csm_last_error().  Waits for the last streamer launch only.  Options: "prefetch_budget_us",
  * "prefetch_rearm" (clears reasons 1 / 2), "prefetch_force_serial" (TEST HOOK: streamer and probe on the engine stream) */

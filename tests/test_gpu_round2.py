@@ -191,6 +191,7 @@ def test_weight_streamer_is_transparent(dtype):
     assert st["launches_counted"] == st["frames"] * st["streamed_launches"], msg   # the end-of-chain rule relies on this
     assert 0 < st["scheduled_bytes"] <= st["streamed_launch_bytes"], msg
     assert st["health"]["disabled"] == 0 and st["health"]["pending"] == 0, msg
+    assert "dispatch-rate probe" in st["note"], msg          # round 6: engine creation also measured the engine stream's dispatch rate beside a resident kernel
     m._engine.set_option("weight_prefetch", 0)
     off = m.generate(ids, mask, max_new_frames=12, topk=1, stop_on_all_zeros=False).cpu()
     assert torch.equal(on, off)
