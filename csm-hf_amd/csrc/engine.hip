@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <string>
 #include <vector>
@@ -118,6 +119,7 @@ struct csm_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t pooled_own = nullptr;   // the engine's own stream of its pooled pair (== stream when the caller passed none)
   csm_weights_t w{};
   bool bound = false;
   Stack bb, dec;
@@ -330,6 +332,16 @@ static int check_stack(const csm_llama_cfg_t& c, const char* name) {
 }
 
 
+// ---- stream pool (round 6) ----
+// The streams of a destroyed engine are kept and handed to the next engine on the same device instead of being destroyed and created
+// anew: which hardware queue slot a HIP stream gets depends on everything the process created before, and the frame-step time depends on
+// the slots of the engine stream and of the streamer's stream (profiles/r06_queue_layout_states.md: an engine that replaced a smaller one
+// -- a short generate() first, then a longer one -- ran at 2.87 ms per step against 2.75 for the first engine of the process).  The first
+// engine of a process gets the good layout; its successors inherit it.  Engines alive at the same time get pairs of their own.
+struct StreamPair { int device; hipStream_t own, s2; };
+static std::mutex g_stream_pool_mu;
+static std::vector<StreamPair> g_stream_pool;
+
 // ---- weight-streamer health (prefetch.h) ----
 // Stream-concurrency probe: a waiter on the streamer's stream must see a flag raised by a kernel submitted AFTER it on the engine
 // stream.  If the two HIP streams share a hardware queue the waiter times out (3 ms) and the streamer, which is submitted ahead of the
@@ -439,11 +451,16 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
     HIPCK(hipStreamSynchronize(nullptr));
     HIPCK(hipFree(z));
   }
+  {
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+      if (g_stream_pool[i].device == device) { e->pooled_own = g_stream_pool[i].own; e->stream2 = g_stream_pool[i].s2; g_stream_pool.erase(g_stream_pool.begin() + i); break; }
+  }
+  if (!e->pooled_own) HIPCK(hipStreamCreateWithPriority(&e->pooled_own, hipStreamNonBlocking, prio_greatest));   // (created even when the caller brings a stream: the pair stays together)
   if (stream) {
     e->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
-    // highest priority: streams of different priority classes never share a hardware queue with the weight streamer
-    HIPCK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_greatest));
+    e->stream = e->pooled_own;
     e->own_stream = true;
   }
   HIPCK(hipEventCreate(&e->ev0));
@@ -534,7 +551,7 @@ extern "C" int csm_engine_create(const csm_config_t* cfg, int device, void* stre
   LCK(launch_set_int(e->stream, e->d_len, 0));
   LCK(launch_set_int(e->stream, e->d_frame, 0));
   // weight streamer: second stream, fork/join events, launch counter, and the dispatcher's workgroup -> XCD rotation
-  HIPCK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_least));
+  if (!e->stream2) HIPCK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_least));
   HIPCK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   if ((r = dalloc(e, &e->d_prog, 16)) || (r = dalloc(e, &e->d_pf_misc, 64))) return r;
@@ -581,7 +598,6 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   drop_graphs(e);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
-  if (e->stream2) hipStreamDestroy(e->stream2);
   if (e->h_pf) hipHostFree(e->h_pf);
   for (void* p : e->allocs) hipFree(p);
   if (e->shift_kt) hipFree(e->shift_kt);
@@ -589,7 +605,14 @@ extern "C" int csm_engine_destroy(csm_engine_t* e) {
   drop_tiled(e);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream) hipStreamDestroy(e->stream);
+  if (e->pooled_own && e->stream2) {   // the pair goes back to the pool (both streams are idle: synchronised above)
+    hipStreamSynchronize(e->pooled_own);
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_stream_pool.push_back(StreamPair{e->device, e->pooled_own, e->stream2});
+  } else {
+    if (e->stream2) hipStreamDestroy(e->stream2);
+    if (e->pooled_own) hipStreamDestroy(e->pooled_own);
+  }
   delete e;
   return 0;
 }
