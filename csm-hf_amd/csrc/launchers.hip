@@ -430,8 +430,10 @@ int launch_pf_rate_probe(hipStream_t waiter_stream, hipStream_t chain_stream, un
   // the chain is a hipGraph of dependent launches (dispatched by the command processor at its own rate, like the frame-step: eager
   // launches are host-bound at ~2 us each and hide what happens between two packets)
   static thread_local hipGraphExec_t ge = nullptr;
-  static thread_local int ge_n = 0;
-  if (!ge || ge_n != n) {
+  static thread_local int ge_n = 0, ge_dev = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (!ge || ge_n != n || ge_dev != dev) {   // (one cached probe graph per thread; rebuilt for another device)
     if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(chain_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
@@ -440,6 +442,7 @@ int launch_pf_rate_probe(hipStream_t waiter_stream, hipStream_t chain_stream, un
     if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(g); return -1; }
     hipGraphDestroy(g);
     ge_n = n;
+    ge_dev = dev;
     hipGraphLaunch(ge, chain_stream);            // first launch: uploads
     hipStreamSynchronize(chain_stream);
   }
