@@ -139,3 +139,17 @@ def test_graft_entry_build_runs():
     engine.ABI_VERSION -- it asserted a literal 3 after the ABI had moved to 4 and failed the check for a while"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_every_engine_option_is_documented_in_the_header():
+    """include/csm_hip.h calls its option list COMPLETE: every name csm_set_option accepts (csrc/engine.hip) must appear there."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "csm-hf_amd", "csrc", "engine.hip")).read()
+    body = src[src.index('extern "C" int csm_set_option'):]
+    body = body[:body.index("\n}\n")]
+    names = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', body))
+    assert len(names) > 40, names
+    hdr = open(os.path.join(root, "include", "csm_hip.h")).read()
+    missing = sorted(n for n in names if f'"{n}"' not in hdr)
+    assert not missing, f"options accepted by csm_set_option but not documented in include/csm_hip.h: {missing}"
