@@ -36,13 +36,18 @@ def _build_lib():
 # so that a late failure cannot hide the parity evidence behind `-x`.
 _ORDER = ["test_gpu_default_mode.py", "test_gpu_generate.py", "test_gpu_kernels.py", "test_gpu_round6.py", "test_gpu_round5.py", "test_gpu_round4.py",
           "test_gpu_round2.py", "test_gpu_round3.py", "test_mimi.py"]
-_LAST = ("test_sampling_from_torchs_global_generator", "test_bench_", "sampling_distribution", "test_csm1b_config5_mxfp8_prefill_pinned")
+_LAST = ("test_sampling_from_torchs_global_generator", "sampling_distribution", "test_csm1b_config5_mxfp8_prefill_pinned")
+# BASELINE configs[3] through the real engine on several ranks (bench.py under gloo / RCCL on one device): right behind the parity and
+# streamer-health files, ahead of the feature suites (they were unreached in round 5)
+_MULTI_RANK = ("test_bench_two_ranks", "test_bench_eight_ranks", "test_bench_under_rccl")
 
 
 def pytest_collection_modifyitems(session, config, items):
     def key(it):
         f = os.path.basename(str(it.fspath))
         rank = _ORDER.index(f) if f in _ORDER else len(_ORDER)
+        if any(t in it.name for t in _MULTI_RANK):
+            rank = _ORDER.index("test_gpu_round6.py") + 0.5
         late = any(t in it.name for t in _LAST)
         return (1 if late else 0, rank)
     items.sort(key=key)      # stable: the order inside a file is kept
